@@ -1,0 +1,310 @@
+"""Thin Python handles over the C ABI (include/dust_hip.h) for tests and bench.py.
+
+Names follow the reference's surface: Tree (crates/vdb/src/tree.rs), VoxLoader/VoxGeometry
+(crates/vox/src/{loader,geometry}.rs), StandardPipeline/GBuffer/PinholeProjection/Sunlight
+(crates/render/src/pipeline/standard.rs, projection.rs, pipeline/sky.rs). The C++ mirror of the same
+surface, which is what a Rust maintainer would read, is include/dust_hip.hpp.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+BLOCK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("w", "<u2"), ("mask", "<u8"),
+                        ("material_ptr", "<u4"), ("avg_albedo", "<u4")])
+assert BLOCK_DTYPE.itemsize == 24
+
+PLANE_DTYPES = {
+    L.PLANE_ILLUMINANCE: (np.uint16, 4), L.PLANE_DENOISED: (np.uint16, 4), L.PLANE_ALBEDO: (np.uint32, 1),
+    L.PLANE_NORMAL: (np.uint32, 1), L.PLANE_DEPTH: (np.float32, 1), L.PLANE_MOTION: (np.uint16, 4),
+    L.PLANE_VOXEL_ID: (np.uint32, 1), L.PLANE_ACCUM: (np.float32, 4),
+}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Tree:
+    """dust_vdb::Tree<hierarchy!(...)> (crates/vdb/src/tree.rs:7-124)."""
+
+    def __init__(self, *fanout_log2):
+        self._lib = L.load()
+        arr = (C.c_uint32 * len(fanout_log2))(*fanout_log2)
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_vdb_tree_create(arr, len(fanout_log2), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_vdb_tree_destroy(self._h)
+            self._h = None
+
+    def set_value(self, xyz, value):
+        v = -1 if value is None else (1 if value else 0)
+        L.check(self._lib.dust_vdb_tree_set(self._h, int(xyz[0]), int(xyz[1]), int(xyz[2]), v))
+
+    def get_value(self, xyz):
+        out = C.c_int32()
+        L.check(self._lib.dust_vdb_tree_get(self._h, int(xyz[0]), int(xyz[1]), int(xyz[2]), C.byref(out)))
+        return None if out.value < 0 else bool(out.value)
+
+    def iter(self):
+        n = C.c_size_t()
+        L.check(self._lib.dust_vdb_tree_iter(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.uint32)
+        L.check(self._lib.dust_vdb_tree_iter(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n)))
+        return out[: n.value]
+
+    def iter_leaf(self):
+        n = C.c_size_t()
+        L.check(self._lib.dust_vdb_tree_iter_leaf(self._h, None, None, None, 0, C.byref(n)))
+        k = max(n.value, 1)
+        xyz = np.zeros((k, 3), np.uint32)
+        occ = np.zeros(k, np.uint64)
+        mat = np.zeros(k, np.uint32)
+        L.check(self._lib.dust_vdb_tree_iter_leaf(self._h, xyz.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                  occ.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                  mat.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n)))
+        return xyz[: n.value], occ[: n.value], mat[: n.value]
+
+    def meta(self):
+        mask, lvl = C.c_uint32(), C.c_uint32()
+        L.check(self._lib.dust_vdb_tree_meta(self._h, C.byref(mask), C.byref(lvl)))
+        return mask.value, lvl.value
+
+    def accessor(self):
+        return Accessor(self)
+
+
+class Accessor:
+    """dust_vdb::Accessor (crates/vdb/src/accessor.rs:5-57)."""
+
+    def __init__(self, tree):
+        self._tree = tree
+        self._lib = tree._lib
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_vdb_accessor_create(tree._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_vdb_accessor_destroy(self._h)
+            self._h = None
+
+    def get(self, xyz):
+        out = C.c_int32()
+        L.check(self._lib.dust_vdb_accessor_get(self._h, int(xyz[0]), int(xyz[1]), int(xyz[2]), C.byref(out)))
+        return None if out.value < 0 else bool(out.value)
+
+
+def lca_level(a, b, mask, root_level):
+    lib = L.load()
+    aa = (C.c_uint32 * 3)(*[int(v) for v in a])
+    bb = (C.c_uint32 * 3)(*[int(v) for v in b])
+    return lib.dust_vdb_lca_level(aa, bb, mask, root_level)
+
+
+def flatten_model(xyzi, size, palette256):
+    """load_model + VoxGeometry::from_tree (loader.rs:238-308, geometry.rs:55-179) -> (blocks, materials)."""
+    lib = L.load()
+    xyzi = np.ascontiguousarray(xyzi, np.uint8).reshape(-1, 4)
+    pal = np.ascontiguousarray(palette256, np.uint8).reshape(256, 4)
+    sz = (C.c_uint32 * 3)(*[int(v) for v in size])
+    blocks = C.POINTER(L.Block)()
+    mats = C.POINTER(C.c_uint8)()
+    nb, nm = C.c_uint32(), C.c_uint64()
+    L.check(lib.dust_vox_flatten_model(_ptr(xyzi), xyzi.shape[0], sz, _ptr(pal), C.byref(blocks), C.byref(nb),
+                                       C.byref(mats), C.byref(nm)))
+    try:
+        b = np.frombuffer(C.string_at(blocks, nb.value * 24), BLOCK_DTYPE).copy()
+        m = np.frombuffer(C.string_at(mats, nm.value), np.uint8).copy()
+    finally:
+        lib.dust_vox_free(blocks)
+        lib.dust_vox_free(mats)
+    return b, m
+
+
+class VoxScene:
+    """What VoxLoader::load yields before upload (loader.rs:322-415): models, palette, instances."""
+
+    def __init__(self, data: bytes):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        buf = np.frombuffer(data, np.uint8)
+        L.check(self._lib.dust_vox_load(_ptr(buf), buf.size, C.byref(self._h)))
+        nm, ni = C.c_uint32(), C.c_uint32()
+        L.check(self._lib.dust_vox_scene_counts(self._h, C.byref(nm), C.byref(ni)))
+        self.n_models, self.n_instances = nm.value, ni.value
+        pal = C.POINTER(C.c_uint8)()
+        L.check(self._lib.dust_vox_scene_palette(self._h, C.byref(pal)))
+        self.palette = np.frombuffer(C.string_at(pal, 1024), np.uint8).reshape(256, 4).copy()
+        inst = (L.VoxInstance * max(ni.value, 1))()
+        L.check(self._lib.dust_vox_scene_instances(self._h, inst, ni.value))
+        self.instances = [(inst[i].model, np.array(inst[i].obj_to_world, np.float32)) for i in range(ni.value)]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_vox_scene_destroy(self._h)
+            self._h = None
+
+    def model_info(self, i):
+        info = L.VoxModelInfo()
+        L.check(self._lib.dust_vox_scene_model_info(self._h, i, C.byref(info)))
+        return info
+
+    def model_data(self, i):
+        info = self.model_info(i)
+        blocks = C.POINTER(L.Block)()
+        mats = C.POINTER(C.c_uint8)()
+        L.check(self._lib.dust_vox_scene_model_data(self._h, i, C.byref(blocks), C.byref(mats)))
+        b = np.frombuffer(C.string_at(blocks, info.n_blocks * 24), BLOCK_DTYPE).copy() if info.n_blocks else np.zeros(0, BLOCK_DTYPE)
+        m = np.frombuffer(C.string_at(mats, info.n_materials), np.uint8).copy() if info.n_materials else np.zeros(0, np.uint8)
+        return b, m
+
+
+class PinholeProjection:
+    """crates/render/src/projection.rs:3-29"""
+
+    def __init__(self, fov=math.pi / 4, near=0.1, far=10000.0):
+        self.fov, self.near, self.far = fov, near, far
+
+
+def look_at_rotation(eye, target, up=(0.0, 1.0, 0.0)):
+    """Rotation of a camera looking from eye to target (columns = camera x, y, z axes; -z is forward),
+    as Transform::looking_at builds it for the FPS camera of examples/castle.rs:120-129."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    back = eye - target
+    back /= np.linalg.norm(back)
+    right = np.cross(up, back)
+    right /= np.linalg.norm(right)
+    up2 = np.cross(back, right)
+    return np.stack([right, up2, back], axis=1).astype(np.float32)  # columns
+
+
+def make_camera(eye, rotation_cols, projection: PinholeProjection):
+    """CameraSettings members the shaders read (standard.rs:277-302)."""
+    cam = L.Camera()
+    r = np.asarray(rotation_cols, np.float32)
+    cam.view_col0[:] = r[:, 0].tolist()
+    cam.view_col1[:] = r[:, 1].tolist()
+    cam.view_col2[:] = r[:, 2].tolist()
+    cam.position[:] = [float(np.float32(v)) for v in eye]
+    cam.tan_half_fov = float(np.float32(np.tan(np.float32(projection.fov) / np.float32(2.0))))
+    cam.far_ = projection.far
+    cam.near_ = projection.near
+    return cam
+
+
+class Context:
+    def __init__(self, device=-1, timing=True, stream=None, lds_root_bytes=0):
+        self._lib = L.load()
+        cfg = L.Config(C.sizeof(L.Config), device, stream, lds_root_bytes, L.CONTEXT_TIMING if timing else 0)
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_hip_context_create(C.byref(cfg), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_hip_context_destroy(self._h)
+            self._h = None
+
+    def sync(self):
+        L.check(self._lib.dust_hip_sync(self._h))
+
+
+class Model:
+    """VoxGeometry + PaletteMaterial on the device."""
+
+    def __init__(self, ctx, blocks, materials, palette, tree_extent_log2=8):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        blocks = np.ascontiguousarray(blocks, BLOCK_DTYPE)
+        materials = np.ascontiguousarray(materials, np.uint8)
+        pal = np.ascontiguousarray(np.asarray(palette, np.uint8).reshape(-1, 4)[:255])
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_hip_model_create(ctx._h, _ptr(blocks), blocks.size, _ptr(materials), materials.size,
+                                                _ptr(pal), tree_extent_log2, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_hip_model_destroy(self._h)
+            self._h = None
+
+
+class Scene:
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._models = []
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_hip_scene_create(ctx._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_hip_scene_destroy(self._h)
+            self._h = None
+
+    def add_instance(self, model, obj_to_world, prev=None):
+        m = np.ascontiguousarray(obj_to_world, np.float32).reshape(12)
+        p = None if prev is None else np.ascontiguousarray(prev, np.float32).reshape(16)
+        idx = C.c_uint32()
+        L.check(self._lib.dust_hip_scene_add_instance(
+            self._h, model._h, m.ctypes.data_as(C.POINTER(C.c_float)),
+            None if p is None else p.ctypes.data_as(C.POINTER(C.c_float)), C.byref(idx)))
+        self._models.append(model)
+        return idx.value
+
+    def commit(self):
+        L.check(self._lib.dust_hip_scene_commit(self._h))
+
+
+class StandardPipeline:
+    """StandardPipeline (crates/render/src/pipeline/standard.rs:51-60, :222-240) + its GBuffer (:881-917)."""
+
+    PRIMARY_RAYTYPE = 0
+    AMBIENT_OCCLUSION_RAYTYPE = 1
+    FINAL_GATHER_RAYTYPE = 2
+    SURFEL_RAYTYPE = 3
+
+    def __init__(self, ctx, width, height):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self.width, self.height = width, height
+        self._h = C.c_void_p()
+        L.check(self._lib.dust_hip_pipeline_create(ctx._h, width, height, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_hip_pipeline_destroy(self._h)
+            self._h = None
+
+    def set_noise(self, texture, texels):
+        t = np.ascontiguousarray(texels, np.uint8)
+        layers = t.size // (128 * 128 * (1 if texture == 0 else 4))
+        L.check(self._lib.dust_hip_pipeline_set_noise(self._h, texture, _ptr(t), layers))
+
+    def render(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
+        s = L.Sky()
+        s.state[:] = np.asarray(sky, np.float32).reshape(56).tolist()
+        fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1])
+        L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
+
+    def pass_stats(self, index):
+        st = L.PassStats()
+        L.check(self._lib.dust_hip_pipeline_pass_stats(self._h, index, C.byref(st)))
+        return st
+
+    def read_plane(self, plane):
+        dt, ch = PLANE_DTYPES[plane]
+        shape = (self.height, self.width, ch) if ch > 1 else (self.height, self.width)
+        out = np.zeros(shape, dt)
+        L.check(self._lib.dust_hip_pipeline_read_plane(self._h, plane, _ptr(out), out.nbytes))
+        return out
+
+    def plane_device_ptr(self, plane):
+        p, n = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.dust_hip_pipeline_plane_device_ptr(self._h, plane, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def clear(self):
+        L.check(self._lib.dust_hip_pipeline_clear(self._h))

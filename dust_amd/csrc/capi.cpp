@@ -1,0 +1,759 @@
+// capi.cpp -- the extern "C" boundary (include/dust_hip.h) and the host runtime behind it:
+// device-side VDB hierarchy build, instance records, persistent pipeline buffers, pass scheduling.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dust_dev.h"
+#include "vdb.hpp"
+#include "vox.hpp"
+
+namespace dust {
+hipError_t launch_primary(const FrameArgs&, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_ambient_occlusion(const FrameArgs&, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_accumulate(const FrameArgs&, hipStream_t);
+hipError_t configure_kernels(size_t max_lds);
+}  // namespace dust
+
+namespace {
+
+thread_local std::string g_last_error;
+
+DustStatus fail(DustStatus s, const std::string& msg) {
+  g_last_error = msg;
+  return s;
+}
+DustStatus hip_fail(hipError_t e, const char* what) {
+  return fail(DUST_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+template <class F>
+DustStatus guarded(F&& f) {  // nothing may unwind across the C boundary
+  try {
+    return f();
+  } catch (const dust::vox::ParseError& e) {
+    return fail(e.unsupported ? DUST_ERR_UNSUPPORTED : DUST_ERR_PARSE, e.what);
+  } catch (const std::bad_alloc&) {
+    return fail(DUST_ERR_OUT_OF_MEMORY, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(DUST_ERR_INVALID_ARGUMENT, e.what());
+  } catch (...) {
+    return fail(DUST_ERR_INVALID_ARGUMENT, "unknown error");
+  }
+}
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    return hipMalloc(&p, n ? n : 16);
+  }
+  hipError_t upload(const void* src, size_t n) {
+    hipError_t e = alloc(n);
+    if (e != hipSuccess || n == 0) return e;
+    return hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+  }
+};
+
+}  // namespace
+
+struct DustVdbTree { dust::vdb::Tree tree; DustVdbTree(const uint32_t* f, int n) : tree(f, n) {} };
+struct DustVdbAccessor { dust::vdb::Tree::Accessor acc; explicit DustVdbAccessor(const dust::vdb::Tree& t) : acc(t) {} };
+struct DustVdbPool { dust::vdb::Pool pool; DustVdbPool(size_t b, unsigned c) : pool(b, c) {} };
+struct DustVoxScene { dust::vox::Scene scene; };
+
+struct DustHipContext {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint32_t lds_root_bytes = 64 * 1024;
+  bool timing = false;
+  int num_cus = 256;
+  size_t max_lds = 64 * 1024;
+};
+
+struct DustHipModel {
+  DustHipContext* ctx = nullptr;
+  DeviceBuffer root, l2, mid, brick_mask, blocks, materials, palette;
+  dust::DevModel dev{};
+  uint32_t id = 0;
+};
+
+struct HostInstance {
+  const DustHipModel* model;
+  float o2w[12];
+  float prev[16];
+};
+
+struct DustHipScene {
+  DustHipContext* ctx = nullptr;
+  std::vector<HostInstance> instances;
+  std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
+  DeviceBuffer d_models, d_instances;
+  uint32_t n_lds_models = 0;
+  bool committed = false;
+};
+
+struct DustHipPipeline {
+  DustHipContext* ctx = nullptr;
+  uint32_t width = 0, height = 0;
+  DeviceBuffer planes[DUST_PLANE_COUNT];
+  DeviceBuffer noise0, noise5, counters, stats;
+  uint32_t noise0_layers = 0, noise5_layers = 0;
+  uint32_t accum_count = 0;
+  hipEvent_t ev[8] = {};
+  bool ev_valid[4] = {false, false, false, false};  // primary, ao
+  bool stats_valid = false;
+  dust::DevStats host_stats[4] = {};
+};
+
+static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16};
+
+// ------------------------------------------------------------------ device hierarchy build
+namespace {
+
+struct N16Builder {
+  std::vector<uint8_t> bytes;  // kN16Bytes per node
+  uint8_t* node(size_t i) { return bytes.data() + i * dust::kN16Bytes; }
+  size_t add() {
+    bytes.resize(bytes.size() + dust::kN16Bytes, 0);
+    return bytes.size() / dust::kN16Bytes - 1;
+  }
+  void finish(size_t i, uint32_t child_base) {  // rank prefix per 64-bit word + base of the first child
+    uint64_t* mask = reinterpret_cast<uint64_t*>(node(i));
+    uint16_t* pre = reinterpret_cast<uint16_t*>(node(i) + 512);
+    uint32_t run = 0;
+    for (int w = 0; w < 64; ++w) {
+      pre[w] = static_cast<uint16_t>(run);
+      run += static_cast<uint32_t>(__builtin_popcountll(mask[w]));
+    }
+    std::memcpy(node(i) + 640, &child_base, 4);
+  }
+};
+
+// Builds root / l2 / mid arrays from blocks given in Tree::iter_leaf order (depth-first, ascending bits).
+DustStatus build_hierarchy(const DustHipBlock* blocks, uint32_t n, uint32_t extent_log2, N16Builder& root,
+                           N16Builder& l2, std::vector<dust::DevN4>& mid, std::vector<uint64_t>& brick_mask,
+                           float bmin[3], float bmax[3]) {
+  const bool deep = extent_log2 == 12;
+  const uint32_t extent = 1u << extent_log2;
+  root.add();
+  brick_mask.resize(n);
+  uint64_t prev_key = 0;
+  int64_t cur_l2 = -1, cur_mid = -1;
+  uint32_t cur_l2_cell = 0xFFFFFFFFu, cur_mid_cell = 0xFFFFFFFFu;
+  for (int a = 0; a < 3; ++a) { bmin[a] = 1e30f; bmax[a] = -1e30f; }
+  auto idx16 = [](uint32_t x, uint32_t y, uint32_t z) { return (x << 8) | (y << 4) | z; };
+  for (uint32_t i = 0; i < n; ++i) {
+    const DustHipBlock& b = blocks[i];
+    if ((b.x & 3) || (b.y & 3) || (b.z & 3) || b.x >= extent || b.y >= extent || b.z >= extent)
+      return fail(DUST_ERR_INVALID_ARGUMENT, "block position is not a 4-aligned coordinate inside the tree extent");
+    if (b.mask == 0) return fail(DUST_ERR_INVALID_ARGUMENT, "block with empty occupancy mask");
+    // depth-first order key: per level, x slowest (node/internal.rs:78-81)
+    uint64_t key = 0;
+    const uint32_t shifts_deep[3] = {8, 4, 2}, bits_deep[3] = {4, 4, 2};
+    const uint32_t shifts_std[2] = {4, 2}, bits_std[2] = {4, 2};
+    const uint32_t* sh = deep ? shifts_deep : shifts_std;
+    const uint32_t* bt = deep ? bits_deep : bits_std;
+    const int nl = deep ? 3 : 2;
+    for (int l = 0; l < nl; ++l) {
+      const uint32_t m = (1u << bt[l]) - 1;
+      key = (key << (3 * bt[l])) | (uint64_t(((b.x >> sh[l]) & m)) << (2 * bt[l])) | (uint64_t((b.y >> sh[l]) & m) << bt[l]) |
+            uint64_t((b.z >> sh[l]) & m);
+    }
+    if (i > 0 && key <= prev_key)
+      return fail(DUST_ERR_INVALID_ARGUMENT, "blocks are not in Tree::iter_leaf order (depth-first, ascending child bits)");
+    prev_key = key;
+    brick_mask[i] = b.mask;
+    const float p[3] = {float(b.x), float(b.y), float(b.z)};
+    for (int a = 0; a < 3; ++a) {
+      bmin[a] = std::min(bmin[a], p[a]);
+      bmax[a] = std::max(bmax[a], p[a] + 4.0f);
+    }
+    // descend, creating nodes on first touch (children of a node are contiguous because of the order)
+    size_t n16 = 0;           // node holding the 16-cell bit
+    N16Builder* holder = &root;
+    if (deep) {
+      const uint32_t cell = idx16(b.x >> 8, b.y >> 8, b.z >> 8);
+      if (cell != cur_l2_cell) {
+        cur_l2 = int64_t(l2.add());
+        cur_l2_cell = cell;
+        dust::vdb::bit_set(reinterpret_cast<uint64_t*>(root.node(0)), cell, true);
+        cur_mid_cell = 0xFFFFFFFFu;
+      }
+      holder = &l2;
+      n16 = size_t(cur_l2);
+    }
+    const uint32_t cell16 = idx16((b.x >> 4) & 15, (b.y >> 4) & 15, (b.z >> 4) & 15);
+    const uint32_t mid_cell_key = deep ? uint32_t(cur_l2) * 4096u + cell16 : cell16;
+    if (mid_cell_key != cur_mid_cell) {
+      dust::vdb::bit_set(reinterpret_cast<uint64_t*>(holder->node(n16)), cell16, true);
+      dust::DevN4 nd{0, 0, i, 0};
+      mid.push_back(nd);
+      cur_mid = int64_t(mid.size()) - 1;
+      cur_mid_cell = mid_cell_key;
+    }
+    const uint32_t bit = (((b.x >> 2) & 3) << 4) | (((b.y >> 2) & 3) << 2) | ((b.z >> 2) & 3);
+    if (bit < 32) mid[size_t(cur_mid)].mask_lo |= 1u << bit;
+    else mid[size_t(cur_mid)].mask_hi |= 1u << (bit - 32);
+  }
+  // prefixes and child bases: children were appended in order, so base = running count
+  if (deep) {
+    root.finish(0, 0);
+    uint32_t run = 0;
+    for (size_t i = 0; i < l2.bytes.size() / dust::kN16Bytes; ++i) {
+      l2.finish(i, run);
+      const uint64_t* mask = reinterpret_cast<const uint64_t*>(l2.node(i));
+      for (int w = 0; w < 64; ++w) run += uint32_t(__builtin_popcountll(mask[w]));
+    }
+  } else {
+    root.finish(0, 0);
+  }
+  if (n == 0) { for (int a = 0; a < 3; ++a) { bmin[a] = 0.0f; bmax[a] = 0.0f; } }
+  return DUST_OK;
+}
+
+// inverse of a 3x4 affine transform, evaluated in double and rounded once
+void invert_affine(const float m[12], float out[12]) {
+  const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double id = 1.0 / det;
+  const double r[9] = {A * id, -(b * i - c * h) * id, (b * f - c * e) * id,
+                       B * id, (a * i - c * g) * id, -(a * f - c * d) * id,
+                       C * id, -(a * h - b * g) * id, (a * e - b * d) * id};
+  const double tx = m[3], ty = m[7], tz = m[11];
+  for (int k = 0; k < 3; ++k) {
+    out[k * 4 + 0] = float(r[k * 3 + 0]); out[k * 4 + 1] = float(r[k * 3 + 1]); out[k * 4 + 2] = float(r[k * 3 + 2]);
+    out[k * 4 + 3] = float(-(r[k * 3 + 0] * tx + r[k * 3 + 1] * ty + r[k * 3 + 2] * tz));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dust_hip_last_error(void) { return g_last_error.c_str(); }
+
+int dust_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ===================================================================== vdb
+DustStatus dust_vdb_tree_create(const uint32_t* fanout_log2, uint32_t n_levels, DustVdbTree** out) {
+  if (!fanout_log2 || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] { *out = new DustVdbTree(fanout_log2, int(n_levels)); return DUST_OK; });
+}
+void dust_vdb_tree_destroy(DustVdbTree* t) { delete t; }
+DustStatus dust_vdb_tree_set(DustVdbTree* t, uint32_t x, uint32_t y, uint32_t z, int32_t value) {
+  if (!t) return fail(DUST_ERR_INVALID_ARGUMENT, "null tree");
+  const uint32_t e = 1u << t->tree.extent_log2();
+  if (x >= e || y >= e || z >= e) return fail(DUST_ERR_INVALID_ARGUMENT, "coordinate outside the tree extent");
+  return guarded([&] {
+    if (!t->tree.set(x, y, z, value < 0 ? -1 : (value ? 1 : 0)))
+      return fail(DUST_ERR_UNSUPPORTED, "clearing voxels through internal nodes is todo!() in the reference");
+    return DUST_OK;
+  });
+}
+DustStatus dust_vdb_tree_get(const DustVdbTree* t, uint32_t x, uint32_t y, uint32_t z, int32_t* value) {
+  if (!t || !value) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  const uint32_t e = 1u << t->tree.extent_log2();
+  if (x >= e || y >= e || z >= e) return fail(DUST_ERR_INVALID_ARGUMENT, "coordinate outside the tree extent");
+  *value = t->tree.get(x, y, z);
+  return DUST_OK;
+}
+DustStatus dust_vdb_tree_iter(const DustVdbTree* t, uint32_t* xyz, size_t cap, size_t* count) {
+  if (!t || !count) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  size_t n = 0;
+  t->tree.for_each_voxel([&](uint32_t x, uint32_t y, uint32_t z) {
+    if (xyz && n < cap) { xyz[n * 3] = x; xyz[n * 3 + 1] = y; xyz[n * 3 + 2] = z; }
+    ++n;
+  });
+  *count = n;
+  return DUST_OK;
+}
+DustStatus dust_vdb_tree_iter_leaf(const DustVdbTree* t, uint32_t* xyz, uint64_t* occupancy, uint32_t* material_ptr,
+                                   size_t cap, size_t* count) {
+  if (!t || !count) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  size_t n = 0;
+  t->tree.for_each_leaf([&](dust::vdb::LeafRef& l) {
+    if (n < cap) {
+      if (xyz) { xyz[n * 3] = l.origin[0]; xyz[n * 3 + 1] = l.origin[1]; xyz[n * 3 + 2] = l.origin[2]; }
+      if (occupancy) occupancy[n] = l.occupancy;
+      if (material_ptr) material_ptr[n] = *l.material_ptr;
+    }
+    ++n;
+  });
+  *count = n;
+  return DUST_OK;
+}
+DustStatus dust_vdb_tree_meta(const DustVdbTree* t, uint32_t* meta_mask, uint32_t* root_level) {
+  if (!t) return fail(DUST_ERR_INVALID_ARGUMENT, "null tree");
+  if (meta_mask) *meta_mask = t->tree.meta_mask();
+  if (root_level) *root_level = uint32_t(t->tree.root_level());
+  return DUST_OK;
+}
+uint32_t dust_vdb_lca_level(const uint32_t a[3], const uint32_t b[3], uint32_t meta_mask, uint32_t root_level) {
+  return dust::vdb::Tree::lca_level(a, b, meta_mask, root_level);
+}
+DustStatus dust_vdb_accessor_create(const DustVdbTree* t, DustVdbAccessor** out) {
+  if (!t || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] { *out = new DustVdbAccessor(t->tree); return DUST_OK; });
+}
+void dust_vdb_accessor_destroy(DustVdbAccessor* a) { delete a; }
+DustStatus dust_vdb_accessor_get(DustVdbAccessor* a, uint32_t x, uint32_t y, uint32_t z, int32_t* value) {
+  if (!a || !value) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  *value = a->acc.get(x, y, z);
+  return DUST_OK;
+}
+DustStatus dust_vdb_pool_create(size_t item_size, uint32_t chunk_size_log2, DustVdbPool** out) {
+  if (!out || item_size < 4 || chunk_size_log2 > 24) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pool parameters");
+  return guarded([&] { *out = new DustVdbPool(item_size, chunk_size_log2); return DUST_OK; });
+}
+void dust_vdb_pool_destroy(DustVdbPool* p) { delete p; }
+uint32_t dust_vdb_pool_alloc(DustVdbPool* p) { return p->pool.alloc(); }
+void dust_vdb_pool_free(DustVdbPool* p, uint32_t index) { p->pool.free(index); }
+size_t dust_vdb_pool_num_chunks(const DustVdbPool* p) { return p->pool.num_chunks(); }
+void dust_vdb_bitmask_set(uint64_t* words, size_t index, int32_t value) { dust::vdb::bit_set(words, index, value != 0); }
+size_t dust_vdb_bitmask_iter_set_bits(const uint64_t* words, size_t n_words, uint32_t* out, size_t cap) {
+  size_t n = 0;
+  dust::vdb::for_each_set_bit(words, n_words, [&](uint32_t i) {
+    if (out && n < cap) out[n] = i;
+    ++n;
+  });
+  return n;
+}
+
+// ===================================================================== vox
+DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** out) {
+  if (!bytes || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] {
+    std::unique_ptr<DustVoxScene> s(new DustVoxScene);
+    s->scene = dust::vox::load(bytes, n_bytes);
+    *out = s.release();
+    return DUST_OK;
+  });
+}
+void dust_vox_scene_destroy(DustVoxScene* s) { delete s; }
+DustStatus dust_vox_scene_counts(const DustVoxScene* s, uint32_t* n_models, uint32_t* n_instances) {
+  if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
+  if (n_models) *n_models = uint32_t(s->scene.models.size());
+  if (n_instances) *n_instances = uint32_t(s->scene.instances.size());
+  return DUST_OK;
+}
+DustStatus dust_vox_scene_model_info(const DustVoxScene* s, uint32_t model, DustVoxModelInfo* out) {
+  if (!s || !out || model >= s->scene.models.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "bad model index");
+  const auto& m = s->scene.models[model];
+  std::memcpy(out->size, m.size, sizeof(out->size));
+  out->n_voxels = uint32_t(m.xyzi.size() / 4);
+  out->n_blocks = uint32_t(m.blocks.size());
+  out->n_materials = m.materials.size();
+  out->used = m.used ? 1u : 0u;
+  return DUST_OK;
+}
+DustStatus dust_vox_scene_model_data(const DustVoxScene* s, uint32_t model, const DustHipBlock** blocks,
+                                     const uint8_t** materials) {
+  if (!s || model >= s->scene.models.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "bad model index");
+  const auto& m = s->scene.models[model];
+  if (blocks) *blocks = m.blocks.data();
+  if (materials) *materials = m.materials.data();
+  return DUST_OK;
+}
+DustStatus dust_vox_scene_palette(const DustVoxScene* s, const uint8_t** rgba) {
+  if (!s || !rgba) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  *rgba = s->scene.palette;
+  return DUST_OK;
+}
+DustStatus dust_vox_scene_instances(const DustVoxScene* s, DustVoxInstance* out, uint32_t cap) {
+  if (!s || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t n = std::min<size_t>(cap, s->scene.instances.size());
+  std::memcpy(out, s->scene.instances.data(), n * sizeof(DustVoxInstance));
+  return DUST_OK;
+}
+DustStatus dust_vox_flatten_model(const uint8_t* xyzi, size_t n_voxels, const uint32_t size[3], const uint8_t* palette,
+                                  DustHipBlock** blocks, uint32_t* n_blocks, uint8_t** materials,
+                                  uint64_t* n_materials) {
+  if ((!xyzi && n_voxels) || !size || !palette || !blocks || !n_blocks || !materials || !n_materials)
+    return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (size[0] > 256 || size[1] > 256 || size[2] > 256) return fail(DUST_ERR_INVALID_ARGUMENT, "model larger than 256^3");
+  for (size_t i = 0; i < n_voxels; ++i)
+    if (xyzi[i * 4] >= size[0] || xyzi[i * 4 + 1] >= size[1] || xyzi[i * 4 + 2] >= size[2])
+      return fail(DUST_ERR_INVALID_ARGUMENT, "voxel outside model size");
+  return guarded([&] {
+    std::vector<DustHipBlock> b;
+    std::vector<uint8_t> m;
+    dust::vox::flatten_model(xyzi, n_voxels, size, palette, b, m);
+    *blocks = static_cast<DustHipBlock*>(std::malloc(std::max<size_t>(1, b.size()) * sizeof(DustHipBlock)));
+    *materials = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, m.size())));
+    if (!*blocks || !*materials) return fail(DUST_ERR_OUT_OF_MEMORY, "host allocation failed");
+    std::memcpy(*blocks, b.data(), b.size() * sizeof(DustHipBlock));
+    std::memcpy(*materials, m.data(), m.size());
+    *n_blocks = uint32_t(b.size());
+    *n_materials = m.size();
+    return DUST_OK;
+  });
+}
+void dust_vox_free(void* p) { std::free(p); }
+
+// ===================================================================== device side
+DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** out) {
+  if (!out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(DUST_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+  std::unique_ptr<DustHipContext> c(new DustHipContext);
+  int dev = cfg ? cfg->device : -1;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= n) return fail(DUST_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(dev));
+  c->device = dev;
+  if (cfg && cfg->stream) c->stream = static_cast<hipStream_t>(cfg->stream);
+  else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  if (cfg && cfg->lds_root_bytes) c->lds_root_bytes = cfg->lds_root_bytes;
+  c->timing = cfg && (cfg->flags & DUST_HIP_CONTEXT_TIMING);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024;
+  if (const char* env = std::getenv("DUST_HIP_LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));
+  const size_t cap = c->max_lds > 8192 ? c->max_lds - 8192 : 0;
+  if (c->lds_root_bytes > cap) c->lds_root_bytes = uint32_t(cap);
+  HIP_TRY(dust::configure_kernels(c->max_lds));
+  *out = c.release();
+  return DUST_OK;
+}
+void dust_hip_context_destroy(DustHipContext* c) {
+  if (!c) return;
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+DustStatus dust_hip_sync(DustHipContext* c) {
+  if (!c) return fail(DUST_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DUST_OK;
+}
+
+DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks, uint32_t n_blocks,
+                                 const uint8_t* materials, uint64_t n_materials, const uint8_t* palette,
+                                 uint32_t tree_extent_log2, DustHipModel** out) {
+  if (!ctx || !out || (!blocks && n_blocks) || (!materials && n_materials) || !palette)
+    return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (tree_extent_log2 != 8 && tree_extent_log2 != 12)
+    return fail(DUST_ERR_INVALID_ARGUMENT, "tree_extent_log2 must be 8 (hierarchy 4,2,2) or 12 (hierarchy 4,4,2,2)");
+  return guarded([&]() -> DustStatus {
+    N16Builder root, l2;
+    std::vector<dust::DevN4> mid;
+    std::vector<uint64_t> brick_mask;
+    float bmin[3], bmax[3];
+    DustStatus s = build_hierarchy(blocks, n_blocks, tree_extent_log2, root, l2, mid, brick_mask, bmin, bmax);
+    if (s != DUST_OK) return s;
+    for (uint32_t i = 0; i < n_blocks; ++i) {
+      const uint64_t need = uint64_t(blocks[i].material_ptr) + uint64_t(__builtin_popcountll(blocks[i].mask));
+      if (need > n_materials) return fail(DUST_ERR_INVALID_ARGUMENT, "block material_ptr runs past the material buffer");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<DustHipModel> m(new DustHipModel);
+    m->ctx = ctx;
+    HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size()));
+    HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size()));
+    HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4)));
+    HIP_TRY(m->brick_mask.upload(brick_mask.data(), brick_mask.size() * 8));
+    HIP_TRY(m->blocks.upload(blocks, size_t(n_blocks) * sizeof(DustHipBlock)));
+    HIP_TRY(m->materials.upload(materials, size_t(n_materials)));
+    uint32_t pal[256];
+    std::memset(pal, 0, sizeof(pal));
+    std::memcpy(pal, palette, 255 * 4);  // loader.rs:214-218: entries 0..254
+    HIP_TRY(m->palette.upload(pal, sizeof(pal)));
+    dust::DevModel& d = m->dev;
+    d.root = static_cast<const uint8_t*>(m->root.p);
+    d.l2 = tree_extent_log2 == 12 ? static_cast<const uint8_t*>(m->l2.p) : nullptr;
+    d.mid = static_cast<const dust::DevN4*>(m->mid.p);
+    d.brick_mask = static_cast<const uint64_t*>(m->brick_mask.p);
+    d.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
+    d.materials = static_cast<const uint8_t*>(m->materials.p);
+    d.palette = static_cast<const uint32_t*>(m->palette.p);
+    std::memcpy(d.bmin, bmin, sizeof(bmin));
+    std::memcpy(d.bmax, bmax, sizeof(bmax));
+    d.extent = 1u << tree_extent_log2;
+    d.n_levels = tree_extent_log2 == 12 ? 3 : 2;
+    d.n_blocks = n_blocks;
+    d.lds_slot = -1;
+    *out = m.release();
+    return DUST_OK;
+  });
+}
+void dust_hip_model_destroy(DustHipModel* m) { delete m; }
+
+DustStatus dust_hip_scene_create(DustHipContext* ctx, DustHipScene** out) {
+  if (!ctx || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] {
+    *out = new DustHipScene;
+    (*out)->ctx = ctx;
+    return DUST_OK;
+  });
+}
+void dust_hip_scene_destroy(DustHipScene* s) { delete s; }
+
+static DustStatus check_affine(const float m[12]) {
+  for (int i = 0; i < 12; ++i)
+    if (!std::isfinite(m[i])) return fail(DUST_ERR_INVALID_ARGUMENT, "non-finite instance transform");
+  const double det = double(m[0]) * (double(m[5]) * m[10] - double(m[6]) * m[9]) -
+                     double(m[1]) * (double(m[4]) * m[10] - double(m[6]) * m[8]) +
+                     double(m[2]) * (double(m[4]) * m[9] - double(m[5]) * m[8]);
+  if (!(std::fabs(det) > 1e-20)) return fail(DUST_ERR_INVALID_ARGUMENT, "singular instance transform");
+  return DUST_OK;
+}
+
+DustStatus dust_hip_scene_add_instance(DustHipScene* s, const DustHipModel* model, const float o2w[12],
+                                       const float prev[16], uint32_t* instance_id) {
+  if (!s || !model || !o2w) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (model->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "model belongs to another context");
+  if (s->instances.size() >= 65535) return fail(DUST_ERR_INVALID_ARGUMENT, "too many instances (voxel_id holds 16 bits)");
+  DustStatus st = check_affine(o2w);
+  if (st != DUST_OK) return st;
+  return guarded([&] {
+    HostInstance hi;
+    hi.model = model;
+    std::memcpy(hi.o2w, o2w, sizeof(hi.o2w));
+    if (prev) std::memcpy(hi.prev, prev, sizeof(hi.prev));
+    else {  // first frame: previous transform == current (standard.rs:856-878), column-major mat4
+      for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) hi.prev[c * 4 + r] = r < 3 ? o2w[r * 4 + c] : (c == 3 ? 1.0f : 0.0f);
+    }
+    if (instance_id) *instance_id = uint32_t(s->instances.size());
+    s->instances.push_back(hi);
+    s->committed = false;
+    return DUST_OK;
+  });
+}
+DustStatus dust_hip_scene_set_transform(DustHipScene* s, uint32_t id, const float o2w[12], const float prev[16]) {
+  if (!s || !o2w || id >= s->instances.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "bad instance id");
+  DustStatus st = check_affine(o2w);
+  if (st != DUST_OK) return st;
+  HostInstance& hi = s->instances[id];
+  std::memcpy(hi.o2w, o2w, sizeof(hi.o2w));
+  if (prev) std::memcpy(hi.prev, prev, sizeof(hi.prev));
+  s->committed = false;
+  return DUST_OK;
+}
+
+DustStatus dust_hip_scene_commit(DustHipScene* s) {
+  if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
+  return guarded([&]() -> DustStatus {
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    s->models.clear();
+    std::vector<dust::DevInstance> di(s->instances.size());
+    for (size_t i = 0; i < s->instances.size(); ++i) {
+      const HostInstance& hi = s->instances[i];
+      auto it = std::find(s->models.begin(), s->models.end(), hi.model);
+      uint32_t slot = uint32_t(it - s->models.begin());
+      if (it == s->models.end()) s->models.push_back(hi.model);
+      dust::DevInstance& d = di[i];
+      std::memcpy(d.o2w, hi.o2w, sizeof(d.o2w));
+      std::memcpy(d.prev, hi.prev, sizeof(d.prev));
+      invert_affine(hi.o2w, d.w2o);
+      d.model = slot;
+      d.pad = 0;
+      const dust::DevModel& m = hi.model->dev;
+      for (int a = 0; a < 3; ++a) { d.wmin[a] = 1e30f; d.wmax[a] = -1e30f; }
+      for (int c = 0; c < 8; ++c) {
+        const double p[3] = {(c & 1) ? m.bmax[0] : m.bmin[0], (c & 2) ? m.bmax[1] : m.bmin[1], (c & 4) ? m.bmax[2] : m.bmin[2]};
+        for (int a = 0; a < 3; ++a) {
+          const float* r = hi.o2w + a * 4;
+          const double w = double(r[0]) * p[0] + double(r[1]) * p[1] + double(r[2]) * p[2] + double(r[3]);
+          const double pad = 1e-4 * (std::fabs(w) + 1.0);
+          d.wmin[a] = std::min(d.wmin[a], float(w - pad));
+          d.wmax[a] = std::max(d.wmax[a], float(w + pad));
+        }
+      }
+    }
+    // roots of the first models go to LDS, as many as the budget holds
+    s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
+    std::vector<dust::DevModel> dm(s->models.size());
+    for (size_t i = 0; i < s->models.size(); ++i) {
+      dm[i] = s->models[i]->dev;
+      dm[i].lds_slot = i < s->n_lds_models ? int32_t(i) : -1;
+    }
+    HIP_TRY(s->d_models.upload(dm.data(), dm.size() * sizeof(dust::DevModel)));
+    HIP_TRY(s->d_instances.upload(di.data(), di.size() * sizeof(dust::DevInstance)));
+    s->committed = true;
+    return DUST_OK;
+  });
+}
+
+DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_t height, DustHipPipeline** out) {
+  if (!ctx || !out || width == 0 || height == 0 || width > 16384 || height > 16384)
+    return fail(DUST_ERR_INVALID_ARGUMENT, "bad pipeline size");
+  return guarded([&]() -> DustStatus {
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<DustHipPipeline> p(new DustHipPipeline);
+    p->ctx = ctx;
+    p->width = width; p->height = height;
+    const size_t px = size_t(width) * height;
+    for (int i = 0; i < DUST_PLANE_COUNT; ++i) {
+      HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
+      HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
+    }
+    HIP_TRY(p->counters.alloc(64 * sizeof(uint32_t)));
+    HIP_TRY(p->stats.alloc(4 * sizeof(dust::DevStats)));
+    for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    *out = p.release();
+    return DUST_OK;
+  });
+}
+void dust_hip_pipeline_destroy(DustHipPipeline* p) {
+  if (!p) return;
+  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  delete p;
+}
+DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
+  if (!p || !texels || layers == 0 || (texture != 0 && texture != 5))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "noise texture must be 0 (scalar R8) or 5 (unitvec3_cosine RGBA8)");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  const size_t bytes = size_t(128) * 128 * layers * (texture == 0 ? 1 : 4);
+  if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes)); p->noise0_layers = layers; }
+  else { HIP_TRY(p->noise5.upload(texels, bytes)); p->noise5_layers = layers; }
+  return DUST_OK;
+}
+
+DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
+                                 const DustHipSky* sky, const DustHipFrameParams* fp) {
+  if (!p || !s || !cam || !sky || !fp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "pipeline and scene belong to different contexts");
+  if (!s->committed) return fail(DUST_ERR_NOT_READY, "scene has uncommitted changes (call dust_hip_scene_commit)");
+  const uint32_t need5 = DUST_PASS_AMBIENT_OCCLUSION | DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL;
+  if ((fp->passes & need5) && !p->noise5.p)
+    return fail(DUST_ERR_NOT_READY, "blue-noise texture 5 (unitvec3_cosine) not loaded");  // standard.rs:254
+  if (fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL))
+    return fail(DUST_ERR_UNSUPPORTED, "final-gather and surfel passes are not built yet");
+  DustHipContext* ctx = p->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  dust::FrameArgs a{};
+  a.models = static_cast<const dust::DevModel*>(s->d_models.p);
+  a.instances = static_cast<const dust::DevInstance*>(s->d_instances.p);
+  a.n_models = uint32_t(s->models.size());
+  a.n_instances = uint32_t(s->instances.size());
+  a.n_lds_models = s->n_lds_models;
+  std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
+  std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
+  a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;
+  std::memcpy(a.sky, sky->state, sizeof(a.sky));
+  a.g.illuminance = static_cast<uint16_t*>(p->planes[DUST_PLANE_ILLUMINANCE].p);
+  a.g.denoised = static_cast<uint16_t*>(p->planes[DUST_PLANE_DENOISED].p);
+  a.g.albedo = static_cast<uint32_t*>(p->planes[DUST_PLANE_ALBEDO].p);
+  a.g.normal = static_cast<uint32_t*>(p->planes[DUST_PLANE_NORMAL].p);
+  a.g.depth = static_cast<float*>(p->planes[DUST_PLANE_DEPTH].p);
+  a.g.motion = static_cast<uint16_t*>(p->planes[DUST_PLANE_MOTION].p);
+  a.g.voxel_id = static_cast<uint32_t*>(p->planes[DUST_PLANE_VOXEL_ID].p);
+  a.g.accum = static_cast<float*>(p->planes[DUST_PLANE_ACCUM].p);
+  a.width = p->width; a.height = p->height;
+  a.row_begin = fp->row_begin;
+  a.row_end = fp->row_end ? fp->row_end : p->height;
+  if (a.row_begin >= a.row_end || a.row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
+  a.tiles_x = (p->width + 7) / 8;
+  a.tiles_y = (a.row_end - a.row_begin + 7) / 8;
+  a.rand = fp->rand; a.frame_index = fp->frame_index;
+  if (p->noise0.p) a.noise0 = static_cast<const uint8_t*>(p->noise0.p) + size_t(fp->frame_index % p->noise0_layers) * 128 * 128;
+  if (p->noise5.p) a.noise5 = static_cast<const uint8_t*>(p->noise5.p) + size_t(fp->frame_index % p->noise5_layers) * 128 * 128 * 4;  // noise.rs:50
+  a.stats = static_cast<dust::DevStats*>(p->stats.p);
+  a.accum_count = p->accum_count;
+  const bool count = fp->passes & DUST_PASS_COUNT_STATS;
+  const uint32_t block = 512;
+  uint32_t bpc = 2;
+  if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
+  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 2;
+  while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
+  const uint32_t total_tiles = a.tiles_x * a.tiles_y;
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (total_tiles + 7) / 8));
+  hipStream_t st = ctx->stream;
+  p->stats_valid = false;
+  if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 4 * sizeof(dust::DevStats), st));
+  if (fp->passes & DUST_PASS_PRIMARY) {
+    a.work_counters = static_cast<uint32_t*>(p->counters.p);
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
+    a.stats = static_cast<dust::DevStats*>(p->stats.p);
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
+    HIP_TRY(dust::launch_primary(a, grid, block, count, st));
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
+  }
+  if (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) {
+    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 8;
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
+    a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
+    HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
+  }
+  if (fp->passes & DUST_PASS_ACCUMULATE) {
+    HIP_TRY(dust::launch_accumulate(a, st));
+    p->accum_count += 1;
+  }
+  if (count) {
+    HIP_TRY(hipMemcpyAsync(p->host_stats, p->stats.p, 4 * sizeof(dust::DevStats), hipMemcpyDeviceToHost, st));
+    p->stats_valid = true;
+  }
+  return DUST_OK;
+}
+
+DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustHipPassStats* out) {
+  if (!p || !out || pass > 4) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
+  std::memset(out, 0, sizeof(*out));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  // pass 0: primary kernel; passes 1 and 2: the two ray classes of the AO kernel (share its time)
+  const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : -1);
+  if (kernel >= 0 && p->ctx->timing && p->ev_valid[kernel]) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev[kernel * 2], p->ev[kernel * 2 + 1]));
+    out->ms = ms;
+  }
+  if (p->stats_valid && pass <= 2) {
+    const dust::DevStats& s = p->host_stats[pass];
+    out->rays = s.rays; out->instances_tested = s.instances_tested; out->upper_descents = s.upper_descents;
+    out->mid_descents = s.mid_descents; out->bricks_tested = s.bricks_tested; out->hits = s.hits;
+  }
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline* p, DustHipPlane plane, void** ptr, size_t* bytes) {
+  if (!p || int(plane) < 0 || plane >= DUST_PLANE_COUNT) return fail(DUST_ERR_INVALID_ARGUMENT, "bad plane");
+  if (ptr) *ptr = p->planes[plane].p;
+  if (bytes) *bytes = p->planes[plane].bytes;
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, void* dst, size_t dst_bytes) {
+  if (!p || !dst || int(plane) < 0 || plane >= DUST_PLANE_COUNT) return fail(DUST_ERR_INVALID_ARGUMENT, "bad plane");
+  if (dst_bytes < p->planes[plane].bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(hipMemcpy(dst, p->planes[plane].p, p->planes[plane].bytes, hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
+  if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->planes[i].p, 0, p->planes[i].bytes, p->ctx->stream));
+  p->accum_count = 0;
+  return DUST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// dust_dev.h -- plain structs shared by the host runtime (capi.cpp) and the HIP kernels (kernels.hip).
+//
+// HBM layout of one model (DESIGN.md "Data layout"):
+//   root      : one N16 node   [64 x u64 child mask][64 x u16 rank prefix][u32 child_base][pad]   656 B
+//   l2        : N16 nodes, only for 4096^3 trees (hierarchy (4,4,2,2)), same 656 B layout
+//   mid       : N4 nodes       {u64 child mask, u32 first_block, u32 pad}                         16 B
+//   brick_mask: u64 occupancy per 4^3 brick, block order                                          8 B
+//   blocks    : the reference's 24-byte Block records, block order (shading only)
+//   materials : u8 palette index per solid voxel; palette: 255 x RGBA8
+// A child "pointer" is child_base + prefix[word] + popcount(mask[word] & below(bit)): nodes of one
+// level are stored in depth-first order, which is also Tree::iter_leaf order, so the block index the
+// traversal arrives at IS the reference's gl_PrimitiveID.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/dust_hip.h"
+
+namespace dust {
+
+constexpr uint32_t kN16Bytes = 656;      // 512 mask + 128 prefix + 4 base + 12 pad
+constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base is 0)
+constexpr uint32_t kMaxCand = 96;        // per-wave candidate instance list capacity
+constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
+constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
+
+struct DevN4 {
+  uint32_t mask_lo, mask_hi;
+  uint32_t first_block;
+  uint32_t pad;
+};
+
+struct DevModel {
+  const uint8_t* root;          // N16
+  const uint8_t* l2;            // N16[] or null
+  const DevN4* mid;
+  const uint64_t* brick_mask;
+  const DustHipBlock* blocks;
+  const uint8_t* materials;
+  const uint32_t* palette;      // RGBA8 packed little-endian, 255 entries (+1 pad)
+  float bmin[3], bmax[3];       // tight object-space bounds of the bricks
+  uint32_t extent;              // 256 or 4096
+  uint32_t n_levels;            // internal levels: 2 (root,mid) or 3 (root,l2,mid)
+  uint32_t n_blocks;
+  int32_t lds_slot;             // slot of the staged root in LDS, -1 = read it from HBM/L2
+};
+
+struct DevInstance {
+  float w2o[12];   // world -> object, 3x4 row-major
+  float o2w[12];   // object -> world, 3x4 row-major (VkTransformMatrixKHR)
+  float prev[16];  // previous-frame object -> world, column-major mat4 (`instances[]`, layout.playout:72)
+  float wmin[3], wmax[3];  // conservative world-space bounds
+  uint32_t model;
+  uint32_t pad;
+};
+
+struct DevCamera {
+  float col0[3], col1[3], col2[3], pos[3];
+  float tan_half_fov, far_, near_;
+};
+
+struct DevStats {
+  unsigned long long rays, instances_tested, upper_descents, mid_descents, bricks_tested, hits;
+};
+
+struct DevGBuffer {
+  uint16_t* illuminance;  // 4 halves / px
+  uint16_t* denoised;     // 4 halves / px
+  uint32_t* albedo;
+  uint32_t* normal;
+  float* depth;
+  uint16_t* motion;       // 4 halves / px
+  uint32_t* voxel_id;
+  float* accum;           // 4 floats / px
+};
+
+struct FrameArgs {
+  const DevModel* models;
+  const DevInstance* instances;
+  uint32_t n_models, n_instances;
+  uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
+  DevCamera cam;
+  float sky[56];
+  DevGBuffer g;
+  uint32_t width, height;
+  uint32_t row_begin, row_end;
+  uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
+  uint32_t* work_counters;    // 8 per-region tile counters (zeroed before launch)
+  const uint8_t* noise0;      // 128*128 R8 slice for this frame, or null
+  const uint8_t* noise5;      // 128*128 RGBA8 slice for this frame, or null
+  uint32_t rand, frame_index;
+  DevStats* stats;            // [2]: per pass kind, only written by the counting build
+  uint32_t accum_count;       // frames already in `accum`
+};
+
+}  // namespace dust

@@ -1,0 +1,744 @@
+// kernels.hip -- CDNA4 (gfx950) ray traversal + shading kernels for Dust's StandardPipeline.
+//
+// What the reference does with four vkCmdTraceRaysKHR calls over a driver BVH of per-leaf AABBs
+// (crates/render/src/pipeline/standard.rs:477-725, assets/shaders/{primary,final_gather,surfel})
+// is done here by walking the VDB hierarchy directly:
+//   * persistent workgroups, one 64-lane wavefront per 8x8 pixel packet, packets pulled from
+//     per-XCD-region atomic counters (block b runs on XCD b%8, so a region stays in one L2);
+//   * the root node (4096-bit child mask + rank prefix) of every model is staged in LDS once per
+//     workgroup; mid nodes and brick masks come from HBM/L2 (16 B and 8 B loads);
+//   * the packet's rays are bounded once (wave reductions) and tested against all instance boxes
+//     64 at a time (__ballot compaction into an LDS candidate list);
+//   * per ray, a hierarchical DDA over 16^3 / 4^3 cells finds candidate bricks front to back; the
+//     brick test itself is the reference's intersection shader arithmetic, bit for bit
+//     (primary/hit.rint:43-131, final_gather/ambient_occlusion.rint:46-134, rough.rint:42-59).
+// Built with -ffp-contract=off: the brick test and the G-buffer maths must round exactly like the
+// oracle's. No MFMA: this is pointer chasing, not a contraction.
+#include <hip/hip_runtime.h>
+
+#include "dust_dev.h"
+
+namespace dust {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
+
+namespace {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float gsign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+__device__ __forceinline__ float gstep(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+__device__ __forceinline__ float gclamp(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 normalize3(V3 v) {
+  float l = sqrtf(dot3(v, v));
+  return mk(v.x / l, v.y / l, v.z / l);
+}
+__device__ __forceinline__ int f2i_clamp(float f, int lo, int hi) {  // clamp(int(floor-ed f)) with NaN -> lo side of 0
+  float c = fminf(fmaxf(f, (float)lo), (float)hi);                   // fmaxf(NaN, lo) == lo
+  return (int)c;
+}
+__device__ __forceinline__ V3 xform_point(const float* m, V3 p) {
+  return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+            ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+}
+__device__ __forceinline__ V3 xform_dir(const float* m, V3 d) {
+  return mk((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z,
+            (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
+}
+
+// ------------------------------------------------------------------ storage formats (standard.rs:974-1050)
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // RNE
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint32_t unorm(float v, float scale) {
+  if (!(v > 0.0f)) return 0;
+  if (v >= 1.0f) return (uint32_t)scale;
+  return (uint32_t)rintf(v * scale);
+}
+__device__ __forceinline__ uint32_t pack_rgb10a2(float r, float g, float b, float a) {
+  return unorm(r, 1023.0f) | (unorm(g, 1023.0f) << 10) | (unorm(b, 1023.0f) << 20) | (unorm(a, 3.0f) << 30);
+}
+__device__ __forceinline__ void store_half4(uint16_t* plane, size_t pix, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = (uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16);
+  v.y = (uint32_t)f2h(c) | ((uint32_t)f2h(d) << 16);
+  *reinterpret_cast<uint2*>(plane + pix * 4) = v;
+}
+
+// ------------------------------------------------------------------ headers/normal.glsl, nrd.glsl
+__device__ __forceinline__ V3 cubed_normalize(V3 d) {  // normal.glsl:39-43
+  V3 a = mk(fabsf(d.x), fabsf(d.y), fabsf(d.z));
+  float mx = fmaxf(a.x, fmaxf(a.y, a.z));
+  return mk(gsign(d.x) * gstep(mx, a.x), gsign(d.y) * gstep(mx, a.y), gsign(d.z) * gstep(mx, a.z));
+}
+__device__ __forceinline__ V3 rotate_by_normal(V3 n, V3 t) {  // normal.glsl:31-37
+  float qx = -n.y, qy = n.x, qz = 0.0f, qw = 1.0f + n.z;
+  float l = sqrtf(((qx * qx + qy * qy) + qz * qz) + qw * qw);
+  qx /= l; qy /= l; qz /= l; qw /= l;
+  if (n.z < -0.99999f) { qx = -1.0f; qy = 0.0f; qz = 0.0f; qw = 0.0f; }
+  V3 q = mk(qx, qy, qz);
+  float two_dot = 2.0f * dot3(q, t);
+  float k = qw * qw - dot3(q, q);
+  V3 c = mk(q.y * t.z - t.y * q.z, q.z * t.x - t.z * q.x, q.x * t.y - t.x * q.y);
+  float tw = 2.0f * qw;
+  return mk((two_dot * q.x + k * t.x) + tw * c.x, (two_dot * q.y + k * t.y) + tw * c.y,
+            (two_dot * q.z + k * t.z) + tw * c.z);
+}
+__device__ __forceinline__ uint32_t nrd_pack_normal(V3 v, float roughness, float material_id) {  // nrd.glsl:2-10,25-52
+  float s = (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z);
+  v.x /= s; v.y /= s; v.z /= s;
+  float wx = (1.0f - fabsf(v.y)) * (gstep(0.0f, v.x) * 2.0f - 1.0f);
+  float wy = (1.0f - fabsf(v.x)) * (gstep(0.0f, v.y) * 2.0f - 1.0f);
+  float ex = v.z >= 0.0f ? v.x : wx, ey = v.z >= 0.0f ? v.y : wy;
+  return pack_rgb10a2(ex * 0.5f + 0.5f, ey * 0.5f + 0.5f, roughness, gclamp(material_id / 3.0f, 0.0f, 1.0f));
+}
+__device__ __forceinline__ V3 nrd_unpack_normal(uint32_t p) {  // nrd.glsl:54-94 on an A2B10G10R10 texel
+  float p0 = (float)(p & 1023u) / 1023.0f, p1 = (float)((p >> 10) & 1023u) / 1023.0f;
+  float px = p0 * 2.0f - 1.0f, py = p1 * 2.0f - 1.0f;
+  V3 n = mk(px, py, (1.0f - fabsf(px)) - fabsf(py));
+  float t = gclamp(-n.z, 0.0f, 1.0f);
+  n.x -= t * (gstep(0.0f, n.x) * 2.0f - 1.0f);
+  n.y -= t * (gstep(0.0f, n.y) * 2.0f - 1.0f);
+  return normalize3(n);
+}
+__device__ __forceinline__ void store_radiance(uint16_t* plane, size_t pix, V3 r, float hitdist) {  // nrd.glsl:127-147
+  if (hitdist != 0.0f) hitdist = fmaxf(hitdist, 1e-7f);
+  float Y = (r.x * 0.25f + r.y * 0.5f) + r.z * 0.25f;
+  float Co = (r.x * 0.5f + r.y * 0.0f) + r.z * -0.5f;
+  float Cg = (r.x * -0.25f + r.y * 0.5f) + r.z * -0.25f;
+  store_half4(plane, pix, Y, Co, Cg, hitdist);
+}
+__device__ __forceinline__ V3 load_radiance(const uint16_t* plane, size_t pix, float& w) {  // nrd.glsl:107-125
+  uint2 v = *reinterpret_cast<const uint2*>(plane + pix * 4);
+  float Y = h2f((uint16_t)v.x), Co = h2f((uint16_t)(v.x >> 16)), Cg = h2f((uint16_t)v.y);
+  w = h2f((uint16_t)(v.y >> 16));
+  float t = Y - Cg;
+  return mk(fmaxf(t + Co, 0.0f), fmaxf(Y + Cg, 0.0f), fmaxf(t - Co, 0.0f));
+}
+
+// ------------------------------------------------------------------ headers/color.glsl, sky.glsl
+__device__ __forceinline__ V3 xyz_to_acescg(V3 v) {  // color.glsl:24-31 (column-major mat3)
+  return mk((1.6410228f * v.x + -0.32480323f * v.y) + -0.23642465f * v.z,
+            (-0.66366285f * v.x + 1.6153315f * v.y) + 0.016756356f * v.z,
+            (0.011721907f * v.x + -0.0082844375f * v.y) + 0.9883947f * v.z);
+}
+__device__ float sky_internal(const float* c, float cos_theta, float gamma, float cos_gamma) {  // sky.glsl:1-15
+  float expM = expf(c[4] * gamma);
+  float rayM = cos_gamma * cos_gamma;
+  float mieM = (1.0f + rayM) / powf((1.0f + c[8] * c[8]) - (2.0f * c[8]) * cos_gamma, 1.5f);
+  float zenith = sqrtf(cos_theta);
+  return (1.0f + c[0] * expf(c[1] / (cos_theta + 0.01f))) *
+         ((((c[2] + c[3] * expM) + c[5] * rayM) + c[6] * mieM) + c[7] * zenith);
+}
+__device__ V3 sky_radiance(const float* s, V3 dir) {  // sky.glsl:18-79
+  if (s[49] <= 0.0f) return mk(0, 0, 0);
+  float cos_theta = gclamp(dir.y, 0.0f, 1.0f);
+  float cos_gamma = dot3(dir, mk(s[48], s[49], s[50]));
+  float gamma = acosf(cos_gamma);
+  float x = sky_internal(s, cos_theta, gamma, cos_gamma) * s[9];
+  float y = sky_internal(s + 16, cos_theta, gamma, cos_gamma) * s[25];
+  float z = sky_internal(s + 32, cos_theta, gamma, cos_gamma) * s[41];
+  return xyz_to_acescg(mk(x * 683.0f, y * 683.0f, z * 683.0f));
+}
+__device__ V3 sun_radiance(const float* s, V3 dir) {  // sky.glsl:81-113
+  float cos_gamma = dot3(dir, mk(s[48], s[49], s[50]));
+  if (cos_gamma < 0.0f || dir.y < 0.0f) return mk(0, 0, 0);
+  float sol_rad_sin = sinf(s[55]);
+  float ar2 = 1.0f / (sol_rad_sin * sol_rad_sin);
+  float singamma = 1.0f - (cos_gamma * cos_gamma);
+  float sc2 = 1.0f - (ar2 * singamma) * singamma;
+  if (sc2 <= 0.0f) return mk(0, 0, 0);
+  float sc = sqrtf(sc2);
+  V3 dark = mk(s[10], s[26], s[42]);
+  dark.x += s[11] * sc; dark.y += s[27] * sc; dark.z += s[43] * sc;
+  float cur = sc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cur *= sc;
+    dark.x += s[12 + i] * cur; dark.y += s[28 + i] * cur; dark.z += s[44 + i] * cur;
+  }
+  return xyz_to_acescg(mk(s[52] * dark.x, s[53] * dark.y, s[54] * dark.z));
+}
+
+// ------------------------------------------------------------------ the intersection shaders
+constexpr int kDdaMaxIters = 64;  // the reference loop is unbounded; a NaN ray would hang the GPU there
+
+__device__ __forceinline__ bool grid_clear(uint32_t m1, uint32_t m2, uint32_t hit) {  // hit.rint:13-15
+  return ((hit < 32u) ? (m1 & (1u << (hit & 31u))) : (m2 & (1u << ((hit - 32u) & 31u)))) == 0;
+}
+__device__ __forceinline__ uint32_t encode_index(int px, int py, int pz) {  // hit.rint:30-32 on u8vec3
+  return (((uint32_t)px << 4) | ((uint32_t)py << 2) | ((uint32_t)pz & 0xFFu)) & 0xFFu;
+}
+__device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, float& t_min, float& t_max) {  // hit.rint:20-28
+  float ax = (0.0f - o.x) / d.x, ay = (0.0f - o.y) / d.y, az = (0.0f - o.z) / d.z;
+  float bx = (4.0f - o.x) / d.x, by = (4.0f - o.y) / d.y, bz = (4.0f - o.z) / d.z;
+  t_min = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  t_max = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+
+// RT 0: primary/hit.rint:43-131. RT 1: ambient_occlusion.rint:46-134. RT 2,3: rough.rint:42-59.
+// o is brick-local (objOrigin - block.position). Returns true when reportIntersectionEXT is reached.
+template <int RT>
+__device__ bool brick_intersect(V3 o, V3 d, uint32_t m1, uint32_t m2, float tmin, float& t_out, uint32_t& voxel) {
+  float t0, t1;
+  intersect_aabb04(o, d, t0, t1);
+  if (t0 >= t1) return false;
+  if (RT >= 2) {
+    if (m1 == 0 && m2 == 0) return false;
+    t_out = t0;
+    voxel = 0;
+    return true;
+  }
+  if (t1 <= 0.0f) return false;
+  if (RT == 1) {
+    if (t0 <= 8.0f && 8.0f <= t1) {
+      if (!(m1 == 0 && m2 == 0)) { t_out = t0; voxel = 0xFF; return true; }
+      return false;
+    }
+  }
+  float hd = fmaxf(t0, tmin);
+  int px = f2i_clamp(floorf(o.x + d.x * hd), 0, 3), py = f2i_clamp(floorf(o.y + d.y * hd), 0, 3),
+      pz = f2i_clamp(floorf(o.z + d.z * hd), 0, 3);
+  V3 st = mk(gsign(d.x), gsign(d.y), gsign(d.z));
+  V3 tc = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  V3 tb = mk(tc.x * o.x, tc.y * o.y, tc.z * o.z);
+  V3 tm = mk(((float)px + fmaxf(st.x, 0.0f)) * tc.x - tb.x, ((float)py + fmaxf(st.y, 0.0f)) * tc.y - tb.y,
+             ((float)pz + fmaxf(st.z, 0.0f)) * tc.z - tb.z);
+  V3 td = mk((1.0f * tc.x) * st.x, (1.0f * tc.y) * st.y, (1.0f * tc.z) * st.z);
+  uint32_t hit = encode_index(px, py, pz);
+  int iters = 0;
+  while (grid_clear(m1, m2, hit)) {
+    if (++iters > kDdaMaxIters) return false;
+    float cx = gstep(tm.x, tm.z) * gstep(tm.x, tm.y);
+    float cy = gstep(tm.y, tm.x) * gstep(tm.y, tm.z);
+    float cz = gstep(tm.z, tm.y) * gstep(tm.z, tm.x);
+    px = (int)(int8_t)(px + (int)(st.x * cx));
+    py = (int)(int8_t)(py + (int)(st.y * cy));
+    pz = (int)(int8_t)(pz + (int)(st.z * cz));
+    hd = fminf(fminf(tm.x, tm.y), tm.z);
+    if (hd + 0.001f >= t1) return false;
+    tm.x += td.x * cx; tm.y += td.y * cy; tm.z += td.z * cz;
+    hit = encode_index(px, py, pz);
+  }
+  t_out = hd / 1.0f;
+  voxel = hit;
+  return true;
+}
+
+// ------------------------------------------------------------------ traversal
+struct Hit {
+  float t;
+  uint32_t inst, block, voxel;
+  bool found;
+};
+struct LaneStats {
+  uint32_t rays, instances_tested, upper_descents, mid_descents, bricks_tested, hits;
+};
+struct MidCache {
+  int key;
+  uint32_t mlo, mhi, first;
+};
+
+__device__ __forceinline__ bool slab_box(V3 o, V3 d, const float* lo, const float* hi, float& te, float& tx) {
+  te = -INFINITY; tx = INFINITY;
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (dd[a] != 0.0f) {
+      float inv = 1.0f / dd[a];
+      float t0 = (lo[a] - oo[a]) * inv, t1 = (hi[a] - oo[a]) * inv;
+      te = fmaxf(te, fminf(t0, t1));
+      tx = fminf(tx, fmaxf(t0, t1));
+    } else if (oo[a] < lo[a] - 1e-3f || oo[a] > hi[a] + 1e-3f) {
+      return false;
+    }
+  }
+  float slack = 1e-5f * (fabsf(te) + fabsf(tx)) + 1e-5f;
+  return !(te > tx + slack) && !(tx + slack < 0.0f);
+}
+
+// N16 lookup: bit test + rank. Root nodes staged in LDS are read with ds_read, the rest from memory.
+__device__ __forceinline__ bool n16_child(const uint8_t* node, int lds_slot, uint32_t idx, uint32_t& child) {
+  uint32_t w = idx >> 6, bit = idx & 63u;
+  uint64_t word;
+  uint32_t pre;
+  if (lds_slot >= 0) {
+    word = reinterpret_cast<const uint64_t*>(g_lds + (uint32_t)lds_slot * kN16LdsBytes)[w];
+    if (!((word >> bit) & 1ull)) return false;
+    pre = reinterpret_cast<const uint16_t*>(g_lds + (uint32_t)lds_slot * kN16LdsBytes + 512)[w];
+  } else {
+    word = reinterpret_cast<const uint64_t*>(node)[w];
+    if (!((word >> bit) & 1ull)) return false;
+    pre = reinterpret_cast<const uint16_t*>(node + 512)[w] + *reinterpret_cast<const uint32_t*>(node + 640);
+  }
+  child = pre + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+  return true;
+}
+
+// deepest occupied cell containing voxel (x,y,z): block index or -1; cell_log2 = size of that cell
+template <bool COUNT>
+__device__ __forceinline__ int find_brick(const DevModel& m, int x, int y, int z, uint32_t& cell_log2, MidCache& mc,
+                                          LaneStats& st, bool count) {
+  const int key = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
+  if (key != mc.key) {
+    uint32_t mid_index;
+    if (m.n_levels == 2) {
+      uint32_t idx = ((uint32_t)(x >> 4) << 8) | ((uint32_t)(y >> 4) << 4) | (uint32_t)(z >> 4);
+      if (!n16_child(m.root, m.lds_slot, idx, mid_index)) { cell_log2 = 4; return -1; }
+      if (COUNT && count) st.upper_descents += 1;
+    } else {
+      uint32_t idx = ((uint32_t)(x >> 8) << 8) | ((uint32_t)(y >> 8) << 4) | (uint32_t)(z >> 8);
+      uint32_t l2;
+      if (!n16_child(m.root, m.lds_slot, idx, l2)) { cell_log2 = 8; return -1; }
+      if (COUNT && count) st.upper_descents += 1;
+      uint32_t idx2 = ((uint32_t)((x >> 4) & 15) << 8) | ((uint32_t)((y >> 4) & 15) << 4) | (uint32_t)((z >> 4) & 15);
+      if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return -1; }
+      if (COUNT && count) st.upper_descents += 1;
+    }
+    const uint4 n = *reinterpret_cast<const uint4*>(m.mid + mid_index);
+    mc.key = key; mc.mlo = n.x; mc.mhi = n.y; mc.first = n.z;
+  }
+  const uint32_t bit = ((uint32_t)((x >> 2) & 3) << 4) | ((uint32_t)((y >> 2) & 3) << 2) | (uint32_t)((z >> 2) & 3);
+  const uint64_t mm = ((uint64_t)mc.mhi << 32) | mc.mlo;
+  cell_log2 = 2;
+  if (!((mm >> bit) & 1ull)) return -1;
+  if (COUNT && count) st.mid_descents += 1;
+  return (int)(mc.first + (uint32_t)__popcll(mm & ((1ull << bit) - 1ull)));
+}
+
+// run the ray type's intersection routine on one brick and apply Vulkan's accept rule
+// (tmin <= t <= current tmax; equal t: lower (instance, block) wins -- see oracle/shade.c header)
+template <int RT, bool COUNT>
+__device__ __forceinline__ void test_brick(const DevModel& m, uint32_t inst, uint32_t bi, int bx, int by, int bz, V3 o,
+                                           V3 d, float tmin, float tmax, Hit& best, LaneStats& st) {
+  const uint64_t mask = m.brick_mask[bi];
+  V3 ol = mk(o.x - (float)bx, o.y - (float)by, o.z - (float)bz);  // hit.rint:137-140
+  float t;
+  uint32_t vox;
+  if (COUNT) st.bricks_tested += 1;
+  if (!brick_intersect<RT>(ol, d, (uint32_t)mask, (uint32_t)(mask >> 32), tmin, t, vox)) return;
+  const float cur = best.found ? best.t : tmax;
+  if (!(t >= tmin && t <= cur)) return;
+  if (best.found && t == best.t) {
+    if (inst > best.inst || (inst == best.inst && bi >= best.block)) return;
+  }
+  best.found = true; best.t = t; best.inst = inst; best.block = bi; best.voxel = vox;
+}
+
+// Hierarchical traversal of one instance in object space. Visits, front to back, a SUPERSET of the
+// bricks whose intersection routine can report an accepted hit: exit planes are recomputed from
+// integer cell coordinates at every step (no accumulated error), and whenever the walk passes within
+// delta of a brick-grid edge or corner every brick around it is tested too (DESIGN.md "Conservative walk").
+template <int RT, bool ANY, bool COUNT>
+__device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, Hit& best,
+                               LaneStats& st) {
+  float te, tx;
+  if (!slab_box(o, d, m.bmin, m.bmax, te, tx)) return;
+  const int E = (int)m.extent;
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  float t = fmaxf(te, 0.0f);
+  if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
+  int ijk[3];
+  uint32_t stepped = 0;  // bit a: axis a crossed a plane on the last step
+#pragma unroll
+  for (int a = 0; a < 3; ++a) ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * t), 0, E - 1);
+  MidCache mc;
+  mc.key = -1;
+  const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
+  for (int guard = 0; guard < 100000; ++guard) {
+    const float limit = best.found ? best.t : tmax;
+    if (t * (1.0f - 2e-6f) > limit) return;
+    if (ANY && best.found) return;
+    uint32_t cl;
+    const int bi = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl, mc, st, true);
+    if (bi >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)bi, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, tmin, tmax, best, st);
+    // bricks around a brick-grid edge/corner the ray passes within delta of (rare)
+    int near_dir[3];
+    uint32_t n_near_unstepped = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float p = oo[a] + dd[a] * t;
+      const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
+      const float q = p - (float)(ijk[a] & ~3);
+      near_dir[a] = 0;
+      if (stepped & (1u << a)) near_dir[a] = dd[a] > 0.0f ? -1 : 1;
+      else if (q <= delta) { near_dir[a] = -1; n_near_unstepped++; }
+      else if (q >= 4.0f - delta) { near_dir[a] = 1; n_near_unstepped++; }
+    }
+    if (n_near_unstepped > 0 || __popc(stepped) > 1) {
+      for (uint32_t sub = 1; sub < 8; ++sub) {
+        bool ok = true;
+        int nj[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          nj[a] = ijk[a];
+          if (sub & (1u << a)) {
+            if (!near_dir[a]) ok = false;
+            nj[a] = near_dir[a] < 0 ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
+            if (nj[a] < 0 || nj[a] >= E) ok = false;
+          }
+        }
+        if (!ok) continue;
+        if (stepped != 0 && sub == stepped) continue;  // the cell we came from
+        uint32_t cl2;
+        MidCache mc2;
+        mc2.key = -1;
+        const int nb = find_brick<COUNT>(m, nj[0], nj[1], nj[2], cl2, mc2, st, false);
+        if (nb >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)nb, nj[0] & ~3, nj[1] & ~3, nj[2] & ~3, o, d, tmin, tmax, best, st);
+      }
+    }
+    // leave the cell of size 2^cl that contains ijk
+    const int S = 1 << cl;
+    float ta[3], tn = INFINITY;
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      c[a] = ijk[a] & ~(S - 1);
+      if (dd[a] != 0.0f) {
+        const float plane = (float)(dd[a] > 0.0f ? c[a] + S : c[a]);
+        ta[a] = (plane - oo[a]) * inv[a];
+      } else {
+        ta[a] = INFINITY;
+      }
+      tn = fminf(tn, ta[a]);
+    }
+    if (!(tn < INFINITY)) return;
+    stepped = 0;
+    bool outside = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (ta[a] == tn) {
+        stepped |= 1u << a;
+        ijk[a] = dd[a] > 0.0f ? c[a] + S : c[a] - 1;
+        if (ijk[a] < 0 || ijk[a] >= E) outside = true;
+      } else {
+        ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * tn), c[a], c[a] + S - 1);
+      }
+    }
+    if (outside) return;
+    t = fmaxf(t, tn);
+    if (t * (1.0f - 2e-6f) > tx_stop) return;
+  }
+}
+
+// ------------------------------------------------------------------ packet-level instance culling
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s));
+  return v;
+}
+
+// Bounds the packet's rays by per-axis origin and direction intervals, tests all instance boxes
+// against that bundle 64 at a time and compacts the survivors (ascending instance id) into `cand`.
+// Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
+__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, uint16_t* cand) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  float omin[3], omax[3], dmin[3], dmax[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    omin[k] = wave_min(active ? oo[k] : INFINITY);
+    omax[k] = wave_max(active ? oo[k] : -INFINITY);
+    dmin[k] = wave_min(active ? dd[k] : INFINITY);
+    dmax[k] = wave_max(active ? dd[k] : -INFINITY);
+  }
+  const float T = wave_max(active ? tmax : 0.0f);
+  if (!(omin[0] <= omax[0])) return 0;  // no active lane
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t n = 0;
+  for (uint32_t base = 0; base < a.n_instances; base += 64) {
+    const uint32_t i = base + lane;
+    bool pass = false;
+    if (i < a.n_instances) {
+      const DevInstance& in = a.instances[i];
+      float t_lo = 0.0f, t_hi = T;
+      pass = true;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        // exists o in [omin,omax], d in [dmin,dmax]: lo <= o + d t <= hi
+        //   <=>  omin + dmin t <= hi  and  omax + dmax t >= lo      (t >= 0)
+        const float c1 = in.wmax[k] - omin[k], c2 = in.wmin[k] - omax[k];
+        if (dmin[k] > 0.0f) t_hi = fminf(t_hi, c1 / dmin[k]);
+        else if (dmin[k] < 0.0f) t_lo = fmaxf(t_lo, c1 / dmin[k]);
+        else if (c1 < 0.0f) pass = false;
+        if (dmax[k] > 0.0f) t_lo = fmaxf(t_lo, c2 / dmax[k]);
+        else if (dmax[k] < 0.0f) t_hi = fminf(t_hi, c2 / dmax[k]);
+        else if (c2 > 0.0f) pass = false;
+      }
+      if (t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f) pass = false;
+    }
+    const uint64_t bal = __ballot(pass);
+    if (pass) {
+      const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < kMaxCand) cand[pos] = (uint16_t)i;
+    }
+    n += (uint32_t)__popcll(bal);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return n;
+}
+
+template <int RT, bool ANY, bool COUNT>
+__device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, const uint16_t* cand,
+                          uint32_t ncand, Hit& best, LaneStats& st) {
+  best.found = false;
+  best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
+  if (COUNT && active) st.rays += 1;
+  const bool all = ncand > kMaxCand;
+  const uint32_t n = all ? a.n_instances : ncand;
+  for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
+    const uint32_t ii = all ? ci : (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[ci]);
+    const DevInstance& in = a.instances[ii];
+    bool go = active && !(ANY && best.found);
+    float te, tx;
+    if (go) go = slab_box(o, d, in.wmin, in.wmax, te, tx);
+    if (go) {
+      const float limit = best.found ? best.t : tmax;
+      if (te * (1.0f - 2e-6f) > limit) go = false;
+    }
+    if (!__any(go)) continue;
+    if (go) {
+      if (COUNT) st.instances_tested += 1;
+      const DevModel& m = a.models[in.model];
+      trace_instance<RT, ANY, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, best, st);
+    }
+  }
+  if (COUNT && best.found) st.hits += 1;
+}
+
+// ------------------------------------------------------------------ work distribution
+struct Packet {
+  uint32_t px, py;
+  bool valid;
+};
+
+// Pulls the next 8x8 pixel packet for this wave. The tile list is cut into 8 contiguous regions,
+// one per XCD; a wave drains its own region (blockIdx & 7) first, then helps the others.
+__device__ __forceinline__ bool next_packet(const FrameArgs& a, uint32_t& region_try, Packet& p) {
+  const uint32_t total = a.tiles_x * a.tiles_y;
+  const uint32_t per = (total + 7u) / 8u;
+  const uint32_t lane = threadIdx.x & 63u;
+  while (region_try < 8u) {
+    const uint32_t region = (blockIdx.x + region_try) & 7u;
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&a.work_counters[region], 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t tile = region * per + k;
+    if (k < per && tile < total) {
+      const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+      p.px = tx * 8u + (lane & 7u);
+      p.py = a.row_begin + ty * 8u + (lane >> 3);
+      p.valid = p.px < a.width && p.py < a.row_end;
+      return true;
+    }
+    region_try += 1;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void stage_roots(const FrameArgs& a) {
+  // root masks + prefixes of the first n_lds_models models -> LDS, 16 B per lane per step
+  const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
+  for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
+    const uint32_t mdl = i / (kN16LdsBytes / 16u), off = i % (kN16LdsBytes / 16u);
+    reinterpret_cast<uint4*>(g_lds)[i] = reinterpret_cast<const uint4*>(a.models[mdl].root)[off];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ uint16_t* wave_cand_list(const FrameArgs& a) {
+  return reinterpret_cast<uint16_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * kMaxCand;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_stats(const FrameArgs& a, int slot, const LaneStats& st) {
+  if (!COUNT) return;
+  atomicAdd(&a.stats[slot].rays, (unsigned long long)st.rays);
+  atomicAdd(&a.stats[slot].instances_tested, (unsigned long long)st.instances_tested);
+  atomicAdd(&a.stats[slot].upper_descents, (unsigned long long)st.upper_descents);
+  atomicAdd(&a.stats[slot].mid_descents, (unsigned long long)st.mid_descents);
+  atomicAdd(&a.stats[slot].bricks_tested, (unsigned long long)st.bricks_tested);
+  atomicAdd(&a.stats[slot].hits, (unsigned long long)st.hits);
+}
+
+__device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
+  // camera.glsl:4-16
+  float nx = ((float)px + 0.5f) / (float)w, ny = ((float)py + 0.5f) / (float)h;
+  float cx = 2.0f * nx - 1.0f, cy = 2.0f * ny - 1.0f;
+  cy *= -1.0f;
+  cx *= (float)w / (float)h;
+  cx *= c.tan_half_fov; cy *= c.tan_half_fov;
+  const float cz = -1.0f;
+  return mk((c.col0[0] * cx + c.col1[0] * cy) + c.col2[0] * cz, (c.col0[1] * cx + c.col1[1] * cy) + c.col2[1] * cz,
+            (c.col0[2] * cx + c.col1[2] * cy) + c.col2[2] * cz);
+}
+
+}  // namespace
+
+// ==================================================================== primary visibility
+// primary.rgen:8-22 + hit.rint + hit.rchit:16-95 + miss.rmiss:7-17
+template <bool COUNT>
+__global__ void __launch_bounds__(512) k_primary(FrameArgs a) {
+  stage_roots(a);
+  uint16_t* cand = wave_cand_list(a);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  uint32_t region_try = 0;
+  Packet p;
+  while (next_packet(a, region_try, p)) {
+    const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
+    const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+    const uint32_t ncand = cull_instances(a, p.valid, o, d, a.cam.far_, cand);
+    Hit h;
+    trace_ray<0, false, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, cand, ncand, h, st);
+    __builtin_amdgcn_wave_barrier();
+    if (!p.valid) continue;
+    const size_t pix = (size_t)p.py * a.width + p.px;
+    if (!h.found) {
+      const V3 dir = normalize3(d);
+      const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
+      store_radiance(a.g.denoised, pix, mk((s0.x + s1.x) / 3.14f, (s0.y + s1.y) / 3.14f, (s0.z + s1.z) / 3.14f), 100000.0f);
+      a.g.albedo[pix] = 0xFFFFFFFFu;
+      a.g.depth[pix] = INFINITY;
+      store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+      continue;
+    }
+    const DevInstance& in = a.instances[h.inst];
+    const DevModel& m = a.models[in.model];
+    const DustHipBlock b = m.blocks[h.block];
+    const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
+    const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
+    const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
+    const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
+    const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
+    const V3 nw = xform_dir(in.o2w, no);
+    store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
+    const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
+    const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
+    const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
+    const uint32_t pal = m.materials[b.material_ptr + voff];
+    const uint32_t col = m.palette[pal];
+    a.g.albedo[pix] = pack_rgb10a2((float)(col & 255u) / 255.0f, (float)((col >> 8) & 255u) / 255.0f,
+                                   (float)((col >> 16) & 255u) / 255.0f, 1.0f);
+    a.g.depth[pix] = h.t;
+    a.g.normal[pix] = nrd_pack_normal(nw, 1.0f, (float)pal);
+    a.g.voxel_id[pix] = (h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16);
+    const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
+    const V3 hpm = xform_point(in.w2o, hpw);
+    const float* P = in.prev;
+    const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
+    const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
+    const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
+    const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
+    store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
+  }
+  flush_stats<COUNT>(a, 0, st);
+}
+
+// ==================================================================== sun shadow + ambient occlusion
+// ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22
+template <bool COUNT>
+__global__ void __launch_bounds__(512) k_ambient_occlusion(FrameArgs a) {
+  stage_roots(a);
+  uint16_t* cand = wave_cand_list(a);
+  LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
+  uint32_t region_try = 0;
+  Packet p;
+  const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
+  while (next_packet(a, region_try, p)) {
+    const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
+    const float hitT = p.valid ? a.g.depth[pix] : INFINITY;
+    const bool live = p.valid && !(hitT == INFINITY);
+    V3 n = mk(0, 0, 1), loc = mk(0, 0, 0), payload = mk(0, 0, 0), ad = mk(0, 0, 1);
+    if (live) {
+      n = nrd_unpack_normal(a.g.normal[pix]);
+      const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+      loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
+               (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+      float w;
+      payload = load_radiance(a.g.illuminance, pix, w);
+      const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
+      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
+      V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
+                 (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+      ad = normalize3(rotate_by_normal(n, ns));
+    }
+    // sun shadow ray: any-hit, ray type 1 (ambient_occlusion.rgen:33-50)
+    const bool sun_live = live && dot3(sun, n) > 0.0f;
+    const V3 sd = normalize3(sun);
+    Hit h;
+    uint32_t ncand = cull_instances(a, sun_live, loc, sd, 10000.0f, cand);
+    trace_ray<1, true, COUNT>(a, sun_live, loc, sd, 0.1f, 10000.0f, cand, ncand, h, st_sun);
+    __builtin_amdgcn_wave_barrier();
+    if (sun_live && !h.found) {
+      const V3 sr = sun_radiance(a.sky, normalize3(sd));
+      const float k = 1.0f - cosf(a.sky[55]);
+      const float dn = dot3(n, sd);
+      payload.x += (sr.x * k) * dn; payload.y += (sr.y * k) * dn; payload.z += (sr.z * k) * dn;
+    }
+    // ambient occlusion ray: closest hit within 8 units (ambient_occlusion.rgen:52-65)
+    ncand = cull_instances(a, live, loc, ad, 8.0f, cand);
+    trace_ray<1, false, COUNT>(a, live, loc, ad, 0.1f, 8.0f, cand, ncand, h, st_ao);
+    __builtin_amdgcn_wave_barrier();
+    if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
+  }
+  flush_stats<COUNT>(a, 0, st_sun);
+  flush_stats<COUNT>(a, 1, st_ao);
+}
+
+// ==================================================================== N-frame mean (stands in for NRD)
+__global__ void k_accumulate(FrameArgs a) {
+  const uint32_t rows = a.row_end - a.row_begin;
+  const size_t n = (size_t)rows * a.width;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = (size_t)a.row_begin * a.width + i;
+    float w;
+    const bool miss = a.g.depth[pix] == INFINITY;
+    const V3 r = load_radiance(miss ? a.g.denoised : a.g.illuminance, pix, w);  // miss.rmiss writes the denoised target
+    float4 acc = reinterpret_cast<float4*>(a.g.accum)[pix];
+    const float k = 1.0f / (float)(a.accum_count + 1u);
+    if (a.accum_count == 0u) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc.x += (r.x - acc.x) * k; acc.y += (r.y - acc.y) * k; acc.z += (r.z - acc.z) * k;
+    acc.w = (float)(a.accum_count + 1u);
+    reinterpret_cast<float4*>(a.g.accum)[pix] = acc;
+  }
+}
+
+// ==================================================================== launchers (called from capi.cpp)
+static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
+  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * sizeof(uint16_t);
+}
+
+hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_accumulate(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t configure_kernels(size_t max_lds) {
+  hipError_t e;
+  const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
+                       (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>};
+  for (const void* f : fns) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace dust

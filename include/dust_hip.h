@@ -1,0 +1,233 @@
+/*
+ * dust_hip.h -- C ABI of the MI355X-native replacement for Dust's ray-tracing hot path.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to the
+ * dust-engine/dust checkout). Plain pointers and sizes only; no C++ or torch types cross this
+ * boundary; no exception or panic crosses it either: every function returns a DustStatus and
+ * dust_hip_last_error() holds the message of the calling thread's last failure.
+ *
+ * Ownership: handles are owned by the library and released by the matching *_destroy; input
+ * arrays are borrowed for the duration of the call only (the library copies what it keeps).
+ * Threading: a context and everything created from it is externally synchronised (one thread
+ * at a time), matching the reference's single render system per frame (examples/castle.rs:139-236).
+ */
+#ifndef DUST_HIP_H
+#define DUST_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum DustStatus {
+  DUST_OK = 0,
+  DUST_ERR_INVALID_ARGUMENT = -1,
+  DUST_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime failure at context creation */
+  DUST_ERR_HIP = -3,            /* a HIP call or kernel launch failed; see dust_hip_last_error() */
+  DUST_ERR_OUT_OF_MEMORY = -4,
+  DUST_ERR_PARSE = -5,          /* VoxLoadingError::ParseError (crates/vox/src/loader.rs:311-317) */
+  DUST_ERR_UNSUPPORTED = -6,    /* the reference's unimplemented!() paths (loader.rs:103-105,149-151) */
+  DUST_ERR_NOT_READY = -7       /* StandardPipeline::render returning None (standard.rs:254-266) */
+} DustStatus;
+
+const char* dust_hip_last_error(void);
+/* number of HIP devices visible; 0 when there is no GPU (never fails) */
+int dust_hip_device_count(void);
+
+/* ===================================================================== vdb tree builder (host)
+ * Replaces dust_vdb::Tree<hierarchy!(...)> (crates/vdb/src/tree.rs:7-124) and Accessor
+ * (accessor.rs:5-139). The hierarchy is given at run time as per-level fan-out log2s, root first:
+ * hierarchy!(4,2,2) == {4,2,2}. */
+typedef struct DustVdbTree DustVdbTree;
+typedef struct DustVdbAccessor DustVdbAccessor;
+
+DustStatus dust_vdb_tree_create(const uint32_t* fanout_log2, uint32_t n_levels, DustVdbTree** out); /* Tree::new, tree.rs:30-48 */
+void dust_vdb_tree_destroy(DustVdbTree*);
+/* Tree::set_value (tree.rs:83-85). value: 1 = Some(true), 0 = Some(false), -1 = None.
+ * None returns DUST_ERR_UNSUPPORTED where the reference is todo!() (node/internal.rs:121-124). */
+DustStatus dust_vdb_tree_set(DustVdbTree*, uint32_t x, uint32_t y, uint32_t z, int32_t value);
+/* Tree::get_value (tree.rs:78-80). *value: 1 Some(true), 0 Some(false), -1 None */
+DustStatus dust_vdb_tree_get(const DustVdbTree*, uint32_t x, uint32_t y, uint32_t z, int32_t* value);
+/* Tree::iter (tree.rs:102-104): writes up to cap (x,y,z) triples in iteration order, *count = total */
+DustStatus dust_vdb_tree_iter(const DustVdbTree*, uint32_t* xyz, size_t cap, size_t* count);
+/* Tree::iter_leaf (tree.rs:106-113): leaf origins, 64-bit occupancy and material_ptr per leaf */
+DustStatus dust_vdb_tree_iter_leaf(const DustVdbTree*, uint32_t* xyz, uint64_t* occupancy, uint32_t* material_ptr,
+                                   size_t cap, size_t* count);
+/* TreeMeta::META_MASK (tree.rs:154-167) and ROOT::LEVEL */
+DustStatus dust_vdb_tree_meta(const DustVdbTree*, uint32_t* meta_mask, uint32_t* root_level);
+/* lowest_common_ancestor_level (accessor.rs:15-30) */
+uint32_t dust_vdb_lca_level(const uint32_t a[3], const uint32_t b[3], uint32_t meta_mask, uint32_t root_level);
+/* Tree::accessor + Accessor::get (accessor.rs:37-57,125-131) */
+DustStatus dust_vdb_accessor_create(const DustVdbTree*, DustVdbAccessor** out);
+void dust_vdb_accessor_destroy(DustVdbAccessor*);
+DustStatus dust_vdb_accessor_get(DustVdbAccessor*, uint32_t x, uint32_t y, uint32_t z, int32_t* value);
+
+/* BitMask / Pool of crates/vdb (bitmask.rs:3-124, pool.rs:3-176), exposed for the reference's doctests */
+typedef struct DustVdbPool DustVdbPool;
+DustStatus dust_vdb_pool_create(size_t item_size, uint32_t chunk_size_log2, DustVdbPool** out); /* Pool::new */
+void dust_vdb_pool_destroy(DustVdbPool*);
+uint32_t dust_vdb_pool_alloc(DustVdbPool*);            /* Pool::alloc */
+void dust_vdb_pool_free(DustVdbPool*, uint32_t index); /* Pool::free */
+size_t dust_vdb_pool_num_chunks(const DustVdbPool*);   /* Pool::num_chunks */
+/* BitMask::set / iter_set_bits over n_words 64-bit words */
+void dust_vdb_bitmask_set(uint64_t* words, size_t index, int32_t value);
+size_t dust_vdb_bitmask_iter_set_bits(const uint64_t* words, size_t n_words, uint32_t* out, size_t cap);
+
+/* ===================================================================== .vox loader (host)
+ * Replaces VoxLoader::load up to the point where it uploads (crates/vox/src/loader.rs:322-415):
+ * file parse (dot_vox 5.1.1 in the reference), scene-graph walk (loader.rs:60-204), per-model
+ * tree build + palette-index collector (loader.rs:238-288, collector.rs:2-88) and
+ * VoxGeometry::from_tree (geometry.rs:55-179). */
+typedef struct DustVoxScene DustVoxScene;
+
+/* GPUVoxNode / shader `Block`, 24 bytes (geometry.rs:40-49, assets/shaders/headers/sbt.glsl:1-19) */
+typedef struct DustHipBlock {
+  uint16_t x, y, z, w;
+  uint64_t mask;
+  uint32_t material_ptr;
+  uint32_t avg_albedo; /* R10 G10 B10 A2, sRGB-encoded */
+} DustHipBlock;
+
+typedef struct DustVoxModelInfo {
+  uint32_t size[3]; /* model.size in file axes */
+  uint32_t n_voxels;
+  uint32_t n_blocks;      /* leaves of the tree == primitives of the reference BLAS */
+  uint64_t n_materials;   /* bytes in the material buffer */
+  uint32_t used;          /* referenced by at least one instance (loader.rs:360-372 only loads those) */
+} DustVoxModelInfo;
+
+typedef struct DustVoxInstance {
+  uint32_t model;
+  float obj_to_world[12]; /* 3x4 row-major, the TLAS instance transform (accel_struct/tlas.rs:99-105) */
+} DustVoxInstance;
+
+DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** out);
+void dust_vox_scene_destroy(DustVoxScene*);
+DustStatus dust_vox_scene_counts(const DustVoxScene*, uint32_t* n_models, uint32_t* n_instances);
+DustStatus dust_vox_scene_model_info(const DustVoxScene*, uint32_t model, DustVoxModelInfo* out);
+/* pointers stay valid until the scene is destroyed */
+DustStatus dust_vox_scene_model_data(const DustVoxScene*, uint32_t model, const DustHipBlock** blocks,
+                                     const uint8_t** materials);
+DustStatus dust_vox_scene_palette(const DustVoxScene*, const uint8_t** rgba255x4); /* load_palette, loader.rs:208-236 */
+DustStatus dust_vox_scene_instances(const DustVoxScene*, DustVoxInstance* out, uint32_t cap);
+
+/* load_model + from_tree on caller-provided voxels (file axes, i = 0-based palette index).
+ * Outputs are malloc'ed by the library; release with dust_vox_free(). */
+DustStatus dust_vox_flatten_model(const uint8_t* xyzi, size_t n_voxels, const uint32_t size[3],
+                                  const uint8_t* palette_rgba256, DustHipBlock** blocks, uint32_t* n_blocks,
+                                  uint8_t** materials, uint64_t* n_materials);
+void dust_vox_free(void*);
+
+/* ===================================================================== device side
+ * Replaces the Vulkan objects the render plugin owns (crates/render/src/lib.rs:58-134): device,
+ * BLAS/TLAS stores, SBT, the four ray-tracing pipelines and their persistent buffers. */
+typedef struct DustHipContext DustHipContext;
+typedef struct DustHipModel DustHipModel;
+typedef struct DustHipScene DustHipScene;
+typedef struct DustHipPipeline DustHipPipeline;
+
+typedef struct DustHipConfig {
+  uint32_t struct_size;     /* sizeof(DustHipConfig) */
+  int32_t device;           /* HIP device ordinal; -1 = current device */
+  void* stream;             /* hipStream_t to launch on; NULL = a stream owned by the context */
+  uint32_t lds_root_bytes;  /* LDS budget for staged root nodes per workgroup; 0 = default (64 KiB) */
+  uint32_t flags;           /* DUST_HIP_CONTEXT_* */
+} DustHipConfig;
+#define DUST_HIP_CONTEXT_TIMING 1u /* record hipEvents around every pass (dust_hip_pipeline_pass_stats) */
+
+/* RenderPlugin::build -> device creation (crates/render/src/lib.rs:58-134) */
+DustStatus dust_hip_context_create(const DustHipConfig*, DustHipContext** out);
+void dust_hip_context_destroy(DustHipContext*);
+DustStatus dust_hip_sync(DustHipContext*); /* waits for everything submitted on the context's stream */
+
+/* Geometry + Material registration: VoxGeometry (AABB buffer + Block buffer, vox/src/geometry.rs:129-165),
+ * PaletteMaterial parameters {geometry_ptr, material_ptr, palette_ptr} (vox/src/material.rs:30-41,106-119),
+ * and the BLAS build (render/src/accel_struct/blas.rs:125-230), which here is the device-side VDB hierarchy.
+ * tree_extent_log2: 8 for hierarchy!(4,2,2), 12 for (4,4,2,2). */
+DustStatus dust_hip_model_create(DustHipContext*, const DustHipBlock* blocks, uint32_t n_blocks,
+                                 const uint8_t* materials, uint64_t n_materials, const uint8_t* palette_rgba255x4,
+                                 uint32_t tree_extent_log2, DustHipModel** out);
+void dust_hip_model_destroy(DustHipModel*);
+
+/* TLASStore (render/src/accel_struct/tlas.rs:28-180) + the prev-frame transform vec (standard.rs:845-878) */
+DustStatus dust_hip_scene_create(DustHipContext*, DustHipScene** out);
+void dust_hip_scene_destroy(DustHipScene*);
+/* tlas_system push (tlas.rs:79-128): returns gl_InstanceID == push order */
+DustStatus dust_hip_scene_add_instance(DustHipScene*, const DustHipModel*, const float obj_to_world[12],
+                                       const float prev_obj_to_world_mat4[16], uint32_t* instance_id);
+DustStatus dust_hip_scene_set_transform(DustHipScene*, uint32_t instance_id, const float obj_to_world[12],
+                                        const float prev_obj_to_world_mat4[16]);
+/* TLAS build (tlas.rs:43-64): uploads instance records; must be called after add/set before rendering */
+DustStatus dust_hip_scene_commit(DustHipScene*);
+
+/* the members of CameraSettings the shaders read (standard.rs:277-302,813-827; layout.playout:20-33) */
+typedef struct DustHipCamera {
+  float view_col0[3], view_col1[3], view_col2[3]; /* camera_view_col0..2 */
+  float position[3];
+  float tan_half_fov, far_, near_;
+} DustHipCamera;
+
+/* SkyModelState as Sunlight::bake() produces it, 56 floats (pipeline/sky.rs:66-132; layout.playout:35-51) */
+typedef struct DustHipSky { float state[56]; } DustHipSky;
+
+/* GBuffer planes (standard.rs:881-917; formats :974-1050) */
+typedef enum DustHipPlane {
+  DUST_PLANE_ILLUMINANCE = 0, /* RGBA16F, 8 B/px  (img_illuminance) */
+  DUST_PLANE_DENOISED = 1,    /* RGBA16F, 8 B/px  (img_illuminance_denoised) */
+  DUST_PLANE_ALBEDO = 2,      /* A2B10G10R10, 4 B/px */
+  DUST_PLANE_NORMAL = 3,      /* A2B10G10R10, 4 B/px */
+  DUST_PLANE_DEPTH = 4,       /* R32F, 4 B/px */
+  DUST_PLANE_MOTION = 5,      /* RGBA16F, 8 B/px */
+  DUST_PLANE_VOXEL_ID = 6,    /* R32UI, 4 B/px */
+  DUST_PLANE_ACCUM = 7,       /* RGBA32F, 16 B/px: N-frame mean of unpacked illuminance (stands in for NRD) */
+  DUST_PLANE_COUNT = 8
+} DustHipPlane;
+
+/* ray types (StandardPipeline::*_RAYTYPE, standard.rs:223-226) double as pass bits */
+#define DUST_PASS_PRIMARY (1u << 0)            /* standard.rs:477-490 */
+#define DUST_PASS_AMBIENT_OCCLUSION (1u << 1)  /* standard.rs:564-577 (sun shadow + AO ray) */
+#define DUST_PASS_FINAL_GATHER (1u << 2)       /* standard.rs:627-640 */
+#define DUST_PASS_SURFEL (1u << 3)             /* standard.rs:712-725 */
+#define DUST_PASS_ACCUMULATE (1u << 4)         /* stands in for NRDPipeline::render (nrd.rs:272-617) */
+#define DUST_PASS_COUNT_STATS (1u << 16)       /* run the counting build of the kernels (slower) */
+
+typedef struct DustHipFrameParams {
+  uint32_t struct_size;
+  uint32_t passes;       /* DUST_PASS_* */
+  uint32_t frame_index;  /* push constant frame_index (standard.rs:252,457-463) */
+  uint32_t rand;         /* push constant rand (standard.rs:449-456) */
+  uint32_t row_begin, row_end; /* rows of the frame this call renders (multi-GPU bands); 0,0 = all */
+} DustHipFrameParams;
+
+typedef struct DustHipPassStats {
+  float ms;                 /* kernel time from HIP events on the launch stream (needs DUST_HIP_CONTEXT_TIMING) */
+  uint64_t rays;            /* rays issued (needs DUST_PASS_COUNT_STATS, else 0) */
+  uint64_t instances_tested;
+  uint64_t upper_descents;
+  uint64_t mid_descents;
+  uint64_t bricks_tested;
+  uint64_t hits;
+} DustHipPassStats;
+
+/* StandardPipeline::new + use_gbuffer (standard.rs:90-173, :940-1065): persistent buffers and G-buffer */
+DustStatus dust_hip_pipeline_create(DustHipContext*, uint32_t width, uint32_t height, DustHipPipeline** out);
+void dust_hip_pipeline_destroy(DustHipPipeline*);
+/* BlueNoise (noise.rs:7-56): texture 0 (scalar, R8) or 5 (unitvec3_cosine, RGBA8), 128 x 128 x layers */
+DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const uint8_t* texels, uint32_t layers);
+/* StandardPipeline::render (standard.rs:228-810). Asynchronous on the context's stream.
+ * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set. */
+DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
+                                 const DustHipFrameParams*);
+/* pass: 0 primary, 1 AO sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel; valid after dust_hip_sync */
+DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
+DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline*, DustHipPlane, void** ptr, size_t* bytes);
+/* synchronous device-to-host copy of one plane */
+DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* dst, size_t dst_bytes);
+/* zero every plane and the accumulation count */
+DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+"""Shared helpers for the parity tests, __graft_entry__.smoke() and bench.py's cpu_baseline leg:
+build the same scene for the HIP library (through the C ABI) and for the CPU oracle, render, compare."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as O
+from dust_amd import _lib as L
+from dust_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sky_state(name="default"):
+    with open(os.path.join(ROOT, "tests", "golden", "sky_states.json")) as f:
+        return np.asarray(json.load(f)[name]["state"], np.float32)
+
+
+class SceneDesc:
+    """Flattened scene: models [(blocks, materials)], one palette, instances [(model, obj_to_world[12])]."""
+
+    def __init__(self, models, palette, instances):
+        self.models, self.palette, self.instances = models, palette, instances
+
+    @staticmethod
+    def from_vox(data: bytes):
+        vs = api.VoxScene(data)
+        used = sorted({m for m, _ in vs.instances})
+        remap = {m: i for i, m in enumerate(used)}
+        models = [vs.model_data(m) for m in used]
+        return SceneDesc(models, vs.palette, [(remap[m], t) for m, t in vs.instances])
+
+    def n_bricks(self):
+        return sum(len(b) for b, _ in self.models)
+
+
+def random_model(rng, size=(48, 40, 56), fill=0.08, blobs=6):
+    """A sparse random model plus a few solid blobs, returned as xyzi (0-based colour index)."""
+    sx, sy, sz = size
+    solid = rng.random(size) < fill
+    for _ in range(blobs):
+        c = [int(rng.integers(0, s)) for s in size]
+        r = int(rng.integers(3, 9))
+        x, y, z = np.ogrid[:sx, :sy, :sz]
+        solid |= (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2 <= r * r
+    x, y, z = np.nonzero(solid)
+    xyzi = np.stack([x, y, z, rng.integers(0, 255, x.size)], axis=1).astype(np.uint8)
+    return xyzi
+
+
+def small_scene(seed=1, n_models=3, n_instances=5, size=(48, 40, 56)):
+    """Random models flattened by the product loader, instances with axis rotations/mirrors and offsets."""
+    rng = np.random.default_rng(seed)
+    pal = synth.make_palette(seed)
+    models = []
+    for _ in range(n_models):
+        sz = tuple(int(v) for v in (rng.integers(size[0] // 2, size[0] + 1), rng.integers(size[1] // 2, size[1] + 1),
+                                    rng.integers(size[2] // 2, size[2] + 1)))
+        xyzi = random_model(rng, sz)
+        models.append(api.flatten_model(xyzi, sz, pal))
+    rots = [np.eye(3), np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]]), np.array([[-1, 0, 0], [0, 1, 0], [0, 0, -1]]),
+            np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]]), np.array([[-1, 0, 0], [0, 1, 0], [0, 0, 1]])]
+    instances = []
+    for i in range(n_instances):
+        m = np.zeros((3, 4), np.float32)
+        m[:, :3] = rots[i % len(rots)]
+        m[:, 3] = rng.integers(-60, 60, 3) + (0.5 if i % 2 else 0.0)
+        instances.append((int(rng.integers(0, n_models)), m.reshape(12)))
+    return SceneDesc(models, pal, instances)
+
+
+def oracle_scene(desc: SceneDesc):
+    s = O.Scene()
+    for b, m in desc.models:
+        s.add_model(b, m, desc.palette)
+    for mid, t in desc.instances:
+        s.add_instance(mid, t)
+    s.commit()
+    return s
+
+
+def hip_scene(ctx, desc: SceneDesc):
+    models = [api.Model(ctx, b, m, desc.palette) for b, m in desc.models]
+    s = api.Scene(ctx)
+    for mid, t in desc.instances:
+        s.add_instance(models[mid], t)
+    s.commit()
+    return s
+
+
+def camera_for(desc_or_eye, target=(0.0, 0.0, 0.0), proj=None):
+    proj = proj or api.PinholeProjection()
+    eye = desc_or_eye
+    return api.make_camera(eye, api.look_at_rotation(eye, target), proj)
+
+
+def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.ORC_MODE_HIER, rows=None, stats=None):
+    g = O.GBuffer(w, h)
+    oc, osky = O.camera_from(cam), O.sky_from(sky)
+    y0, y1 = rows if rows else (0, h)
+    st = stats if stats is not None else [O.OrcRayStats(), O.OrcRayStats(), O.OrcRayStats()]
+    l = O.lib()
+    if passes & L.PASS_PRIMARY:
+        l.orc_pass_primary(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), y0, y1, C.byref(st[0]))
+    if passes & L.PASS_AMBIENT_OCCLUSION:
+        n5 = np.ascontiguousarray(noise5, np.uint8)
+        l.orc_pass_ao(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), n5.ctypes.data_as(C.c_void_p), rand, y0, y1,
+                      C.byref(st[1]), C.byref(st[2]))
+    return g
+
+
+PLANES = [("illuminance", L.PLANE_ILLUMINANCE), ("denoised", L.PLANE_DENOISED), ("albedo", L.PLANE_ALBEDO),
+          ("normal", L.PLANE_NORMAL), ("depth", L.PLANE_DEPTH), ("motion", L.PLANE_MOTION), ("voxel_id", L.PLANE_VOXEL_ID)]
+
+
+def read_hip_gbuffer(pipe):
+    return {name: pipe.read_plane(pid) for name, pid in PLANES}
+
+
+def half_to_float(a):
+    return a.view(np.float16).astype(np.float32)
+
+
+def compare_gbuffers(g, hip, check_ao=False):
+    """Returns a dict of mismatch counts. Integer/packed planes and depth must be bit-exact where the
+    reference defines them (hit pixels: all planes; miss pixels: denoised, albedo, depth, motion)."""
+    depth = g.depth
+    hit = np.isfinite(depth)
+    res = {}
+    res["depth"] = int(np.count_nonzero(depth.view(np.uint32) != hip["depth"].view(np.uint32)))
+    res["albedo"] = int(np.count_nonzero(g.albedo != hip["albedo"]))
+    res["motion"] = int(np.count_nonzero((g.motion != hip["motion"]).any(axis=-1)))
+    res["normal"] = int(np.count_nonzero((g.normal != hip["normal"]) & hit))
+    res["voxel_id"] = int(np.count_nonzero((g.voxel_id != hip["voxel_id"]) & hit))
+    # radiance planes go through exp/pow/acos: compare as floats
+    den_o, den_h = half_to_float(g.denoised), half_to_float(hip["denoised"])
+    miss = ~hit
+    if miss.any():
+        a, b = den_o[miss][:, :3], den_h[miss][:, :3]
+        res["denoised_rel_l2"] = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))
+        res["denoised_hitdist"] = int(np.count_nonzero(g.denoised[miss][:, 3] != hip["denoised"][miss][:, 3]))
+    ill_o, ill_h = half_to_float(g.illuminance), half_to_float(hip["illuminance"])
+    if hit.any():
+        a, b = ill_o[hit][:, :3], ill_h[hit][:, :3]
+        res["illuminance_rel_l2"] = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))
+        res["illuminance_hitdist"] = int(np.count_nonzero(g.illuminance[hit][:, 3] != hip["illuminance"][hit][:, 3]))
+    return res
+
+
+def assert_parity(res):
+    for k in ("depth", "albedo", "motion", "normal", "voxel_id"):
+        assert res[k] == 0, f"{k}: {res[k]} pixels differ ({res})"
+    for k in ("denoised_hitdist", "illuminance_hitdist"):
+        assert res.get(k, 0) == 0, f"{k}: {res[k]} pixels differ ({res})"
+    for k in ("denoised_rel_l2", "illuminance_rel_l2"):
+        assert res.get(k, 0.0) <= 1e-3, f"{k} = {res[k]} exceeds 1e-3 ({res})"  # north_star tolerance
+
+
+def run_smoke():
+    """__graft_entry__.smoke(): one 96x64 primary + AO frame on device 0 against the oracle."""
+    desc = small_scene(seed=3)
+    ctx = api.Context(device=0)
+    scene = hip_scene(ctx, desc)
+    w, h = 96, 64
+    pipe = api.StandardPipeline(ctx, w, h)
+    noise5 = synth.stbn_unitvec3_cosine(layers=2)
+    pipe.set_noise(5, noise5)
+    cam = camera_for((90.0, 70.0, 110.0))
+    sky = sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    pipe.render(scene, cam, sky, passes, frame_index=1, rand=12345)
+    ctx.sync()
+    hip = read_hip_gbuffer(pipe)
+    g = render_oracle(oracle_scene(desc), cam, sky, w, h, passes, noise5[1 % 2], 12345)
+    res = compare_gbuffers(g, hip)
+    assert_parity(res)
+    print("smoke ok:", res, "hit pixels:", int(np.isfinite(g.depth).sum()))
