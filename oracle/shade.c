@@ -578,16 +578,21 @@ static int slab_box(v3 o, v3 d, const float lo[3], const float hi[3], float* t_e
   return !(te > tx + slack) && !(tx + slack < 0.0f);
 }
 
-/* deepest occupied cell containing voxel ijk: returns block index or -1, *cell_log2 = size of the empty cell */
-static int find_brick(const SceneModel* m, const int ijk[3], uint32_t* cell_log2, OrcRayStats* st) {
+/* deepest occupied cell containing voxel ijk: returns block index or -1, *cell_log2 = size of the empty cell.
+ * last16: key of the 16-cell whose mid node the caller already holds (the HIP kernel keeps that node in
+ * registers), so that the descent statistics count each mid node once per visit run. */
+static int find_brick(const SceneModel* m, const int ijk[3], uint32_t* cell_log2, OrcRayStats* st, uint64_t* last16) {
+  uint64_t key16 = cell_key((uint32_t)ijk[0] >> 4, (uint32_t)ijk[1] >> 4, (uint32_t)ijk[2] >> 4);
+  int cached = last16 && *last16 == key16;
   for (int l = 0; l < m->n_lv; ++l) {
     uint32_t sh = m->lv_log2[l];
     if (find_key(m->lv_keys[l], m->lv_n[l], cell_key((uint32_t)ijk[0] >> sh, (uint32_t)ijk[1] >> sh, (uint32_t)ijk[2] >> sh)) < 0) {
       *cell_log2 = sh;
       return -1;
     }
-    if (st) st->upper_descents += 1;
+    if (st && !cached) st->upper_descents += 1;
   }
+  if (last16) *last16 = key16;
   int k = find_key(m->brick_keys, m->n_blocks, cell_key((uint32_t)ijk[0] >> 2, (uint32_t)ijk[1] >> 2, (uint32_t)ijk[2] >> 2));
   *cell_log2 = 2;
   if (k < 0) return -1;
@@ -610,6 +615,7 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
   if (rc->raytype >= 2) t = fmaxf(t, rc->tmin * (1.0f - 1e-6f));
   int ijk[3];
   int stepped[3] = {0, 0, 0};
+  uint64_t last16 = ~(uint64_t)0;
   for (int a = 0; a < 3; ++a) {
     int v = f2i_sat(floorf(oo[a] + dd[a] * t));
     ijk[a] = v < 0 ? 0 : (v > E - 1 ? E - 1 : v);
@@ -619,7 +625,7 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
     if (t * (1.0f - 2e-6f) > limit) return;
     if (rc->any_hit && rc->best.found) return;
     uint32_t cl;
-    int bi = find_brick(m, ijk, &cl, rc->st);
+    int bi = find_brick(m, ijk, &cl, rc->st, &last16);
     if (bi >= 0) test_brick(rc, m, inst, (uint32_t)bi, o, d);
     /* neighbours around a brick-grid edge/corner the ray passes within delta of */
     int near_dir[3] = {0, 0, 0};
@@ -648,7 +654,7 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
         if (!ok) continue;
         if (only_stepped && all_stepped_in && n_stepped > 0) continue; /* the cell we came from */
         uint32_t cl2;
-        int nb = find_brick(m, nj, &cl2, NULL);
+        int nb = find_brick(m, nj, &cl2, NULL, NULL);
         if (nb >= 0) test_brick(rc, m, inst, (uint32_t)nb, o, d);
       }
     }
