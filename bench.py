@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the HIP ray-tracing hot path on the castle stand-in (BASELINE.json configs[1]).
+
+One "step" = one frame of the hot path over resident inputs: primary visibility + sun-shadow + ambient
+occlusion passes (StandardPipeline::render's first two vkCmdTraceRaysKHR calls, standard.rs:477-577) at
+1920x1080, 1 spp. "N spp" in the reference means N consecutive frames (frame_index -> STBN slice, fresh
+rand), and those frames are independent for these passes, so with N GPUs a step renders N
+samples of the same view -- rank r takes frame_index k*N + r -- and every rank's RGBA16F illuminance
+frame is gathered to rank 0 over RCCL inside the timed region (weak scaling: 1080p x 1 spp per GPU).
+Row-band sharding of one frame (dust_hip_render_frame row_begin/row_end) is covered by the tests.
+A ray = one traceRayEXT equivalent actually issued (primary / sun-shadow / AO), counted by the counting
+build of the kernels in an untimed frame.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+algorithmic bytes / HIP-event time) and `cpu_baseline` (the C oracle's hierarchical traversal, a port
+of the algorithm -- the reference has no CPU ray traversal at all, SURVEY F2 -- on a bounded row sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scale", type=float, default=1.0, help="castle stand-in scale (1.0 = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st, gbuffer_bytes_per_ray):
+    """64 B per instance tested, 8+4 per root/mid child descended, 24 per brick tested,
+    1+4 per hit (material byte + palette entry), plus the pass's G-buffer traffic."""
+    return (st.instances_tested * 64 + (st.upper_descents + st.mid_descents) * 12 + st.bricks_tested * 24 + st.hits * 5
+            + gbuffer_bytes_per_ray)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import numpy as np
+    import torch  # device memory for the gathered framebuffer, streams, torch.distributed (RCCL): plumbing only
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from dust_amd import _lib as L
+    from dust_amd import api, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_util as P  # scene description helpers + sky fixture (shared with the tests)
+
+    W, H = args.width, args.height
+    Hband = H
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(stream))
+
+    t0 = time.time()
+    data, info = synth.castle_scene(scale=args.scale)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
+    t_load = time.time() - t0
+    scene = P.hip_scene(ctx, desc)
+    pipe = api.StandardPipeline(ctx, W, H)
+    noise5 = synth.stbn_unitvec3_cosine()
+    pipe.set_noise(5, noise5)
+    sky = P.sky_state("default")
+    s = args.scale
+    proj = api.PinholeProjection()
+    # examples/castle.rs:120-129: eye (122, 300.61, 54.45) -> origin, fov pi/4
+    eye = (122.0 * s, 300.61 * s, 54.45 * s)
+    cam = api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), proj)
+    rows = (0, H)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+
+    # framebuffer gather target: the illuminance plane lives in a torch tensor so RCCL can move it
+    band_px = W * Hband
+    ill_ptr, ill_bytes = pipe.plane_device_ptr(L.PLANE_ILLUMINANCE)
+    band = torch.empty((Hband, W, 4), dtype=torch.float16, device="cuda")
+    gathered = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
+    hip = ctypes.CDLL("libamdhip64.so.7")  # resolves to the copy torch / libdust_hip already loaded (same SONAME)
+
+    def step(k, count=False):
+        frame_index = k * world + rank + 1  # sample k*N + r of the spp sequence (frame_index starts at 1, standard.rs:252)
+        pipe.render(scene, cam, sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=frame_index,
+                    rand=synth.frame_rand(1, frame_index))
+        if world > 1:
+            # one device-to-device copy of the frame into the torch tensor, then gather to rank 0
+            src = ill_ptr
+            rc = hip.hipMemcpyAsync(ctypes.c_void_p(band.data_ptr()), ctypes.c_void_p(src), ctypes.c_size_t(band_px * 8),
+                                    ctypes.c_int(3), ctypes.c_void_p(stream))
+            assert rc == 0, rc
+            dist.gather(band, gathered, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed counting frame: rays per class and algorithmic bytes per launch
+    step(0, count=True)
+    barrier()
+    st = [pipe.pass_stats(i) for i in range(3)]
+    rays_rank = sum(x.rays for x in st)
+    names = ("primary", "sun_shadow", "ambient_occlusion")
+    hit_px = st[0].hits
+    miss_px = st[0].rays - st[0].hits
+    bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
+    # AO kernel: per live pixel read depth 4 + normal 4 + illuminance 8, write illuminance 8 (hit.rchit/ao.rgen)
+    bytes_ao = algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0) - (st[1].hits + st[2].hits) * 5 + hit_px * 24
+
+    for i in range(args.warmup):
+        step(1 + i)
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(1 + args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    # kernel durations from the HIP events the library recorded on the launch stream (last timed step)
+    ms_primary = pipe.pass_stats(0).ms
+    ms_ao = pipe.pass_stats(1).ms
+    # average the event timing over a few more (untimed) frames so it is not a single sample
+    acc_p, acc_a, reps = ms_primary, ms_ao, 1
+    for i in range(min(8, max(0, args.steps - 1))):
+        step(100 + i)
+        torch.cuda.synchronize()
+        acc_p += pipe.pass_stats(0).ms
+        acc_a += pipe.pass_stats(1).ms
+        reps += 1
+    ms_primary, ms_ao = acc_p / reps, acc_a / reps
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays_all = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_max.item())
+    total_rays_per_step = float(rays_all.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = total_rays_per_step * args.steps / elapsed / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
+    achieved = dominant[1] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            if pm.get("workload") == "castle-standin" and abs(pm.get("scale", 1.0) - args.scale) < 1e-9:
+                traffic = pm.get("hbm_bytes_per_launch", {}).get(dominant[0])
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
+                "kernels_ms": {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)},
+                "bytes_per_ray": {"primary": round(bytes_primary / max(1, st[0].rays), 1),
+                                  "ao_pass": round(bytes_ao / max(1, st[1].rays + st[2].rays), 1)}}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle_lib as O  # the checker, used here only as the reported CPU baseline (never in the timed GPU path)
+        oscene = P.oracle_scene(desc)
+        cores = os.cpu_count() or 1
+        n_rows = args.cpu_rows or max(cores, min(Hband, 8 * cores))
+        y0 = (Hband - n_rows) // 2
+        g = O.GBuffer(W, H)
+        oc, osky = O.camera_from(cam), O.sky_from(sky)
+        n5 = np.ascontiguousarray(noise5[1 % len(noise5)])
+        stats = [[O.OrcRayStats(), O.OrcRayStats(), O.OrcRayStats()] for _ in range(cores)]
+        lib = O.lib()
+
+        def work(t):
+            a = y0 + (n_rows * t) // cores
+            b = y0 + (n_rows * (t + 1)) // cores
+            lib.orc_pass_primary(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c), a, b,
+                                 ctypes.byref(stats[t][0]))
+            lib.orc_pass_ao(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c),
+                            n5.ctypes.data_as(ctypes.c_void_p), synth.frame_rand(1, 1), a, b, ctypes.byref(stats[t][1]),
+                            ctypes.byref(stats[t][2]))
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dt = time.perf_counter() - t0
+        cpu_rays = sum(s_.rays for ss in stats for s_ in ss)
+        cpu = {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"rows {y0}..{y0 + n_rows} of the same frame ({cpu_rays} rays, {dt:.1f} s), oracle hierarchical mode, "
+                         f"{cores} threads; tree build + flatten of the whole scene took {t_load:.2f} s on the same cores"}
+
+    out = {
+        "metric": "Mrays/s at 1920x1080 1spp castle.vox (primary + sun-shadow + AO rays)",
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "castle.vox stand-in (synth.castle_scene seed 0xD057), 1920x1080 per GPU, 1spp primary+shadow+AO"
+                   if args.scale == 1.0 else f"castle stand-in at scale {args.scale}",
+                   "frame": [W, H], "spp_per_step": world,
+                   "parallelism": f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",
+                   "models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
+                   "bricks": desc.n_bricks(), "scene_build_s": round(t_load, 3),
+                   "rays_per_step": {n: int(x.rays) for n, x in zip(names, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

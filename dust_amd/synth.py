@@ -162,7 +162,9 @@ def model_house(size, rng, wall_colours, roof_colours):
     wall_h = int(sz * 0.6)
     solid = np.zeros(size, bool)
     solid[:, :, :wall_h] = True
-    solid[3:sx - 3, 3:sy - 3, 3:wall_h] = False
+    solid[4:sx - 4, 4:sy - 4, 4:wall_h] = False
+    for fz in range(20, wall_h - 4, 18):  # interior floors
+        solid[:, :, fz:fz + 3] = True
     colour = _colour_field(size, rng, wall_colours)
     # gable roof along x
     for k in range(sz - wall_h):
@@ -227,12 +229,12 @@ def castle_scene(seed=0xD057, scale=1.0):
     def place(mid, x, y, z, r=ROT_IDENTITY):
         instances.append((mid, (int(round(x * scale)), int(round(y * scale)), int(round(z * scale))), r))
 
-    # ground: two slab variants, 5x5 grid of 256x256x8, z centred at -4 so the top is at z = 0
+    # ground: two slab variants, 5x5 grid of 256x256x24, z centred at -12 so the top is at z = 0
     g = s(256)
-    slabs = [add_model(model_box((g, g, s(8)), rng, earth + [9, 10])), add_model(model_box((g, g, s(8)), rng, earth + stone))]
+    slabs = [add_model(model_box((g, g, s(24)), rng, earth + [9, 10])), add_model(model_box((g, g, s(24)), rng, earth + stone))]
     for i in range(-2, 3):
         for j in range(-2, 3):
-            place(slabs[(i + j) & 1], i * 256, j * 256, -4)
+            place(slabs[(i + j) & 1], i * 256, j * 256, -12)
     # curtain walls: 3 variants, 256 x 24 x 96, crenellated, ring at +-384
     walls = [add_model(model_box((s(256), s(24), s(96)), rng, stone if k else stone + dark, crenel=s(6))) for k in range(3)]
     for k, off in enumerate((-256, 0, 256)):
@@ -261,15 +263,15 @@ def castle_scene(seed=0xD057, scale=1.0):
     n_house_models = 85
     houses = []
     for k in range(n_house_models):
-        sz = (s(int(rng.integers(40, 72))), s(int(rng.integers(36, 64))), s(int(rng.integers(40, 80))))
+        sz = (s(int(rng.integers(56, 104))), s(int(rng.integers(48, 88))), s(int(rng.integers(48, 96))))
         houses.append((add_model(model_house(sz, rng, stone + wood, roof)), sz))
     rots = (ROT_IDENTITY, ROT_Z90, ROT_Z180, ROT_Z270)
     placed = 0
-    grid = [(x, y) for x in range(-560, 561, 80) for y in range(-560, 561, 80)
+    grid = [(x, y) for x in range(-600, 601, 100) for y in range(-600, 601, 100)
             if not (abs(x) < 150 and abs(y) < 150) and not (330 < max(abs(x), abs(y)) < 440)]
     order = rng.permutation(len(grid))
     group_members = []
-    for gi in order[:105]:
+    for gi in order[:110]:
         x, y = grid[gi]
         mid, sz = houses[placed % n_house_models]
         place(mid, x + int(rng.integers(-10, 11)), y + int(rng.integers(-10, 11)), sz[2] / (2.0 * scale), rots[int(rng.integers(0, 4))])
