@@ -17,9 +17,9 @@
 #include "vox.hpp"
 
 namespace dust {
-hipError_t launch_primary(const FrameArgs&, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_ambient_occlusion(const FrameArgs&, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_accumulate(const FrameArgs&, hipStream_t);
+hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
 hipError_t configure_kernels(size_t max_lds);
 }  // namespace dust
 
@@ -122,6 +122,13 @@ struct DustHipPipeline {
   uint32_t accum_count = 0;
   hipEvent_t ev[8] = {};
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
+  // launch descriptors: a ring of pinned host slots mirrored in device memory, one slot per kernel launch
+  static constexpr int kArgSlots = 32;
+  dust::FrameArgs* host_args = nullptr;  // hipHostMalloc
+  DeviceBuffer dev_args;
+  hipEvent_t slot_done[kArgSlots] = {};
+  bool slot_used[kArgSlots] = {};
+  int next_slot = 0;
   bool stats_valid = false;
   dust::DevStats host_stats[4] = {};
 };
@@ -618,6 +625,9 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     HIP_TRY(p->counters.alloc(64 * sizeof(uint32_t)));
     HIP_TRY(p->stats.alloc(4 * sizeof(dust::DevStats)));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_args), sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots, hipHostMallocDefault));
+    HIP_TRY(p->dev_args.alloc(sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots));
+    for (auto& e : p->slot_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     *out = p.release();
     return DUST_OK;
   });
@@ -625,6 +635,8 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
 void dust_hip_pipeline_destroy(DustHipPipeline* p) {
   if (!p) return;
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : p->slot_done) if (e) (void)hipEventDestroy(e);
+  if (p->host_args) (void)hipHostFree(p->host_args);
   delete p;
 }
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
@@ -634,6 +646,19 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, con
   const size_t bytes = size_t(128) * 128 * layers * (texture == 0 ? 1 : 4);
   if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes)); p->noise0_layers = layers; }
   else { HIP_TRY(p->noise5.upload(texels, bytes)); p->noise5_layers = layers; }
+  return DUST_OK;
+}
+
+// copies one launch descriptor into the next ring slot (pinned host -> device, on the launch stream)
+static DustStatus upload_args(DustHipPipeline* p, const dust::FrameArgs& a, hipStream_t st, const dust::FrameArgs** dev) {
+  const int slot = p->next_slot;
+  if (p->slot_used[slot]) HIP_TRY(hipEventSynchronize(p->slot_done[slot]));  // the launch that last read this slot is done
+  p->host_args[slot] = a;
+  dust::FrameArgs* d = static_cast<dust::FrameArgs*>(p->dev_args.p) + slot;
+  HIP_TRY(hipMemcpyAsync(d, &p->host_args[slot], sizeof(dust::FrameArgs), hipMemcpyHostToDevice, st));
+  p->slot_used[slot] = true;
+  p->next_slot = (slot + 1) % DustHipPipeline::kArgSlots;
+  *dev = d;
   return DUST_OK;
 }
 
@@ -694,7 +719,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
-    HIP_TRY(dust::launch_primary(a, grid, block, count, st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_primary(a, d, grid, block, count, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
   if (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) {
@@ -702,11 +730,17 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
-    HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_ambient_occlusion(a, d, grid, block, count, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
-    HIP_TRY(dust::launch_accumulate(a, st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_accumulate(d, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     p->accum_count += 1;
   }
   if (count) {

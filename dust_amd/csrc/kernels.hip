@@ -329,75 +329,93 @@ __device__ __forceinline__ void test_brick(const DevModel& m, uint32_t inst, uin
 // bricks whose intersection routine can report an accepted hit: exit planes are recomputed from
 // integer cell coordinates at every step (no accumulated error), and whenever the walk passes within
 // delta of a brick-grid edge or corner every brick around it is tested too (DESIGN.md "Conservative walk").
-template <int RT, bool ANY, bool COUNT>
-__device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, Hit& best,
-                               LaneStats& st) {
+// One loop iteration handles one cell: normally the cell the ray is in; when the entry point lies within
+// delta of other brick planes, the bricks across those planes are queued in `pending` (a 7-bit set of
+// axis subsets) and visited by the same code before the walk advances.
+template <int RT, bool COUNT>
+__device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
+                               Hit& best, LaneStats& st) {
   float te, tx;
   if (!slab_box(o, d, m.bmin, m.bmax, te, tx)) return;
   const int E = (int)m.extent;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-  const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
   float t = fmaxf(te, 0.0f);
   if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
   int ijk[3];
-  uint32_t stepped = 0;  // bit a: axis a crossed a plane on the last step
+  int blo[3], bhi[3];  // voxel range that holds bricks (tight bounds, multiples of 4)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * t), 0, E - 1);
+  for (int a = 0; a < 3; ++a) {
+    blo[a] = (int)m.bmin[a];
+    bhi[a] = (int)m.bmax[a] - 1;
+    // the cell the ray is moving into: floor for d >= 0, ceil - 1 for d < 0 (differs only on a cell plane)
+    const float p = oo[a] + dd[a] * t;
+    ijk[a] = f2i_clamp(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p), 0, E - 1);
+  }
+  uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
+  uint32_t pending = 0;   // bit (sub-1): neighbour subset `sub` still to visit
+  uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the brick's low / high plane on axis a
+  uint32_t cl_main = 2;
   MidCache mc;
   mc.key = -1;
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
-  for (int guard = 0; guard < 100000; ++guard) {
-    const float limit = best.found ? best.t : tmax;
-    if (t * (1.0f - 2e-6f) > limit) return;
-    if (ANY && best.found) return;
-    uint32_t cl;
-    const int bi = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl, mc, st, true);
-    if (bi >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)bi, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, tmin, tmax, best, st);
-    // bricks around a brick-grid edge/corner the ray passes within delta of (rare)
-    int near_dir[3];
-    uint32_t n_near_unstepped = 0;
+  for (int guard = 0; guard < 200000; ++guard) {
+    const bool is_main = pending == 0;
+    int c[3] = {ijk[0], ijk[1], ijk[2]};
+    if (is_main) {
+      const float limit = best.found ? best.t : tmax;
+      if (t * (1.0f - 2e-6f) > limit) return;
+      if (any_hit && best.found) return;
+    } else {
+      const uint32_t sub = (uint32_t)__ffs((int)pending);  // 1..7
+      pending &= pending - 1u;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float p = oo[a] + dd[a] * t;
-      const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
-      const float q = p - (float)(ijk[a] & ~3);
-      near_dir[a] = 0;
-      if (stepped & (1u << a)) near_dir[a] = dd[a] > 0.0f ? -1 : 1;
-      else if (q <= delta) { near_dir[a] = -1; n_near_unstepped++; }
-      else if (q >= 4.0f - delta) { near_dir[a] = 1; n_near_unstepped++; }
-    }
-    if (n_near_unstepped > 0 || __popc(stepped) > 1) {
-      for (uint32_t sub = 1; sub < 8; ++sub) {
-        bool ok = true;
-        int nj[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          nj[a] = ijk[a];
-          if (sub & (1u << a)) {
-            if (!near_dir[a]) ok = false;
-            nj[a] = near_dir[a] < 0 ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
-            if (nj[a] < 0 || nj[a] >= E) ok = false;
-          }
+      for (int a = 0; a < 3; ++a)
+        if (sub & (1u << a)) {
+          c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
         }
-        if (!ok) continue;
-        if (stepped != 0 && sub == stepped) continue;  // the cell we came from
+      {
         uint32_t cl2;
-        MidCache mc2;
-        mc2.key = -1;
-        const int nb = find_brick<COUNT>(m, nj[0], nj[1], nj[2], cl2, mc2, st, false);
-        if (nb >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)nb, nj[0] & ~3, nj[1] & ~3, nj[2] & ~3, o, d, tmin, tmax, best, st);
+        const int nb = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, mc, st, false);
+        if (nb >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)nb, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
+        if (pending != 0) continue;
       }
     }
-    // leave the cell of size 2^cl that contains ijk
-    const int S = 1 << cl;
+    if (is_main) {
+      const int bi = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, mc, st, true);
+      if (bi >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)bi, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
+      // which brick planes is the entry point within delta of?
+      near_neg = 0; near_pos = 0;
+      uint32_t unstepped_near = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float p = oo[a] + dd[a] * t;
+        const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
+        const float q = p - (float)(ijk[a] & ~3);
+        const int b0 = ijk[a] & ~3;
+        // a plane only matters if bricks can exist on its far side
+        if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo[a]) near_neg |= 1u << a; } else if (b0 + 4 <= bhi[a]) near_pos |= 1u << a; }
+        else if (q <= delta) { if (b0 - 1 >= blo[a]) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
+        else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi[a]) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+      }
+      const uint32_t nearm = near_neg | near_pos;
+      if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
+        pending = 0;
+#pragma unroll
+        for (uint32_t sub = 1; sub < 8; ++sub)
+          if ((sub & ~nearm) == 0 && !(stepped != 0 && sub == stepped)) pending |= 1u << (sub - 1);  // sub == stepped: the cell we came from
+        if (pending != 0) continue;
+      }
+    }
+    // leave the cell of size 2^cl_main that contains ijk
+    const int S = 1 << cl_main;
     float ta[3], tn = INFINITY;
-    int c[3];
+    int cc[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      c[a] = ijk[a] & ~(S - 1);
+      cc[a] = ijk[a] & ~(S - 1);
       if (dd[a] != 0.0f) {
-        const float plane = (float)(dd[a] > 0.0f ? c[a] + S : c[a]);
-        ta[a] = (plane - oo[a]) * inv[a];
+        const float plane = (float)(dd[a] > 0.0f ? cc[a] + S : cc[a]);
+        ta[a] = (plane - oo[a]) * (1.0f / dd[a]);
       } else {
         ta[a] = INFINITY;
       }
@@ -410,10 +428,10 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
     for (int a = 0; a < 3; ++a) {
       if (ta[a] == tn) {
         stepped |= 1u << a;
-        ijk[a] = dd[a] > 0.0f ? c[a] + S : c[a] - 1;
+        ijk[a] = dd[a] > 0.0f ? cc[a] + S : cc[a] - 1;
         if (ijk[a] < 0 || ijk[a] >= E) outside = true;
       } else {
-        ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * tn), c[a], c[a] + S - 1);
+        ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * tn), cc[a], cc[a] + S - 1);
       }
     }
     if (outside) return;
@@ -484,9 +502,10 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
   return n;
 }
 
-template <int RT, bool ANY, bool COUNT>
-__device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, const uint16_t* cand,
-                          uint32_t ncand, Hit& best, LaneStats& st) {
+// any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
+template <int RT, bool COUNT>
+__device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
+                          const uint16_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
   best.found = false;
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
@@ -495,7 +514,7 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     const uint32_t ii = all ? ci : (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[ci]);
     const DevInstance& in = a.instances[ii];
-    bool go = active && !(ANY && best.found);
+    bool go = active && !(any_hit && best.found);
     float te, tx;
     if (go) go = slab_box(o, d, in.wmin, in.wmax, te, tx);
     if (go) {
@@ -506,7 +525,7 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
     if (go) {
       if (COUNT) st.instances_tested += 1;
       const DevModel& m = a.models[in.model];
-      trace_instance<RT, ANY, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, best, st);
+      trace_instance<RT, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
     }
   }
   if (COUNT && best.found) st.hits += 1;
@@ -555,6 +574,10 @@ __device__ __forceinline__ uint16_t* wave_cand_list(const FrameArgs& a) {
   return reinterpret_cast<uint16_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * kMaxCand;
 }
 
+__device__ __forceinline__ void add_stats(LaneStats& d, const LaneStats& s) {
+  d.rays += s.rays; d.instances_tested += s.instances_tested; d.upper_descents += s.upper_descents;
+  d.mid_descents += s.mid_descents; d.bricks_tested += s.bricks_tested; d.hits += s.hits;
+}
 template <bool COUNT>
 __device__ __forceinline__ void flush_stats(const FrameArgs& a, int slot, const LaneStats& st) {
   if (!COUNT) return;
@@ -583,7 +606,8 @@ __device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, ui
 // ==================================================================== primary visibility
 // primary.rgen:8-22 + hit.rint + hit.rchit:16-95 + miss.rmiss:7-17
 template <bool COUNT>
-__global__ void __launch_bounds__(512) k_primary(FrameArgs a) {
+__global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
   stage_roots(a);
   uint16_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
@@ -594,7 +618,7 @@ __global__ void __launch_bounds__(512) k_primary(FrameArgs a) {
     const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
     const uint32_t ncand = cull_instances(a, p.valid, o, d, a.cam.far_, cand);
     Hit h;
-    trace_ray<0, false, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, cand, ncand, h, st);
+    trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
     __builtin_amdgcn_wave_barrier();
     if (!p.valid) continue;
     const size_t pix = (size_t)p.py * a.width + p.px;
@@ -643,7 +667,8 @@ __global__ void __launch_bounds__(512) k_primary(FrameArgs a) {
 // ==================================================================== sun shadow + ambient occlusion
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22
 template <bool COUNT>
-__global__ void __launch_bounds__(512) k_ambient_occlusion(FrameArgs a) {
+__global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
   stage_roots(a);
   uint16_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
@@ -668,23 +693,28 @@ __global__ void __launch_bounds__(512) k_ambient_occlusion(FrameArgs a) {
                  (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
       ad = normalize3(rotate_by_normal(n, ns));
     }
-    // sun shadow ray: any-hit, ray type 1 (ambient_occlusion.rgen:33-50)
+    // two rays per pixel through the same code: k = 0 the sun shadow ray (any-hit, ambient_occlusion.rgen:33-50),
+    // k = 1 the ambient occlusion ray (closest hit within 8 units, ambient_occlusion.rgen:52-65)
     const bool sun_live = live && dot3(sun, n) > 0.0f;
     const V3 sd = normalize3(sun);
     Hit h;
-    uint32_t ncand = cull_instances(a, sun_live, loc, sd, 10000.0f, cand);
-    trace_ray<1, true, COUNT>(a, sun_live, loc, sd, 0.1f, 10000.0f, cand, ncand, h, st_sun);
-    __builtin_amdgcn_wave_barrier();
-    if (sun_live && !h.found) {
-      const V3 sr = sun_radiance(a.sky, normalize3(sd));
-      const float k = 1.0f - cosf(a.sky[55]);
-      const float dn = dot3(n, sd);
-      payload.x += (sr.x * k) * dn; payload.y += (sr.y * k) * dn; payload.z += (sr.z * k) * dn;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const bool act = k == 0 ? sun_live : live;
+      const V3 dir = k == 0 ? sd : ad;
+      const float tmax = k == 0 ? 10000.0f : 8.0f;
+      const uint32_t ncand = cull_instances(a, act, loc, dir, tmax, cand);
+      LaneStats cur = {0, 0, 0, 0, 0, 0};
+      trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
+      if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
+      __builtin_amdgcn_wave_barrier();
+      if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22
+        const V3 sr = sun_radiance(a.sky, normalize3(sd));
+        const float kk = 1.0f - cosf(a.sky[55]);
+        const float dn = dot3(n, sd);
+        payload.x += (sr.x * kk) * dn; payload.y += (sr.y * kk) * dn; payload.z += (sr.z * kk) * dn;
+      }
     }
-    // ambient occlusion ray: closest hit within 8 units (ambient_occlusion.rgen:52-65)
-    ncand = cull_instances(a, live, loc, ad, 8.0f, cand);
-    trace_ray<1, false, COUNT>(a, live, loc, ad, 0.1f, 8.0f, cand, ncand, h, st_ao);
-    __builtin_amdgcn_wave_barrier();
     if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
   }
   flush_stats<COUNT>(a, 0, st_sun);
@@ -692,7 +722,8 @@ __global__ void __launch_bounds__(512) k_ambient_occlusion(FrameArgs a) {
 }
 
 // ==================================================================== N-frame mean (stands in for NRD)
-__global__ void k_accumulate(FrameArgs a) {
+__global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
   const uint32_t rows = a.row_end - a.row_begin;
   const size_t n = (size_t)rows * a.width;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -710,24 +741,25 @@ __global__ void k_accumulate(FrameArgs a) {
 }
 
 // ==================================================================== launchers (called from capi.cpp)
+// `host` describes the launch (LDS size); `dev` is the same struct already copied to device memory.
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
   return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * sizeof(uint16_t);
 }
 
-hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, a);
+hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(host, block);
+  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, dev);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, dev);
   return hipGetLastError();
 }
-hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, a);
+hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(host, block);
+  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, dev);
+  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, dev);
   return hipGetLastError();
 }
-hipError_t launch_accumulate(const FrameArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, a);
+hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, dev);
   return hipGetLastError();
 }
 hipError_t configure_kernels(size_t max_lds) {

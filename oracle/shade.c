@@ -616,8 +616,13 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
   int ijk[3];
   int stepped[3] = {0, 0, 0};
   uint64_t last16 = ~(uint64_t)0;
+  int blo[3], bhi[3]; /* voxel range that holds bricks (tight bounds, multiples of 4) */
   for (int a = 0; a < 3; ++a) {
-    int v = f2i_sat(floorf(oo[a] + dd[a] * t));
+    blo[a] = (int)m->bmin[a];
+    bhi[a] = (int)m->bmax[a] - 1;
+    /* the cell the ray is moving into: floor for d >= 0, ceil - 1 for d < 0 (differs only on a cell plane) */
+    float p = oo[a] + dd[a] * t;
+    int v = f2i_sat(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p));
     ijk[a] = v < 0 ? 0 : (v > E - 1 ? E - 1 : v);
   }
   for (int guard = 0; guard < 100000; ++guard) {
@@ -629,17 +634,23 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
     if (bi >= 0) test_brick(rc, m, inst, (uint32_t)bi, o, d);
     /* neighbours around a brick-grid edge/corner the ray passes within delta of */
     int near_dir[3] = {0, 0, 0};
-    int n_near = 0, n_stepped = 0, n_near_unstepped = 0;
+    int n_near = 0, n_stepped = 0, n_near_unstepped = 0, n_stepped_near = 0;
     for (int a = 0; a < 3; ++a) {
       float p = oo[a] + dd[a] * t;
       float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
       float q = p - (float)(ijk[a] & ~3);
-      if (stepped[a]) { near_dir[a] = dd[a] > 0.0f ? -1 : 1; n_stepped++; }
-      else if (q <= delta) { near_dir[a] = -1; n_near_unstepped++; }
-      else if (q >= 4.0f - delta) { near_dir[a] = 1; n_near_unstepped++; }
+      int b0 = ijk[a] & ~3;
+      /* a plane only matters if bricks can exist on its far side (tight bounds) */
+      if (stepped[a]) {
+        n_stepped++;
+        if (dd[a] > 0.0f) { if (b0 - 1 >= blo[a]) near_dir[a] = -1; } else if (b0 + 4 <= bhi[a]) near_dir[a] = 1;
+        if (near_dir[a]) n_stepped_near++;
+      }
+      else if (q <= delta) { if (b0 - 1 >= blo[a]) { near_dir[a] = -1; n_near_unstepped++; } }
+      else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi[a]) { near_dir[a] = 1; n_near_unstepped++; } }
       if (near_dir[a]) n_near++;
     }
-    if (n_near_unstepped > 0 || n_stepped > 1) {
+    if (n_near_unstepped > 0 || n_stepped_near > 1) {
       for (int sub = 1; sub < 8; ++sub) {
         int ok = 1, only_stepped = 1, all_stepped_in = 1, nj[3];
         for (int a = 0; a < 3; ++a) {
@@ -648,13 +659,12 @@ static void trace_instance_hier(RayCtx* rc, const SceneModel* m, uint32_t inst, 
             if (!near_dir[a]) { ok = 0; break; }
             if (!stepped[a]) only_stepped = 0;
             nj[a] = near_dir[a] < 0 ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
-            if (nj[a] < 0 || nj[a] >= E) { ok = 0; break; }
           } else if (stepped[a]) all_stepped_in = 0;
         }
         if (!ok) continue;
         if (only_stepped && all_stepped_in && n_stepped > 0) continue; /* the cell we came from */
         uint32_t cl2;
-        int nb = find_brick(m, nj, &cl2, NULL, NULL);
+        int nb = find_brick(m, nj, &cl2, NULL, &last16);
         if (nb >= 0) test_brick(rc, m, inst, (uint32_t)nb, o, d);
       }
     }
