@@ -72,7 +72,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from dust_amd import _lib as L
-    from dust_amd import api, synth
+    from dust_amd import api, sharding, synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_util as P  # scene description helpers + sky fixture (shared with the tests)
 
@@ -104,11 +104,10 @@ def main():
     band_px = W * Hband
     ill_ptr, ill_bytes = pipe.plane_device_ptr(L.PLANE_ILLUMINANCE)
     band = torch.empty((Hband, W, 4), dtype=torch.float16, device="cuda")
-    gathered = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
     hip = ctypes.CDLL("libamdhip64.so.7")  # resolves to the copy torch / libdust_hip already loaded (same SONAME)
 
     def step(k, count=False):
-        frame_index = k * world + rank + 1  # sample k*N + r of the spp sequence (frame_index starts at 1, standard.rs:252)
+        frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
         pipe.render(scene, cam, sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=frame_index,
                     rand=synth.frame_rand(1, frame_index))
         if world > 1:
@@ -117,7 +116,7 @@ def main():
             rc = hip.hipMemcpyAsync(ctypes.c_void_p(band.data_ptr()), ctypes.c_void_p(src), ctypes.c_size_t(band_px * 8),
                                     ctypes.c_int(3), ctypes.c_void_p(stream))
             assert rc == 0, rc
-            dist.gather(band, gathered, dst=0)
+            sharding.gather_to_root(dist, band)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,104 @@
+// host_mirror_test.cpp -- drives include/dust_hip.hpp the way the reference's doctests and examples/castle.rs
+// drive the Rust crates. Modes:
+//   cpu                      the crates/vdb doctests + a .vox load, no GPU needed
+//   gpu <file.vox> <w> <h> <noise5.bin> <sky.bin> <out_prefix>   offline frame like examples/castle.rs:105-236
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "dust_hip.hpp"
+
+#define EXPECT(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static std::vector<uint8_t> slurp(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static int cpu_tests() {
+  using dust::Tree;
+  {  // crates/vdb/src/tree.rs:15-25
+    Tree tree({2, 2});
+    tree.set_value({0, 4, 0}, true);
+    tree.set_value({0, 2, 2}, false);
+    EXPECT(tree.get_value({0, 4, 0}) == std::optional<bool>(true));
+    EXPECT(tree.get_value({0, 3, 0}) == std::nullopt);
+    EXPECT(tree.get_value({0, 2, 2}) == std::optional<bool>(false));
+  }
+  {  // crates/vdb/src/tree.rs:87-101
+    Tree tree({4, 2});
+    tree.set_value({0, 1, 2}, true);
+    tree.set_value({63, 1, 3}, true);
+    tree.set_value({63, 63, 63}, true);
+    auto it = tree.iter();
+    EXPECT(it.size() == 3);
+    EXPECT((it[0] == dust::UVec3{0, 1, 2}) && (it[1] == dust::UVec3{63, 1, 3}) && (it[2] == dust::UVec3{63, 63, 63}));
+  }
+  {  // crates/vdb/src/accessor.rs:148-170
+    Tree tree({2, 4, 2});
+    EXPECT(tree.meta_mask() == 0b10100010u);
+    const uint32_t a[3] = {0, 0, 0}, b[3] = {255, 255, 255};
+    EXPECT(dust_vdb_lca_level(a, b, tree.meta_mask(), tree.root_level()) == 2);
+    tree.set_value({17, 200, 3}, true);
+    auto acc = tree.accessor();
+    EXPECT(acc.get({17, 200, 3}) == std::optional<bool>(true));
+  }
+  {  // internal.rs:121-124: clearing is todo!() -> DUST_ERR_UNSUPPORTED, reported as an exception, never a crash
+    Tree tree({4, 2, 2});
+    bool threw = false;
+    try { tree.set_value({1, 1, 1}, std::nullopt); } catch (const dust::Error& e) { threw = e.status == DUST_ERR_UNSUPPORTED; }
+    EXPECT(threw);
+  }
+  {  // a malformed file is a ParseError (loader.rs:311-317)
+    const uint8_t junk[16] = {'N', 'O', 'P', 'E'};
+    DustVoxScene* s = nullptr;
+    EXPECT(dust_vox_load(junk, sizeof(junk), &s) == DUST_ERR_PARSE);
+  }
+  std::puts("cpu ok");
+  return 0;
+}
+
+static int gpu_frame(int argc, char** argv) {
+  if (argc < 8) { std::fprintf(stderr, "usage: gpu file.vox w h noise5.bin sky.bin out_prefix\n"); return 2; }
+  const auto vox = slurp(argv[2]);
+  const uint32_t w = uint32_t(std::atoi(argv[3])), h = uint32_t(std::atoi(argv[4]));
+  const auto noise5 = slurp(argv[5]);
+  const auto skyb = slurp(argv[6]);
+  EXPECT(skyb.size() == sizeof(DustHipSky));
+  DustHipSky sky;
+  std::memcpy(&sky, skyb.data(), sizeof(sky));
+
+  dust::RenderContext ctx(0);                       // add_plugins(dust_render::RenderPlugin)
+  dust::VoxLoader loader(ctx);                      // add_plugins(dust_vox::VoxPlugin)
+  dust::VoxScene assets = loader.load(vox.data(), vox.size());   // asset_server.load("castle.vox")
+  dust::Scene scene(ctx);
+  scene.spawn_scene(assets);                        // commands.spawn(SceneBundle{..})
+  scene.commit();
+  dust::StandardPipeline pipeline(ctx, w, h);
+  pipeline.set_blue_noise(5, noise5.data(), uint32_t(noise5.size() / (128 * 128 * 4)));
+  const double eye[3] = {122.0 * 0.15, 300.61 * 0.15, 54.45 * 0.15}, target[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+  const float eyef[3] = {float(eye[0]), float(eye[1]), float(eye[2])};
+  const DustHipCamera cam = dust::make_camera(eyef, dust::look_at_rotation(eye, target, up), dust::PinholeProjection{});
+  const bool ok = pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242);
+  EXPECT(ok);
+  ctx.sync();
+  const auto depth = pipeline.read_plane<float>(DUST_PLANE_DEPTH);
+  const auto ill = pipeline.read_plane<uint16_t>(DUST_PLANE_ILLUMINANCE);
+  const auto vid = pipeline.read_plane<uint32_t>(DUST_PLANE_VOXEL_ID);
+  std::ofstream(std::string(argv[7]) + ".depth", std::ios::binary).write(reinterpret_cast<const char*>(depth.data()), depth.size() * 4);
+  std::ofstream(std::string(argv[7]) + ".ill", std::ios::binary).write(reinterpret_cast<const char*>(ill.data()), ill.size() * 2);
+  std::ofstream(std::string(argv[7]) + ".vid", std::ios::binary).write(reinterpret_cast<const char*>(vid.data()), vid.size() * 4);
+  std::puts("gpu ok");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  try {
+    if (argc >= 2 && std::string(argv[1]) == "gpu") return gpu_frame(argc, argv);
+    return cpu_tests();
+  } catch (const dust::Error& e) {
+    std::fprintf(stderr, "dust::Error %d: %s\n", int(e.status), e.what());
+    return 3;
+  }
+}
