@@ -93,7 +93,7 @@ struct DustHipContext {
 
 struct DustHipModel {
   DustHipContext* ctx = nullptr;
-  DeviceBuffer root, l2, mid, brick_mask, blocks, materials, palette;
+  DeviceBuffer root, l2, mid, dense_mask, blocks, materials, palette;
   dust::DevModel dev{};
   uint32_t id = 0;
 };
@@ -159,12 +159,11 @@ struct N16Builder {
 
 // Builds root / l2 / mid arrays from blocks given in Tree::iter_leaf order (depth-first, ascending bits).
 DustStatus build_hierarchy(const DustHipBlock* blocks, uint32_t n, uint32_t extent_log2, N16Builder& root,
-                           N16Builder& l2, std::vector<dust::DevN4>& mid, std::vector<uint64_t>& brick_mask,
+                           N16Builder& l2, std::vector<dust::DevN4>& mid, std::vector<uint64_t>& dense_mask,
                            float bmin[3], float bmax[3]) {
   const bool deep = extent_log2 == 12;
   const uint32_t extent = 1u << extent_log2;
   root.add();
-  brick_mask.resize(n);
   uint64_t prev_key = 0;
   int64_t cur_l2 = -1, cur_mid = -1;
   uint32_t cur_l2_cell = 0xFFFFFFFFu, cur_mid_cell = 0xFFFFFFFFu;
@@ -190,7 +189,6 @@ DustStatus build_hierarchy(const DustHipBlock* blocks, uint32_t n, uint32_t exte
     if (i > 0 && key <= prev_key)
       return fail(DUST_ERR_INVALID_ARGUMENT, "blocks are not in Tree::iter_leaf order (depth-first, ascending child bits)");
     prev_key = key;
-    brick_mask[i] = b.mask;
     const float p[3] = {float(b.x), float(b.y), float(b.z)};
     for (int a = 0; a < 3; ++a) {
       bmin[a] = std::min(bmin[a], p[a]);
@@ -222,6 +220,8 @@ DustStatus build_hierarchy(const DustHipBlock* blocks, uint32_t n, uint32_t exte
     const uint32_t bit = (((b.x >> 2) & 3) << 4) | (((b.y >> 2) & 3) << 2) | ((b.z >> 2) & 3);
     if (bit < 32) mid[size_t(cur_mid)].mask_lo |= 1u << bit;
     else mid[size_t(cur_mid)].mask_hi |= 1u << (bit - 32);
+    if (dense_mask.size() < mid.size() * 64) dense_mask.resize(mid.size() * 64, 0);
+    dense_mask[size_t(cur_mid) * 64 + bit] = b.mask;
   }
   // prefixes and child bases: children were appended in order, so base = running count
   if (deep) {
@@ -471,9 +471,9 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
   return guarded([&]() -> DustStatus {
     N16Builder root, l2;
     std::vector<dust::DevN4> mid;
-    std::vector<uint64_t> brick_mask;
+    std::vector<uint64_t> dense_mask;
     float bmin[3], bmax[3];
-    DustStatus s = build_hierarchy(blocks, n_blocks, tree_extent_log2, root, l2, mid, brick_mask, bmin, bmax);
+    DustStatus s = build_hierarchy(blocks, n_blocks, tree_extent_log2, root, l2, mid, dense_mask, bmin, bmax);
     if (s != DUST_OK) return s;
     for (uint32_t i = 0; i < n_blocks; ++i) {
       const uint64_t need = uint64_t(blocks[i].material_ptr) + uint64_t(__builtin_popcountll(blocks[i].mask));
@@ -485,7 +485,7 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size()));
     HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size()));
     HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4)));
-    HIP_TRY(m->brick_mask.upload(brick_mask.data(), brick_mask.size() * 8));
+    HIP_TRY(m->dense_mask.upload(dense_mask.data(), dense_mask.size() * 8));
     HIP_TRY(m->blocks.upload(blocks, size_t(n_blocks) * sizeof(DustHipBlock)));
     HIP_TRY(m->materials.upload(materials, size_t(n_materials)));
     uint32_t pal[256];
@@ -496,7 +496,7 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     d.root = static_cast<const uint8_t*>(m->root.p);
     d.l2 = tree_extent_log2 == 12 ? static_cast<const uint8_t*>(m->l2.p) : nullptr;
     d.mid = static_cast<const dust::DevN4*>(m->mid.p);
-    d.brick_mask = static_cast<const uint64_t*>(m->brick_mask.p);
+    d.dense_mask = static_cast<const uint64_t*>(m->dense_mask.p);
     d.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
     d.materials = static_cast<const uint8_t*>(m->materials.p);
     d.palette = static_cast<const uint32_t*>(m->palette.p);
@@ -622,7 +622,7 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
       HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
       HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
     }
-    HIP_TRY(p->counters.alloc(64 * sizeof(uint32_t)));
+    HIP_TRY(p->counters.alloc(2 * 8 * dust::kCounterStride * sizeof(uint32_t)));
     HIP_TRY(p->stats.alloc(4 * sizeof(dust::DevStats)));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_args), sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots, hipHostMallocDefault));
@@ -703,11 +703,12 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (p->noise5.p) a.noise5 = static_cast<const uint8_t*>(p->noise5.p) + size_t(fp->frame_index % p->noise5_layers) * 128 * 128 * 4;  // noise.rs:50
   a.stats = static_cast<dust::DevStats*>(p->stats.p);
   a.accum_count = p->accum_count;
+  if (const char* env = std::getenv("DUST_HIP_DEBUG")) a.debug = uint32_t(std::strtoul(env, nullptr, 10));
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = 512;
   uint32_t bpc = 2;
   if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
-  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 2;
+  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 32;
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
   const uint32_t grid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (total_tiles + 7) / 8));
@@ -716,7 +717,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 4 * sizeof(dust::DevStats), st));
   if (fp->passes & DUST_PASS_PRIMARY) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p);
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     const dust::FrameArgs* d = nullptr;
@@ -726,8 +727,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
   if (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 8;
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * sizeof(uint32_t), st));
+    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 8 * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
     const dust::FrameArgs* d = nullptr;

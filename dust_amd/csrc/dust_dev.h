@@ -4,7 +4,7 @@
 //   root      : one N16 node   [64 x u64 child mask][64 x u16 rank prefix][u32 child_base][pad]   656 B
 //   l2        : N16 nodes, only for 4096^3 trees (hierarchy (4,4,2,2)), same 656 B layout
 //   mid       : N4 nodes       {u64 child mask, u32 first_block, u32 pad}                         16 B
-//   brick_mask: u64 occupancy per 4^3 brick, block order                                          8 B
+//   dense_mask: u64 occupancy per (mid node, child bit), 0 where there is no brick     64 x 8 B per mid node
 //   blocks    : the reference's 24-byte Block records, block order (shading only)
 //   materials : u8 palette index per solid voxel; palette: 255 x RGBA8
 // A child "pointer" is child_base + prefix[word] + popcount(mask[word] & below(bit)): nodes of one
@@ -19,7 +19,8 @@ namespace dust {
 
 constexpr uint32_t kN16Bytes = 656;      // 512 mask + 128 prefix + 4 base + 12 pad
 constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base is 0)
-constexpr uint32_t kMaxCand = 96;        // per-wave candidate instance list capacity
+constexpr uint32_t kCounterStride = 64;  // u32s between the per-region work counters (256 B: no two share a cache line)
+constexpr uint32_t kMaxCand = 40;        // per-wave candidate instance list capacity (32 B per entry in LDS)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
 constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
 
@@ -33,7 +34,7 @@ struct DevModel {
   const uint8_t* root;          // N16
   const uint8_t* l2;            // N16[] or null
   const DevN4* mid;
-  const uint64_t* brick_mask;
+  const uint64_t* dense_mask;   // [mid node][64 child bits] -> brick occupancy, 0 = no brick
   const DustHipBlock* blocks;
   const uint8_t* materials;
   const uint32_t* palette;      // RGBA8 packed little-endian, 255 entries (+1 pad)
@@ -84,12 +85,13 @@ struct FrameArgs {
   uint32_t width, height;
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
-  uint32_t* work_counters;    // 8 per-region tile counters (zeroed before launch)
+  uint32_t* work_counters;    // 8 per-region tile counters, kCounterStride apart (zeroed before launch)
   const uint8_t* noise0;      // 128*128 R8 slice for this frame, or null
   const uint8_t* noise5;      // 128*128 RGBA8 slice for this frame, or null
   uint32_t rand, frame_index;
   DevStats* stats;            // [2]: per pass kind, only written by the counting build
   uint32_t accum_count;       // frames already in `accum`
+  uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling); 0 in production
 };
 
 }  // namespace dust

@@ -234,18 +234,19 @@ struct Hit {
 struct LaneStats {
   uint32_t rays, instances_tested, upper_descents, mid_descents, bricks_tested, hits;
 };
-struct MidCache {
+struct MidCache {  // the 16-cell the ray was last in and its mid-node index (saves the LDS root lookup)
   int key;
-  uint32_t mlo, mhi, first;
+  uint32_t mid;
 };
 
-__device__ __forceinline__ bool slab_box(V3 o, V3 d, const float* lo, const float* hi, float& te, float& tx) {
+// inv = 1/d per component (IEEE divide; +-inf for zero components, which take the other branch)
+__device__ __forceinline__ bool slab_box(V3 o, V3 d, V3 inv_d, const float* lo, const float* hi, float& te, float& tx) {
   te = -INFINITY; tx = INFINITY;
-  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, iv[3] = {inv_d.x, inv_d.y, inv_d.z};
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     if (dd[a] != 0.0f) {
-      float inv = 1.0f / dd[a];
+      float inv = iv[a];
       float t0 = (lo[a] - oo[a]) * inv, t1 = (hi[a] - oo[a]) * inv;
       te = fmaxf(te, fminf(t0, t1));
       tx = fminf(tx, fmaxf(t0, t1));
@@ -275,43 +276,51 @@ __device__ __forceinline__ bool n16_child(const uint8_t* node, int lds_slot, uin
   return true;
 }
 
-// deepest occupied cell containing voxel (x,y,z): block index or -1; cell_log2 = size of that cell
+// Deepest occupied cell containing voxel (x,y,z). Returns the brick's 64-bit occupancy (0 = no brick),
+// cell_log2 = size of the cell that was found empty (2 when a brick exists), key = mid_index*64 + child bit,
+// which orders bricks exactly like the block index does (both are depth-first).
+// One dependent memory access per call: root in LDS -> mid index -> dense_mask[mid*64 + bit].
 template <bool COUNT>
-__device__ __forceinline__ int find_brick(const DevModel& m, int x, int y, int z, uint32_t& cell_log2, MidCache& mc,
-                                          LaneStats& st, bool count) {
-  const int key = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
-  if (key != mc.key) {
+__device__ __forceinline__ uint64_t find_brick(const DevModel& m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
+                                               MidCache& mc, LaneStats& st, bool count) {
+  const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
+  if (k16 != mc.key) {
     uint32_t mid_index;
     if (m.n_levels == 2) {
       uint32_t idx = ((uint32_t)(x >> 4) << 8) | ((uint32_t)(y >> 4) << 4) | (uint32_t)(z >> 4);
-      if (!n16_child(m.root, m.lds_slot, idx, mid_index)) { cell_log2 = 4; return -1; }
+      if (!n16_child(m.root, m.lds_slot, idx, mid_index)) { cell_log2 = 4; return 0; }
       if (COUNT && count) st.upper_descents += 1;
     } else {
       uint32_t idx = ((uint32_t)(x >> 8) << 8) | ((uint32_t)(y >> 8) << 4) | (uint32_t)(z >> 8);
       uint32_t l2;
-      if (!n16_child(m.root, m.lds_slot, idx, l2)) { cell_log2 = 8; return -1; }
+      if (!n16_child(m.root, m.lds_slot, idx, l2)) { cell_log2 = 8; return 0; }
       if (COUNT && count) st.upper_descents += 1;
       uint32_t idx2 = ((uint32_t)((x >> 4) & 15) << 8) | ((uint32_t)((y >> 4) & 15) << 4) | (uint32_t)((z >> 4) & 15);
-      if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return -1; }
+      if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return 0; }
       if (COUNT && count) st.upper_descents += 1;
     }
-    const uint4 n = *reinterpret_cast<const uint4*>(m.mid + mid_index);
-    mc.key = key; mc.mlo = n.x; mc.mhi = n.y; mc.first = n.z;
+    mc.key = k16; mc.mid = mid_index;
   }
   const uint32_t bit = ((uint32_t)((x >> 2) & 3) << 4) | ((uint32_t)((y >> 2) & 3) << 2) | (uint32_t)((z >> 2) & 3);
-  const uint64_t mm = ((uint64_t)mc.mhi << 32) | mc.mlo;
+  key = mc.mid * 64u + bit;
   cell_log2 = 2;
-  if (!((mm >> bit) & 1ull)) return -1;
-  if (COUNT && count) st.mid_descents += 1;
-  return (int)(mc.first + (uint32_t)__popcll(mm & ((1ull << bit) - 1ull)));
+  const uint64_t mask = m.dense_mask[key];
+  if (COUNT && count && mask != 0) st.mid_descents += 1;
+  return mask;
+}
+
+// block index (gl_PrimitiveID) of a brick key: first_block of its mid node + rank of the child bit
+__device__ __forceinline__ uint32_t resolve_block(const DevModel& m, uint32_t key) {
+  const uint4 n = *reinterpret_cast<const uint4*>(m.mid + (key >> 6));
+  const uint64_t mm = ((uint64_t)n.y << 32) | n.x;
+  return n.z + (uint32_t)__popcll(mm & ((1ull << (key & 63u)) - 1ull));
 }
 
 // run the ray type's intersection routine on one brick and apply Vulkan's accept rule
 // (tmin <= t <= current tmax; equal t: lower (instance, block) wins -- see oracle/shade.c header)
 template <int RT, bool COUNT>
-__device__ __forceinline__ void test_brick(const DevModel& m, uint32_t inst, uint32_t bi, int bx, int by, int bz, V3 o,
+__device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_t key, int bx, int by, int bz, V3 o,
                                            V3 d, float tmin, float tmax, Hit& best, LaneStats& st) {
-  const uint64_t mask = m.brick_mask[bi];
   V3 ol = mk(o.x - (float)bx, o.y - (float)by, o.z - (float)bz);  // hit.rint:137-140
   float t;
   uint32_t vox;
@@ -320,9 +329,9 @@ __device__ __forceinline__ void test_brick(const DevModel& m, uint32_t inst, uin
   const float cur = best.found ? best.t : tmax;
   if (!(t >= tmin && t <= cur)) return;
   if (best.found && t == best.t) {
-    if (inst > best.inst || (inst == best.inst && bi >= best.block)) return;
+    if (inst > best.inst || (inst == best.inst && key >= best.block)) return;
   }
-  best.found = true; best.t = t; best.inst = inst; best.block = bi; best.voxel = vox;
+  best.found = true; best.t = t; best.inst = inst; best.block = key; best.voxel = vox;
 }
 
 // Hierarchical traversal of one instance in object space. Visits, front to back, a SUPERSET of the
@@ -335,10 +344,11 @@ __device__ __forceinline__ void test_brick(const DevModel& m, uint32_t inst, uin
 template <int RT, bool COUNT>
 __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                                Hit& best, LaneStats& st) {
+  const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   float te, tx;
-  if (!slab_box(o, d, m.bmin, m.bmax, te, tx)) return;
+  if (!slab_box(o, d, inv_d, m.bmin, m.bmax, te, tx)) return;
   const int E = (int)m.extent;
-  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, inv[3] = {inv_d.x, inv_d.y, inv_d.z};
   float t = fmaxf(te, 0.0f);
   if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
   int ijk[3];
@@ -374,15 +384,16 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
           c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
         }
       {
-        uint32_t cl2;
-        const int nb = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, mc, st, false);
-        if (nb >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)nb, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
+        uint32_t cl2, key;
+        const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
+        if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
         if (pending != 0) continue;
       }
     }
     if (is_main) {
-      const int bi = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, mc, st, true);
-      if (bi >= 0) test_brick<RT, COUNT>(m, inst, (uint32_t)bi, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
+      uint32_t key;
+      const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, key, mc, st, true);
+      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
       // which brick planes is the entry point within delta of?
       near_neg = 0; near_pos = 0;
       uint32_t unstepped_near = 0;
@@ -415,7 +426,7 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
       cc[a] = ijk[a] & ~(S - 1);
       if (dd[a] != 0.0f) {
         const float plane = (float)(dd[a] > 0.0f ? cc[a] + S : cc[a]);
-        ta[a] = (plane - oo[a]) * (1.0f / dd[a]);
+        ta[a] = (plane - oo[a]) * inv[a];
       } else {
         ta[a] = INFINITY;
       }
@@ -455,7 +466,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // Bounds the packet's rays by per-axis origin and direction intervals, tests all instance boxes
 // against that bundle 64 at a time and compacts the survivors (ascending instance id) into `cand`.
 // Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
-__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, uint16_t* cand) {
+__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, float4* cand) {
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   float omin[3], omax[3], dmin[3], dmax[3];
 #pragma unroll
@@ -472,15 +483,18 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
   for (uint32_t base = 0; base < a.n_instances; base += 64) {
     const uint32_t i = base + lane;
     bool pass = false;
+    float wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
     if (i < a.n_instances) {
       const DevInstance& in = a.instances[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { wlo[k] = in.wmin[k]; whi[k] = in.wmax[k]; }
       float t_lo = 0.0f, t_hi = T;
       pass = true;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         // exists o in [omin,omax], d in [dmin,dmax]: lo <= o + d t <= hi
         //   <=>  omin + dmin t <= hi  and  omax + dmax t >= lo      (t >= 0)
-        const float c1 = in.wmax[k] - omin[k], c2 = in.wmin[k] - omax[k];
+        const float c1 = whi[k] - omin[k], c2 = wlo[k] - omax[k];
         if (dmin[k] > 0.0f) t_hi = fminf(t_hi, c1 / dmin[k]);
         else if (dmin[k] < 0.0f) t_lo = fmaxf(t_lo, c1 / dmin[k]);
         else if (c1 < 0.0f) pass = false;
@@ -493,7 +507,10 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
     const uint64_t bal = __ballot(pass);
     if (pass) {
       const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      if (pos < kMaxCand) cand[pos] = (uint16_t)i;
+      if (pos < kMaxCand) {  // box + id travel with the candidate: the per-ray loop reads them with two ds_read_b128
+        cand[pos * 2] = make_float4(wlo[0], wlo[1], wlo[2], __uint_as_float(i));
+        cand[pos * 2 + 1] = make_float4(whi[0], whi[1], whi[2], 0.0f);
+      }
     }
     n += (uint32_t)__popcll(bal);
   }
@@ -505,18 +522,29 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
 // any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
 template <int RT, bool COUNT>
 __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
-                          const uint16_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
+                          const float4* cand, uint32_t ncand, Hit& best, LaneStats& st) {
   best.found = false;
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
   const bool all = ncand > kMaxCand;
   const uint32_t n = all ? a.n_instances : ncand;
+  const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
-    const uint32_t ii = all ? ci : (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[ci]);
-    const DevInstance& in = a.instances[ii];
+    uint32_t ii;
+    float lo[3], hi[3];
+    if (all) {
+      ii = ci;
+      const DevInstance& in = a.instances[ii];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lo[k] = in.wmin[k]; hi[k] = in.wmax[k]; }
+    } else {
+      const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];  // same address in every lane: LDS broadcast
+      ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c0.w));
+      lo[0] = c0.x; lo[1] = c0.y; lo[2] = c0.z; hi[0] = c1.x; hi[1] = c1.y; hi[2] = c1.z;
+    }
     bool go = active && !(any_hit && best.found);
     float te, tx;
-    if (go) go = slab_box(o, d, in.wmin, in.wmax, te, tx);
+    if (go) go = slab_box(o, d, inv_d, lo, hi, te, tx);
     if (go) {
       const float limit = best.found ? best.t : tmax;
       if (te * (1.0f - 2e-6f) > limit) go = false;
@@ -524,6 +552,7 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
     if (!__any(go)) continue;
     if (go) {
       if (COUNT) st.instances_tested += 1;
+      const DevInstance& in = a.instances[ii];
       const DevModel& m = a.models[in.model];
       trace_instance<RT, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
     }
@@ -543,10 +572,21 @@ __device__ __forceinline__ bool next_packet(const FrameArgs& a, uint32_t& region
   const uint32_t total = a.tiles_x * a.tiles_y;
   const uint32_t per = (total + 7u) / 8u;
   const uint32_t lane = threadIdx.x & 63u;
+  if (a.debug & 8u) {  // ablation: static striding instead of atomic counters
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t tile = wave + region_try * gridDim.x * (blockDim.x >> 6);
+    region_try += 1;
+    if (tile >= total) return false;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    p.px = tx * 8u + (lane & 7u);
+    p.py = a.row_begin + ty * 8u + (lane >> 3);
+    p.valid = p.px < a.width && p.py < a.row_end;
+    return true;
+  }
   while (region_try < 8u) {
     const uint32_t region = (blockIdx.x + region_try) & 7u;
     uint32_t k = 0;
-    if (lane == 0) k = atomicAdd(&a.work_counters[region], 1u);
+    if (lane == 0) k = atomicAdd(&a.work_counters[region * kCounterStride], 1u);  // one counter per 256-byte line
     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
     const uint32_t tile = region * per + k;
     if (k < per && tile < total) {
@@ -563,15 +603,15 @@ __device__ __forceinline__ bool next_packet(const FrameArgs& a, uint32_t& region
 
 __device__ __forceinline__ void stage_roots(const FrameArgs& a) {
   // root masks + prefixes of the first n_lds_models models -> LDS, 16 B per lane per step
-  const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
+  const uint32_t n16 = (a.debug & 4u) ? 0u : a.n_lds_models * (kN16LdsBytes / 16u);
   for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
     const uint32_t mdl = i / (kN16LdsBytes / 16u), off = i % (kN16LdsBytes / 16u);
     reinterpret_cast<uint4*>(g_lds)[i] = reinterpret_cast<const uint4*>(a.models[mdl].root)[off];
   }
   __syncthreads();
 }
-__device__ __forceinline__ uint16_t* wave_cand_list(const FrameArgs& a) {
-  return reinterpret_cast<uint16_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * kMaxCand;
+__device__ __forceinline__ float4* wave_cand_list(const FrameArgs& a) {
+  return reinterpret_cast<float4*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * (kMaxCand * 2);
 }
 
 __device__ __forceinline__ void add_stats(LaneStats& d, const LaneStats& s) {
@@ -609,16 +649,17 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  uint16_t* cand = wave_cand_list(a);
+  float4* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
   uint32_t region_try = 0;
   Packet p;
   while (next_packet(a, region_try, p)) {
     const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
     const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
-    const uint32_t ncand = cull_instances(a, p.valid, o, d, a.cam.far_, cand);
+    const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, p.valid, o, d, a.cam.far_, cand);
     Hit h;
-    trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
+    h.found = false;
+    if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
     __builtin_amdgcn_wave_barrier();
     if (!p.valid) continue;
     const size_t pix = (size_t)p.py * a.width + p.px;
@@ -633,7 +674,8 @@ __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict_
     }
     const DevInstance& in = a.instances[h.inst];
     const DevModel& m = a.models[in.model];
-    const DustHipBlock b = m.blocks[h.block];
+    const uint32_t block = resolve_block(m, h.block);
+    const DustHipBlock b = m.blocks[block];
     const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
     const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
     const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
@@ -670,7 +712,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  uint16_t* cand = wave_cand_list(a);
+  float4* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   uint32_t region_try = 0;
   Packet p;
@@ -743,7 +785,7 @@ __global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
 // ==================================================================== launchers (called from capi.cpp)
 // `host` describes the launch (LDS size); `dev` is the same struct already copied to device memory.
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
-  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * sizeof(uint16_t);
+  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 32u;
 }
 
 hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
