@@ -94,6 +94,7 @@ struct DustHipContext {
 struct DustHipModel {
   DustHipContext* ctx = nullptr;
   DeviceBuffer root, l2, mid, dense_mask, blocks, materials, palette;
+  std::vector<uint8_t> host_root;  // 640 B: mask + prefix, what the kernels stage in LDS
   dust::DevModel dev{};
   uint32_t id = 0;
 };
@@ -108,7 +109,8 @@ struct DustHipScene {
   DustHipContext* ctx = nullptr;
   std::vector<HostInstance> instances;
   std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
-  DeviceBuffer d_models, d_instances;
+  DeviceBuffer d_models, d_instances, d_root_table;
+  std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
   uint32_t n_lds_models = 0;
   bool committed = false;
 };
@@ -483,6 +485,7 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     std::unique_ptr<DustHipModel> m(new DustHipModel);
     m->ctx = ctx;
     HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size()));
+    m->host_root.assign(root.bytes.begin(), root.bytes.begin() + dust::kN16LdsBytes);
     HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size()));
     HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4)));
     HIP_TRY(m->dense_mask.upload(dense_mask.data(), dense_mask.size() * 8));
@@ -602,6 +605,10 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       dm[i] = s->models[i]->dev;
       dm[i].lds_slot = i < s->n_lds_models ? int32_t(i) : -1;
     }
+    s->root_table.clear();
+    for (uint32_t i = 0; i < s->n_lds_models; ++i)
+      s->root_table.insert(s->root_table.end(), s->models[i]->host_root.begin(), s->models[i]->host_root.end());
+    HIP_TRY(s->d_root_table.upload(s->root_table.data(), s->root_table.size()));
     HIP_TRY(s->d_models.upload(dm.data(), dm.size() * sizeof(dust::DevModel)));
     HIP_TRY(s->d_instances.upload(di.data(), di.size() * sizeof(dust::DevInstance)));
     s->committed = true;
@@ -680,6 +687,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.n_models = uint32_t(s->models.size());
   a.n_instances = uint32_t(s->instances.size());
   a.n_lds_models = s->n_lds_models;
+  a.root_table = static_cast<const uint8_t*>(s->d_root_table.p);
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
   a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;

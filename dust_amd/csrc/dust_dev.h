@@ -79,6 +79,7 @@ struct FrameArgs {
   const DevInstance* instances;
   uint32_t n_models, n_instances;
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
+  const uint8_t* root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DevCamera cam;
   float sky[56];
   DevGBuffer g;
