@@ -25,6 +25,7 @@ PASS_FINAL_GATHER = 1 << 2
 PASS_SURFEL = 1 << 3
 PASS_ACCUMULATE = 1 << 4
 PASS_COUNT_STATS = 1 << 16
+PASS_GI_ORDERED = 1 << 17
 CONTEXT_TIMING = 1
 
 PLANE_ILLUMINANCE, PLANE_DENOISED, PLANE_ALBEDO, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOTION, PLANE_VOXEL_ID, PLANE_ACCUM = range(8)
@@ -124,6 +125,8 @@ SYMBOLS = {
     "dust_hip_pipeline_pass_stats": (C.c_int, [_P, C.c_uint32, C.POINTER(PassStats)]),
     "dust_hip_pipeline_plane_device_ptr": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dust_hip_pipeline_read_plane": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "dust_hip_pipeline_configure_gi": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "dust_hip_pipeline_read_gi": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
 }
 

@@ -15,6 +15,7 @@ from . import _lib as L
 BLOCK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("w", "<u2"), ("mask", "<u8"),
                         ("material_ptr", "<u4"), ("avg_albedo", "<u4")])
 assert BLOCK_DTYPE.itemsize == 24
+SURFEL_DTYPE = np.dtype([("pos", "<f4", 3), ("direction", "<u4")])
 
 PLANE_DTYPES = {
     L.PLANE_ILLUMINANCE: (np.uint16, 4), L.PLANE_DENOISED: (np.uint16, 4), L.PLANE_ALBEDO: (np.uint32, 1),
@@ -308,3 +309,16 @@ class StandardPipeline:
 
     def clear(self):
         L.check(self._lib.dust_hip_pipeline_clear(self._h))
+
+    def configure_gi(self, hash_capacity=32 * 1024 * 1024, surfel_pool_size=720 * 480):
+        self._gi = (hash_capacity, surfel_pool_size)
+        L.check(self._lib.dust_hip_pipeline_configure_gi(self._h, hash_capacity, surfel_pool_size))
+
+    def read_gi(self):
+        """(hash entries as uint32[capacity+2, 3], surfel pool as structured array)"""
+        cap, pool = self._gi
+        h = np.zeros((cap + 2, 3), np.uint32)
+        L.check(self._lib.dust_hip_pipeline_read_gi(self._h, 0, _ptr(h), h.nbytes))
+        s = np.zeros(pool, SURFEL_DTYPE)
+        L.check(self._lib.dust_hip_pipeline_read_gi(self._h, 1, _ptr(s), s.nbytes))
+        return h, s

@@ -19,6 +19,8 @@
 namespace dust {
 hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
 hipError_t configure_kernels(size_t max_lds);
 }  // namespace dust
@@ -120,6 +122,9 @@ struct DustHipPipeline {
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   DeviceBuffer noise0, noise5, counters, stats;
+  // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
+  DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
+  uint32_t gi_capacity = 0, gi_pool_size = 0;
   uint32_t noise0_layers = 0, noise5_layers = 0;
   uint32_t accum_count = 0;
   hipEvent_t ev[8] = {};
@@ -132,7 +137,7 @@ struct DustHipPipeline {
   bool slot_used[kArgSlots] = {};
   int next_slot = 0;
   bool stats_valid = false;
-  dust::DevStats host_stats[4] = {};
+  dust::DevStats host_stats[8] = {};
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16};
@@ -629,8 +634,8 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
       HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
       HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
     }
-    HIP_TRY(p->counters.alloc(2 * 8 * dust::kCounterStride * sizeof(uint32_t)));
-    HIP_TRY(p->stats.alloc(4 * sizeof(dust::DevStats)));
+    HIP_TRY(p->counters.alloc(4 * 8 * dust::kCounterStride * sizeof(uint32_t)));
+    HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_args), sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots, hipHostMallocDefault));
     HIP_TRY(p->dev_args.alloc(sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots));
@@ -656,6 +661,7 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, con
   return DUST_OK;
 }
 
+extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size);
 // copies one launch descriptor into the next ring slot (pinned host -> device, on the launch stream)
 static DustStatus upload_args(DustHipPipeline* p, const dust::FrameArgs& a, hipStream_t st, const dust::FrameArgs** dev) {
   const int slot = p->next_slot;
@@ -677,8 +683,14 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const uint32_t need5 = DUST_PASS_AMBIENT_OCCLUSION | DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL;
   if ((fp->passes & need5) && !p->noise5.p)
     return fail(DUST_ERR_NOT_READY, "blue-noise texture 5 (unitvec3_cosine) not loaded");  // standard.rs:254
-  if (fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL))
-    return fail(DUST_ERR_UNSUPPORTED, "final-gather and surfel passes are not built yet");
+  if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->noise0.p)
+    return fail(DUST_ERR_NOT_READY, "blue-noise texture 0 (scalar) not loaded");
+  if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && (fp->row_begin != 0 || (fp->row_end != 0 && fp->row_end != p->height)))
+    return fail(DUST_ERR_UNSUPPORTED, "the hash-fed GI passes need the whole frame on one device (surfel pool exchange not built)");
+  if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->gi_hash.p) {
+    DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
+    if (gs != DUST_OK) return gs;
+  }
   DustHipContext* ctx = p->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
   dust::FrameArgs a{};
@@ -722,7 +734,15 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const uint32_t grid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (total_tiles + 7) / 8));
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
-  if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 4 * sizeof(dust::DevStats), st));
+  a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);
+  a.gi.hash_capacity = p->gi_capacity;
+  a.gi.pool = static_cast<dust::DevSurfel*>(p->gi_pool.p);
+  a.gi.pool_size = p->gi_pool_size;
+  a.gi.slot_owner = static_cast<uint32_t*>(p->gi_owner.p);
+  a.gi.pixel_surfel = static_cast<dust::DevSurfel*>(p->gi_pixel_surfel.p);
+  a.gi.requests = static_cast<dust::DevHashRequest*>(p->gi_requests.p);
+  a.gi.replacement = static_cast<dust::DevSurfel*>(p->gi_replacement.p);
+  if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 8 * sizeof(dust::DevStats), st));
   if (fp->passes & DUST_PASS_PRIMARY) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p);
     HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
@@ -745,6 +765,32 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
+  if (fp->passes & DUST_PASS_FINAL_GATHER) {
+    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 16 * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_final_gather(a, d, grid, block, count, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
+  }
+  if (fp->passes & DUST_PASS_SURFEL) {
+    dust::FrameArgs b = a;  // 64 consecutive surfels per wavefront: one row of "tiles"
+    b.tiles_x = (p->gi_pool_size + 63) / 64;
+    b.tiles_y = 1;
+    b.work_counters = static_cast<uint32_t*>(p->counters.p) + 24 * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(b.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
+    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, b, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_surfel(b, d, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
+  }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
     const dust::FrameArgs* d = nullptr;
     { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
@@ -753,24 +799,25 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     p->accum_count += 1;
   }
   if (count) {
-    HIP_TRY(hipMemcpyAsync(p->host_stats, p->stats.p, 4 * sizeof(dust::DevStats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p->host_stats, p->stats.p, 8 * sizeof(dust::DevStats), hipMemcpyDeviceToHost, st));
     p->stats_valid = true;
   }
   return DUST_OK;
 }
 
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustHipPassStats* out) {
-  if (!p || !out || pass > 4) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
+  if (!p || !out || pass > 5) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
   std::memset(out, 0, sizeof(*out));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  // pass 0: primary kernel; passes 1 and 2: the two ray classes of the AO kernel (share its time)
-  const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : -1);
+  // pass 0: primary kernel; 1, 2: the two ray classes of the AO kernel (share its time); 3: final gather (+ surfel
+  // commit); 4, 5: the two ray classes of the surfel pass (trace + apply kernels)
+  const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : (pass == 3 ? 2 : 3));
   if (kernel >= 0 && p->ctx->timing && p->ev_valid[kernel]) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, p->ev[kernel * 2], p->ev[kernel * 2 + 1]));
     out->ms = ms;
   }
-  if (p->stats_valid && pass <= 2) {
+  if (p->stats_valid) {
     const dust::DevStats& s = p->host_stats[pass];
     out->rays = s.rays; out->instances_tested = s.instances_tested; out->upper_descents = s.upper_descents;
     out->mid_descents = s.mid_descents; out->bricks_tested = s.bricks_tested; out->hits = s.hits;
@@ -789,6 +836,33 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, 
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   HIP_TRY(hipMemcpy(dst, p->planes[plane].p, p->planes[plane].bytes, hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size) {
+  if (!p || hash_capacity < 4 || surfel_pool_size == 0) return fail(DUST_ERR_INVALID_ARGUMENT, "bad GI configuration");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  const size_t hash_bytes = (size_t(hash_capacity) + 2) * 12;  // probes run up to 2 past the end (spatial_hash.glsl:154-158)
+  HIP_TRY(p->gi_hash.alloc(hash_bytes));
+  HIP_TRY(hipMemset(p->gi_hash.p, 0, hash_bytes));             // standard.rs:348-358 relies on a zeroed allocation
+  HIP_TRY(p->gi_pool.alloc(size_t(surfel_pool_size) * 16));
+  HIP_TRY(hipMemset(p->gi_pool.p, 0xFF, size_t(surfel_pool_size) * 16));  // fill_buffer(u32::MAX), standard.rs:345-347
+  HIP_TRY(p->gi_owner.alloc(size_t(surfel_pool_size) * 4));
+  HIP_TRY(hipMemset(p->gi_owner.p, 0, size_t(surfel_pool_size) * 4));
+  HIP_TRY(p->gi_pixel_surfel.alloc(size_t(p->width) * p->height * 16));
+  HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));
+  HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
+  p->gi_capacity = hash_capacity;
+  p->gi_pool_size = surfel_pool_size;
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* dst, size_t dst_bytes) {
+  if (!p || !dst || which > 1 || !p->gi_hash.p) return fail(DUST_ERR_INVALID_ARGUMENT, "GI state not configured");
+  const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
+  if (dst_bytes < b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(hipMemcpy(dst, b.p, b.bytes, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {

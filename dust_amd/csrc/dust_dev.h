@@ -74,6 +74,26 @@ struct DevGBuffer {
   float* accum;           // 4 floats / px
 };
 
+// SpatialHashEntry, 12 bytes, scalar layout (layout.playout:13-18): {u32 fingerprint, u32 LogLuv radiance,
+// u16 last_accessed_frame, u16 sample_count}; SurfelEntry, 16 bytes (layout.playout:1-4): {vec3 position, u32 direction}
+struct DevSurfel { float x, y, z; uint32_t direction; };
+struct DevHashRequest {  // one SpatialHashInsert call recorded by the surfel pass, applied afterwards in surfel order
+  int32_t kx, ky, kz;
+  uint32_t dir_flags;    // bits 0-7 face id, bit 8: insert valid
+  float vx, vy, vz;
+  uint32_t pad;
+};
+struct DevGI {
+  uint32_t* hash;           // (capacity + 2) x 3 words
+  uint32_t hash_capacity;
+  DevSurfel* pool;          // pool_size entries
+  uint32_t pool_size;
+  uint32_t* slot_owner;     // pool_size: 1 + highest pixel index that enqueued into the slot this frame, 0 = none
+  DevSurfel* pixel_surfel;  // width*height: the surfel each pixel wants to enqueue
+  DevHashRequest* requests; // pool_size
+  DevSurfel* replacement;   // pool_size: direction == 0xFFFFFFFF means "keep"
+};
+
 struct FrameArgs {
   const DevModel* models;
   const DevInstance* instances;
@@ -92,6 +112,8 @@ struct FrameArgs {
   uint32_t rand, frame_index;
   DevStats* stats;            // [2]: per pass kind, only written by the counting build
   uint32_t accum_count;       // frames already in `accum`
+  // hash-fed GI (final gather + surfel passes)
+  DevGI gi;
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling); 0 in production
 };
 

@@ -38,6 +38,12 @@ __device__ __forceinline__ int f2i_clamp(float f, int lo, int hi) {  // clamp(in
   float c = fminf(fmaxf(f, (float)lo), (float)hi);                   // fmaxf(NaN, lo) == lo
   return (int)c;
 }
+__device__ __forceinline__ int f2i_trunc(float f) {  // ivec3(float): toward zero; NaN -> 0, saturating (v_cvt_i32_f32)
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)f;
+}
 __device__ __forceinline__ V3 xform_point(const float* m, V3 p) {
   return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
             ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
@@ -765,6 +771,349 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* _
   flush_stats<COUNT>(a, 1, st_ao);
 }
 
+// ==================================================================== spatial hash (headers/spatial_hash.glsl)
+namespace {
+__device__ __forceinline__ uint32_t pcg(uint32_t v) {  // spatial_hash.glsl:105-111
+  uint32_t state = v * 747796405u + 2891336453u;
+  uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ uint32_t xxhash32(uint32_t p) {  // spatial_hash.glsl:115-126
+  uint32_t h = p + 374761393u;
+  h = 668265263u * ((h << 17) | (h >> 15));
+  h = 2246822519u * (h ^ (h >> 15));
+  h = 3266489917u * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+struct HashKey { int x, y, z; uint32_t dir; };
+__device__ __forceinline__ uint32_t key_fingerprint(HashKey k) {  // spatial_hash.glsl:128-135
+  uint32_t h = xxhash32((uint32_t)k.x);
+  h = xxhash32((uint32_t)k.y + h);
+  h = xxhash32((uint32_t)k.z + h);
+  h = xxhash32(k.dir + h);
+  return h > 1u ? h : 1u;
+}
+__device__ __forceinline__ uint32_t key_location(HashKey k, uint32_t capacity) {  // spatial_hash.glsl:136-142
+  uint32_t h = pcg((uint32_t)k.x);
+  h = pcg((uint32_t)k.y + h);
+  h = pcg((uint32_t)k.z + h);
+  h = pcg(k.dir + h);
+  return h % capacity;
+}
+__device__ __forceinline__ V3 acescg_to_xyz(V3 v) {  // spatial_hash.glsl:12-19
+  return mk((0.66245437f * v.x + 0.13400422f * v.y) + 0.15618773f * v.z, (0.2722288f * v.x + 0.6740818f * v.y) + 0.05368953f * v.z,
+            (-0.0055746622f * v.x + 0.00406073f * v.y) + 1.0103393f * v.z);
+}
+__device__ uint32_t logluv_encode(V3 rgb) {  // spatial_hash.glsl:28-60
+  const V3 XYZ = acescg_to_xyz(rgb);
+  const float logY = 409.6f * (log2f(XYZ.y) + 20.0f);
+  const float cl = gclamp(logY, 0.0f, 16383.0f);
+  const uint32_t Le = (cl != cl) ? 0u : (uint32_t)cl;
+  if (Le == 0) return 0;
+  const float invDenom = 1.0f / ((-2.0f * XYZ.x + 12.0f * XYZ.y) + 3.0f * ((XYZ.x + XYZ.y) + XYZ.z));
+  const float u = (4.0f * XYZ.x) * invDenom, v = (9.0f * XYZ.y) * invDenom;
+  const float cu = gclamp(820.0f * u, 0.0f, 511.0f), cv = gclamp(820.0f * v, 0.0f, 511.0f);
+  const uint32_t ue = (cu != cu) ? 0u : (uint32_t)cu, ve = (cv != cv) ? 0u : (uint32_t)cv;
+  return (Le << 18) | (ue << 9) | ve;
+}
+__device__ V3 logluv_decode(uint32_t p) {  // spatial_hash.glsl:64-93
+  const uint32_t Le = p >> 18;
+  if (Le == 0) return mk(0, 0, 0);
+  const float logY = ((float)Le + 0.5f) / 409.6f - 20.0f;
+  const float Y = powf(2.0f, logY);
+  const float u = ((float)((p >> 9) & 0x1FFu) + 0.5f) / 820.0f, v = ((float)(p & 0x1FFu) + 0.5f) / 820.0f;
+  const float invDenom = 1.0f / ((6.0f * u - 16.0f * v) + 12.0f);
+  const float x = (9.0f * u) * invDenom, y = (4.0f * v) * invDenom;
+  const float s = Y / y;
+  const V3 r = xyz_to_acescg(mk(s * x, Y, s * ((1.0f - x) - y)));
+  return mk(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f));
+}
+// SpatialHashGet (spatial_hash.glsl:200-219): stamps last_accessed_frame of the entry it finds
+__device__ bool hash_get(const DevGI& gi, HashKey key, uint32_t frame_index, V3& value, uint32_t& count) {
+  const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
+  value = mk(0, 0, 0);
+  count = 0;
+  for (uint32_t i = 0; i < 3; ++i) {
+    uint32_t* e = gi.hash + (size_t)(loc + i) * 3;
+    const uint32_t cur = e[0];
+    if (cur == 0) return false;
+    if (cur == fp) {
+      reinterpret_cast<uint16_t*>(e)[4] = (uint16_t)frame_index;  // every reader stores the same value
+      value = logluv_decode(e[1]);
+      count = e[2] >> 16;
+      return true;
+    }
+  }
+  return false;
+}
+// SpatialHashInsert (spatial_hash.glsl:147-195)
+__device__ void hash_insert(const DevGI& gi, HashKey key, V3 value, uint32_t frame_index) {
+  const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
+  uint32_t i_min = 0, min_frame = 0;
+  for (uint32_t i = 0; i < 3; ++i) {
+    uint32_t* e = gi.hash + (size_t)(loc + i) * 3;
+    const uint32_t cur = atomicCAS(&e[0], 0u, fp);
+    const uint32_t w2 = e[2];
+    const uint32_t cur_frame = w2 & 0xFFFFu;
+    if (i == 0 || cur_frame < min_frame) { i_min = i; min_frame = cur_frame; }
+    if (cur == fp || cur == 0) {
+      V3 rad = mk(0, 0, 0);
+      uint32_t count = 0;
+      if (cur == fp) { count = w2 >> 16; rad = logluv_decode(e[1]); }
+      count = count < 403u ? count : 403u;
+      const uint32_t next = count + 1;
+      const float al = 1.0f / (float)next;
+      const V3 out = mk(rad.x * (1.0f - al) + value.x * al, rad.y * (1.0f - al) + value.y * al, rad.z * (1.0f - al) + value.z * al);
+      e[1] = logluv_encode(out);
+      e[2] = (frame_index & 0xFFFFu) | (next << 16);
+      return;
+    }
+  }
+  uint32_t* e = gi.hash + (size_t)(loc + i_min) * 3;  // evict the least recently accessed of the three probes
+  e[0] = fp;
+  e[1] = logluv_encode(value);
+  e[2] = (frame_index & 0xFFFFu) | (1u << 16);
+}
+__device__ __forceinline__ float srgb_to_linear(float c) {  // color.glsl:1-5
+  return c < 0.04045f ? c / 12.92f : powf(fabsf(c + 0.055f) / 1.055f, 2.4f);
+}
+__device__ V3 modulate_by_avg_albedo(V3 r, uint32_t packed) {  // final_gather.rchit:68-80, surfel.rchit:60-71
+  const V3 alb = mk(srgb_to_linear((float)((packed >> 22) & 1023u) / 1023.0f), srgb_to_linear((float)((packed >> 12) & 1023u) / 1023.0f),
+                    srgb_to_linear((float)((packed >> 2) & 1023u) / 1023.0f));
+  const V3 s = mk((1.7312546f * r.x + -0.6040432f * r.y) + -0.08010775f * r.z, (-0.131619f * r.x + 1.1348418f * r.y) + -0.008679431f * r.z,
+                  (-0.024568284f * r.x + -0.12575036f * r.y) + 1.0656371f * r.z);  // ACEScg -> sRGB, color.glsl:16-23
+  const V3 m = mk(s.x * alb.x, s.y * alb.y, s.z * alb.z);
+  return mk((0.6031065f * m.x + 0.32633433f * m.y) + 0.047995567f * m.z, (0.07011794f * m.x + 0.9199162f * m.y) + 0.012763573f * m.z,
+            (0.022178888f * m.x + 0.11607823f * m.y) + 0.94101846f * m.z);  // sRGB -> ACEScg, color.glsl:8-15
+}
+__device__ __forceinline__ uint32_t normal2faceid(V3 n) {  // normal.glsl:9-18
+  const float s = gclamp((n.x + n.y) + n.z, 0.0f, 1.0f);
+  return ((uint32_t)rintf(s) + (uint32_t)rintf(fabsf(n.z)) * 4u + (uint32_t)rintf(fabsf(n.y)) * 2u) & 0xFFu;
+}
+__device__ __forceinline__ V3 faceid2normal(uint32_t face) {  // normal.glsl:20-26
+  const float s = (float)(face & 1u) * 2.0f - 1.0f;
+  const uint32_t ax = (face & 0xFFu) >> 1;
+  return mk(ax == 0 ? s : 0.0f, ax == 1 ? s : 0.0f, ax == 2 ? s : 0.0f);
+}
+// world-space surfel (brick centre + face) and hash key of a rough hit: final_gather.rchit:35-45, surfel.rchit:35-45
+__device__ void brick_surfel(const FrameArgs& a, const Hit& h, V3 o, V3 d, HashKey& key, DevSurfel& sf, uint32_t& avg_albedo) {
+  const DevInstance& in = a.instances[h.inst];
+  const DevModel& m = a.models[in.model];
+  const DustHipBlock b = m.blocks[resolve_block(m, h.block)];
+  const V3 ctr = mk((float)b.x + 2.0f, (float)b.y + 2.0f, (float)b.z + 2.0f);
+  const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
+  const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
+  const V3 nw = cubed_normalize(xform_dir(in.o2w, mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z)));
+  const V3 cw = xform_point(in.o2w, ctr);
+  const uint32_t face = normal2faceid(nw);
+  key.x = f2i_trunc(cw.x / 4.0f); key.y = f2i_trunc(cw.y / 4.0f); key.z = f2i_trunc(cw.z / 4.0f);
+  key.dir = face;
+  sf.x = cw.x; sf.y = cw.y; sf.z = cw.z; sf.direction = face;
+  avg_albedo = b.avg_albedo;
+}
+}  // namespace
+
+// ==================================================================== final gather
+// final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
+template <bool COUNT>
+__global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  stage_roots(a);
+  float4* cand = wave_cand_list(a);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = {0, 0, 0};
+  Packet p;
+  while (next_packet(a, wc, p)) {
+    const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
+    const float hitT = p.valid ? a.g.depth[pix] : INFINITY;
+    bool live = p.valid && !(hitT == INFINITY);
+    V3 inval = mk(0, 0, 0), loc = mk(0, 0, 0), ad = mk(0, 0, 1);
+    if (live) {
+      float w;
+      inval = load_radiance(a.g.illuminance, pix, w);
+      if (w > 0.0f) live = false;  // resolved by the ambient occlusion pass
+    }
+    if (live) {
+      const V3 n = nrd_unpack_normal(a.g.normal[pix]);
+      const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+      loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
+               (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+      const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
+      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
+      const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
+                       (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+      ad = normalize3(rotate_by_normal(n, ns));
+    }
+    Hit h;
+    const uint32_t ncand = cull_instances(a, live, loc, ad, a.cam.far_, cand);
+    trace_ray<2, COUNT>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
+    __builtin_amdgcn_wave_barrier();
+    if (!live) continue;
+    if (!h.found) {
+      const V3 sk = sky_radiance(a.sky, normalize3(ad));
+      store_radiance(a.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
+      continue;
+    }
+    HashKey key;
+    DevSurfel sf;
+    uint32_t alb;
+    brick_surfel(a, h, loc, ad, key, sf, alb);
+    V3 rad;
+    uint32_t count;
+    hash_get(a.gi, key, a.frame_index, rad, count);
+    const float prob = 1.0f / (float)(count + 2u);
+    const float noise = (float)a.noise0[((p.py + 21u + a.rand) % 128u) * 128u + ((p.px + 34u + a.rand) % 128u)] / 255.0f;
+    if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
+      const uint32_t index = p.px + p.py * a.width;
+      a.gi.pixel_surfel[index] = sf;
+      atomicMax(&a.gi.slot_owner[index % a.gi.pool_size], index + 1u);
+    }
+    rad = modulate_by_avg_albedo(rad, alb);
+    store_radiance(a.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
+  }
+  flush_stats<COUNT>(a, 0, st);
+}
+
+// the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
+__global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    const uint32_t o = a.gi.slot_owner[s];
+    if (o != 0u) {
+      a.gi.pool[s] = a.gi.pixel_surfel[o - 1u];
+      a.gi.slot_owner[s] = 0u;
+    }
+  }
+}
+
+// ==================================================================== surfel pass, phase 1: trace + read the hash
+// surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
+template <bool COUNT>
+__global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  stage_roots(a);
+  float4* cand = wave_cand_list(a);
+  LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = {0, 0, 0};
+  Packet p;
+  const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
+  while (next_packet(a, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
+    const uint32_t i = (p.px >> 3) * 64u + (threadIdx.x & 63u);
+    const bool in_range = i < a.gi.pool_size;
+    DevSurfel e;
+    e.x = e.y = e.z = 0.0f; e.direction = 0xFFFFFFFFu;
+    if (in_range) e = a.gi.pool[i];
+    const bool live = in_range && e.direction < 6u;
+    DevHashRequest rq;
+    rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
+    DevSurfel repl;
+    repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
+    const V3 n = faceid2normal(live ? e.direction : 0u);
+    const V3 org = mk(e.x + 2.01f * n.x, e.y + 2.01f * n.y, e.z + 2.01f * n.z);
+    const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+    V3 cd = mk(0, 0, 1);
+    if (live) {
+      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
+      const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
+                       (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+      cd = normalize3(rotate_by_normal(n, ns));
+    }
+    V3 payload = mk(0, 0, 0);
+    const bool sun_live = live && dot3(sun, n) > 0.0f;
+    const V3 sd = normalize3(sun);
+    Hit h;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const bool act = k == 0 ? sun_live : live;
+      const V3 dir = k == 0 ? sd : cd;
+      const uint32_t ncand = cull_instances(a, act, org, dir, 10000.0f, cand);
+      LaneStats cur = {0, 0, 0, 0, 0, 0};
+      trace_ray<3, COUNT>(a, act, org, dir, 0.1f, 10000.0f, k == 0, cand, ncand, h, cur);
+      if (COUNT) add_stats(k == 0 ? st_sun : st_cos, cur);
+      __builtin_amdgcn_wave_barrier();
+      if (k == 0 && sun_live && !h.found) {  // surfel/nee.rmiss:15-27
+        const V3 sr = sun_radiance(a.sky, normalize3(sd));
+        const float kk = 1.0f - cosf(a.sky[55]);
+        const float dn = dot3(n, sd);
+        payload = mk((sr.x * kk) * dn, (sr.y * kk) * dn, (sr.z * kk) * dn);
+      }
+    }
+    if (live) {
+      rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
+      rq.dir_flags = e.direction & 0xFFu;
+      if (!h.found) {  // surfel.rmiss:14-26
+        const V3 sk = sky_radiance(a.sky, normalize3(cd));
+        rq.vx = sk.x + payload.x; rq.vy = sk.y + payload.y; rq.vz = sk.z + payload.z;
+        rq.dir_flags |= 0x100u;
+      } else {         // surfel.rchit:35-102
+        HashKey key;
+        DevSurfel sf;
+        uint32_t alb;
+        brick_surfel(a, h, org, cd, key, sf, alb);
+        V3 rad;
+        uint32_t count = 0;
+        const bool found = hash_get(a.gi, key, a.frame_index, rad, count);
+        const float rnd0 = (float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)] / 255.0f;
+        if (found) {
+          rad = modulate_by_avg_albedo(rad, alb);
+          rq.vx = rad.x + payload.x; rq.vy = rad.y + payload.y; rq.vz = rad.z + payload.z;
+          rq.dir_flags |= 0x100u;
+        } else if (rnd0 > 1.0f / (float)(count + 2u)) {
+          repl = sf;
+        }
+      }
+    }
+    if (in_range) {
+      a.gi.requests[i] = rq;
+      a.gi.replacement[i] = repl;
+    }
+  }
+  flush_stats<COUNT>(a, 0, st_sun);
+  flush_stats<COUNT>(a, 1, st_cos);
+}
+
+// ==================================================================== surfel pass, phase 2: apply in surfel order
+// Deterministic mode: one wavefront scans the requests 64 at a time and lane 0 applies them in index order.
+__global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t base = 0; base < a.gi.pool_size; base += 64u) {
+    const uint32_t i = base + lane;
+    bool work = false;
+    if (i < a.gi.pool_size) work = (a.gi.requests[i].dir_flags & 0x100u) || a.gi.replacement[i].direction != 0xFFFFFFFFu;
+    uint64_t mask = __ballot(work);
+    if (lane == 0) {
+      while (mask) {
+        const uint32_t j = base + (uint32_t)__ffsll((long long)mask) - 1u;
+        mask &= mask - 1ull;
+        const DevHashRequest rq = a.gi.requests[j];
+        if (rq.dir_flags & 0x100u) {
+          HashKey k;
+          k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+          hash_insert(a.gi, k, mk(rq.vx, rq.vy, rq.vz), a.frame_index);
+        }
+        const DevSurfel r = a.gi.replacement[j];
+        if (r.direction != 0xFFFFFFFFu) a.gi.pool[j % a.gi.pool_size] = r;
+      }
+    }
+  }
+}
+// Throughput mode: every surfel applies its own insert concurrently, as the reference's shaders do (racy by design,
+// spatial_hash.glsl:147-195 only claims the fingerprint atomically); results are statistically, not bitwise, repeatable.
+__global__ void k_surfel_apply_racy(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
+    const DevHashRequest rq = a.gi.requests[j];
+    if (rq.dir_flags & 0x100u) {
+      HashKey k;
+      k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+      hash_insert(a.gi, k, mk(rq.vx, rq.vy, rq.vz), a.frame_index);
+    }
+    const DevSurfel r = a.gi.replacement[j];
+    if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
+  }
+}
+
 // ==================================================================== N-frame mean (stands in for NRD)
 __global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
@@ -802,6 +1151,21 @@ hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev,
   else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, dev);
   return hipGetLastError();
 }
+hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(host, block);
+  if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, dev);
+  else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, dev);
+  hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, dev);
+  return hipGetLastError();
+}
+hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {
+  const size_t lds = lds_bytes(host, block);
+  if (count) hipLaunchKernelGGL(k_surfel_trace<true>, dim3(grid), dim3(block), lds, s, dev);
+  else hipLaunchKernelGGL(k_surfel_trace<false>, dim3(grid), dim3(block), lds, s, dev);
+  if (ordered) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, dev);
+  else hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, dev);
+  return hipGetLastError();
+}
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t s) {
   hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, dev);
   return hipGetLastError();
@@ -809,7 +1173,9 @@ hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t s) {
 hipError_t configure_kernels(size_t max_lds) {
   hipError_t e;
   const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
-                       (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>};
+                       (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>,
+                       (const void*)k_final_gather<false>, (const void*)k_final_gather<true>,
+                       (const void*)k_surfel_trace<false>, (const void*)k_surfel_trace<true>};
   for (const void* f : fns) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;

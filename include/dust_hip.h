@@ -191,6 +191,9 @@ typedef enum DustHipPlane {
 #define DUST_PASS_SURFEL (1u << 3)             /* standard.rs:712-725 */
 #define DUST_PASS_ACCUMULATE (1u << 4)         /* stands in for NRDPipeline::render (nrd.rs:272-617) */
 #define DUST_PASS_COUNT_STATS (1u << 16)       /* run the counting build of the kernels (slower) */
+#define DUST_PASS_GI_ORDERED (1u << 17)        /* apply the surfel pass's hash inserts in surfel-index order (bitwise
+                                                  repeatable, serial); default: concurrently, as the reference's racy
+                                                  shaders do (spatial_hash.glsl:147-195), statistically repeatable */
 
 typedef struct DustHipFrameParams {
   uint32_t struct_size;
@@ -219,11 +222,17 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const
  * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
-/* pass: 0 primary, 1 AO sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel; valid after dust_hip_sync */
+/* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
 DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline*, DustHipPlane, void** ptr, size_t* bytes);
 /* synchronous device-to-host copy of one plane */
 DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* dst, size_t dst_bytes);
+/* Persistent GI buffers (standard.rs:334-358): (re)allocates and resets the spatial hash (SpatialHashCapacity,
+ * spatial_hash.glsl:1, default 32 Mi entries) and the surfel pool (SurfelPoolSize, surfel.glsl:2, default 345600).
+ * Called implicitly with the defaults by the first frame that runs a GI pass. */
+DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline*, uint32_t hash_capacity, uint32_t surfel_pool_size);
+/* synchronous copy of GI state to the host: which = 0 spatial hash ((capacity+2) x 12 B), 1 surfel pool (16 B each) */
+DustStatus dust_hip_pipeline_read_gi(DustHipPipeline*, uint32_t which, void* dst, size_t dst_bytes);
 /* zero every plane and the accumulation count */
 DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
 

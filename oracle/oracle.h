@@ -165,6 +165,24 @@ void orc_pass_primary(const OrcScene*, int mode, const OrcCamera*, const OrcSky*
 void orc_pass_ao(const OrcScene*, int mode, const OrcCamera*, const OrcSky*, OrcGBuffer*, const uint8_t* noise5,
                  uint32_t rand, uint32_t y0, uint32_t y1, OrcRayStats* stats_sun, OrcRayStats* stats_ao);
 
+/* hash-fed GI state: spatial hash (spatial_hash.glsl:1-220) + surfel pool (layout.playout:1-4, standard.rs:334-358) */
+typedef struct OrcGI OrcGI;
+OrcGI* orc_gi_new(uint32_t hash_capacity, uint32_t surfel_pool_size);
+void orc_gi_free(OrcGI*);
+void* orc_gi_hash_ptr(OrcGI*);  /* (capacity + 2) x {u32 fingerprint, u32 LogLuv, u16 last_frame, u16 count} */
+void* orc_gi_pool_ptr(OrcGI*);  /* pool_size x {vec3 position, u32 direction} */
+uint32_t orc_hash_fingerprint(const int32_t pos[3], uint32_t dir);
+uint32_t orc_hash_location(const int32_t pos[3], uint32_t dir, uint32_t capacity);
+void orc_hash_insert(OrcGI*, const int32_t pos[3], uint32_t dir, const float value[3], uint32_t frame_index);
+int orc_hash_get(OrcGI*, const int32_t pos[3], uint32_t dir, uint32_t frame_index, float value[3], uint32_t* count);
+/* final_gather.rgen/.rchit/.rmiss + rough.rint; noise0: 128*128 R8 slice, noise5: 128*128 RGBA8 slice */
+void orc_pass_final_gather(const OrcScene*, int mode, const OrcCamera*, const OrcSky*, OrcGBuffer*, const uint8_t* noise0,
+                           const uint8_t* noise5, uint32_t rand, uint32_t frame_index, OrcGI*, uint32_t y0, uint32_t y1,
+                           OrcRayStats* stats);
+/* surfel.rgen/.rchit/.rmiss + surfel/nee.rmiss */
+void orc_pass_surfel(const OrcScene*, int mode, const OrcSky*, const uint8_t* noise0, const uint8_t* noise5, uint32_t rand,
+                     uint32_t frame_index, OrcGI*, OrcRayStats* stats_sun, OrcRayStats* stats_cos);
+
 /* encodings (headers/nrd.glsl, color.glsl, spatial_hash.glsl, normal.glsl) for unit tests */
 uint32_t orc_pack_rgb10a2(const float v[4]);
 void orc_unpack_rgb10a2(uint32_t p, float v[4]);

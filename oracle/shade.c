@@ -854,3 +854,240 @@ void orc_pass_ao(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky
         pack_radiance(payload, 0.0f, g->illuminance + pix * 4); /* ambient_occlusion.rmiss:10-13 */
     }
 }
+
+/* ================================================================== hash-fed GI: final gather + surfel passes
+ * The reference updates the spatial hash and the surfel pool with racy read-modify-writes, so its
+ * result depends on GPU scheduling. The restatement fixes an order (documented deviation, DESIGN.md "GI order"):
+ *   final gather: pixels in row-major order (the highest pixel index that enqueues wins a surfel slot);
+ *   surfel pass : phase 1 -- every surfel traces its rays and reads the hash AS IT WAS AT THE START OF THE PASS
+ *                            (Get still stamps last_accessed_frame, a write of the same value from everyone);
+ *                 phase 2 -- the SpatialHashInsert calls and pool replacements are applied in surfel-index order.
+ */
+typedef struct OrcHashEntry { uint32_t fingerprint, radiance; uint16_t last_accessed_frame, sample_count; } OrcHashEntry;
+typedef struct OrcSurfel { float pos[3]; uint32_t direction; } OrcSurfel;
+struct OrcGI {
+  uint32_t capacity, pool_size;
+  OrcHashEntry* hash; /* capacity + 2: probes run up to 2 past the end (spatial_hash.glsl:154-158) */
+  OrcSurfel* pool;
+};
+
+OrcGI* orc_gi_new(uint32_t capacity, uint32_t pool_size) {
+  OrcGI* g = (OrcGI*)calloc(1, sizeof(OrcGI));
+  g->capacity = capacity; g->pool_size = pool_size;
+  g->hash = (OrcHashEntry*)calloc((size_t)capacity + 2, sizeof(OrcHashEntry)); /* standard.rs:348-358 relies on zeros */
+  g->pool = (OrcSurfel*)malloc((size_t)pool_size * sizeof(OrcSurfel));
+  memset(g->pool, 0xFF, (size_t)pool_size * sizeof(OrcSurfel)); /* fill_buffer(u32::MAX), standard.rs:345-347 */
+  return g;
+}
+void orc_gi_free(OrcGI* g) { if (g) { free(g->hash); free(g->pool); free(g); } }
+void* orc_gi_hash_ptr(OrcGI* g) { return g->hash; }
+void* orc_gi_pool_ptr(OrcGI* g) { return g->pool; }
+
+typedef struct { int32_t x, y, z; uint32_t dir; } HashKey;
+static uint32_t key_fingerprint(HashKey k) { /* spatial_hash.glsl:128-135 */
+  uint32_t h = orc_xxhash32((uint32_t)k.x);
+  h = orc_xxhash32((uint32_t)k.y + h);
+  h = orc_xxhash32((uint32_t)k.z + h);
+  h = orc_xxhash32(k.dir + h);
+  return h > 1u ? h : 1u;
+}
+static uint32_t key_location(HashKey k, uint32_t capacity) { /* spatial_hash.glsl:136-142 */
+  uint32_t h = orc_pcg((uint32_t)k.x);
+  h = orc_pcg((uint32_t)k.y + h);
+  h = orc_pcg((uint32_t)k.z + h);
+  h = orc_pcg(k.dir + h);
+  return h % capacity;
+}
+uint32_t orc_hash_fingerprint(const int32_t pos[3], uint32_t dir) { HashKey k = {pos[0], pos[1], pos[2], dir}; return key_fingerprint(k); }
+uint32_t orc_hash_location(const int32_t pos[3], uint32_t dir, uint32_t capacity) { HashKey k = {pos[0], pos[1], pos[2], dir}; return key_location(k, capacity); }
+
+static void hash_insert(OrcGI* g, HashKey key, v3 value, uint32_t frame_index) { /* spatial_hash.glsl:147-195 */
+  uint32_t fp = key_fingerprint(key), loc = key_location(key, g->capacity);
+  uint32_t i_min = 0, min_frame = 0;
+  for (uint32_t i = 0; i < 3; ++i) {
+    OrcHashEntry* e = &g->hash[loc + i];
+    uint32_t cur = e->fingerprint; /* atomicCompSwap(fp, 0, new) */
+    if (cur == 0) e->fingerprint = fp;
+    uint32_t cur_frame = e->last_accessed_frame;
+    if (i == 0 || cur_frame < min_frame) { i_min = i; min_frame = cur_frame; }
+    if (cur == fp || cur == 0) {
+      float rad[3] = {0, 0, 0};
+      uint32_t count = 0;
+      if (cur == fp) { count = e->sample_count; orc_logluv_decode(e->radiance, rad); }
+      if (count > 403u) count = 403u; /* min(count, MAX_SAMPLE_COUNT - 1) */
+      uint32_t next = count + 1;
+      float a = 1.0f / (float)next; /* mix(x, y, a) = x*(1-a) + y*a */
+      float out[3] = {rad[0] * (1.0f - a) + value.x * a, rad[1] * (1.0f - a) + value.y * a, rad[2] * (1.0f - a) + value.z * a};
+      e->radiance = orc_logluv_encode(out);
+      e->last_accessed_frame = (uint16_t)frame_index;
+      e->sample_count = (uint16_t)next;
+      return;
+    }
+  }
+  OrcHashEntry* e = &g->hash[loc + i_min]; /* evict the least recently accessed of the three */
+  float v[3] = {value.x, value.y, value.z};
+  e->fingerprint = fp;
+  e->radiance = orc_logluv_encode(v);
+  e->last_accessed_frame = (uint16_t)frame_index;
+  e->sample_count = 1;
+}
+static int hash_get(OrcGI* g, HashKey key, uint32_t frame_index, v3* value, uint32_t* count) { /* spatial_hash.glsl:200-219 */
+  uint32_t fp = key_fingerprint(key), loc = key_location(key, g->capacity);
+  *value = V3(0, 0, 0); *count = 0;
+  for (uint32_t i = 0; i < 3; ++i) {
+    OrcHashEntry* e = &g->hash[loc + i];
+    if (e->fingerprint == 0) return 0;
+    if (e->fingerprint == fp) {
+      e->last_accessed_frame = (uint16_t)frame_index;
+      float rad[3];
+      orc_logluv_decode(e->radiance, rad);
+      *value = V3(rad[0], rad[1], rad[2]);
+      *count = e->sample_count;
+      return 1;
+    }
+  }
+  return 0;
+}
+void orc_hash_insert(OrcGI* g, const int32_t pos[3], uint32_t dir, const float value[3], uint32_t frame_index) {
+  HashKey k = {pos[0], pos[1], pos[2], dir};
+  hash_insert(g, k, V3(value[0], value[1], value[2]), frame_index);
+}
+int orc_hash_get(OrcGI* g, const int32_t pos[3], uint32_t dir, uint32_t frame_index, float value[3], uint32_t* count) {
+  HashKey k = {pos[0], pos[1], pos[2], dir};
+  v3 v;
+  int f = hash_get(g, k, frame_index, &v, count);
+  value[0] = v.x; value[1] = v.y; value[2] = v.z;
+  return f;
+}
+
+static const float M_sRGB2ACEScg[9] = {0.6031065f, 0.07011794f, 0.022178888f, 0.32633433f, 0.9199162f,
+                                       0.11607823f, 0.047995567f, 0.012763573f, 0.94101846f}; /* color.glsl:8-15 */
+static const float M_ACEScg2sRGB[9] = {1.7312546f, -0.131619f, -0.024568284f, -0.6040432f, 1.1348418f,
+                                       -0.12575036f, -0.08010775f, -0.008679431f, 1.0656371f}; /* color.glsl:16-23 */
+static float srgb_to_linear(float c) { /* color.glsl:1-5 */
+  return c < 0.04045f ? c / 12.92f : powf(fabsf(c + 0.055f) / 1.055f, 2.4f);
+}
+/* final_gather.rchit:68-80 / surfel.rchit:60-71 */
+static v3 modulate_by_avg_albedo(v3 radiance, uint32_t packed) {
+  v3 alb = V3(srgb_to_linear((float)((packed >> 22) & 1023u) / 1023.0f), srgb_to_linear((float)((packed >> 12) & 1023u) / 1023.0f),
+              srgb_to_linear((float)((packed >> 2) & 1023u) / 1023.0f));
+  v3 s = mat3_mul(M_ACEScg2sRGB, radiance);
+  return mat3_mul(M_sRGB2ACEScg, V3(s.x * alb.x, s.y * alb.y, s.z * alb.z));
+}
+
+/* the world-space surfel (brick centre + face) of a rough hit: final_gather.rchit:35-45, surfel.rchit:35-45 */
+static void brick_surfel(const OrcScene* s, uint32_t inst, uint32_t block, float t, v3 o, v3 d, HashKey* key, OrcSurfel* sf,
+                         uint32_t* avg_albedo) {
+  const SceneInst* si = &s->insts[inst];
+  const SceneModel* m = &s->models[si->in.model];
+  const OrcBlock* b = &m->blocks[block];
+  v3 ctr = V3((float)b->x + 2.0f, (float)b->y + 2.0f, (float)b->z + 2.0f);
+  v3 oo = xform_point(si->w2o, o), od = xform_dir(si->w2o, d);
+  v3 hpo = V3(t * od.x + oo.x, t * od.y + oo.y, t * od.z + oo.z);
+  v3 nw = cubed_normalize(xform_dir(si->in.obj_to_world, V3(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z)));
+  v3 cw = xform_point(si->in.obj_to_world, ctr);
+  float nwa[3] = {nw.x, nw.y, nw.z};
+  uint32_t face = orc_normal2faceid(nwa);
+  key->x = f2i_sat(cw.x / 4.0f); key->y = f2i_sat(cw.y / 4.0f); key->z = f2i_sat(cw.z / 4.0f);
+  key->dir = face;
+  sf->pos[0] = cw.x; sf->pos[1] = cw.y; sf->pos[2] = cw.z; sf->direction = face;
+  *avg_albedo = b->avg_albedo;
+}
+
+/* final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24 */
+void orc_pass_final_gather(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky* sky, OrcGBuffer* g, const uint8_t* noise0,
+                           const uint8_t* noise5, uint32_t rnd, uint32_t frame_index, OrcGI* gi, uint32_t y0, uint32_t y1,
+                           OrcRayStats* st) {
+  const uint32_t W = g->width, H = g->height;
+  for (uint32_t py = y0; py < y1 && py < H; ++py)
+    for (uint32_t px = 0; px < W; ++px) {
+      size_t pix = (size_t)py * W + px;
+      float hitT = g->depth[pix];
+      if (hitT == INFINITY) continue;
+      v3 inval; float inw;
+      unpack_radiance(g->illuminance + pix * 4, &inval, &inw);
+      if (inw > 0.0f) continue; /* resolved by the AO pass */
+      float pk[4], nw[3], d[3];
+      orc_unpack_rgb10a2(g->normal[pix], pk);
+      orc_nrd_unpack_normal(pk, nw);
+      orc_camera_ray_dir(cam, px, py, W, H, d);
+      float loc[3];
+      for (int a = 0; a < 3; ++a) loc[a] = (hitT * d[a] + cam->pos[a]) + nw[a] * 0.01f;
+      uint32_t nx = (px + 7u + rnd) % 128u, ny = (py + 183u + rnd) % 128u;
+      const uint8_t* tex = noise5 + ((size_t)ny * 128 + nx) * 4;
+      v3 ns = V3((float)tex[0] / 255.0f * 2.0f - 1.0f, (float)tex[1] / 255.0f * 2.0f - 1.0f, (float)tex[2] / 255.0f * 2.0f - 1.0f);
+      v3 ad = normalize3(rotate_by_normal(V3(nw[0], nw[1], nw[2]), ns));
+      float adir[3] = {ad.x, ad.y, ad.z};
+      float t; uint32_t inst, block, voxel;
+      if (!orc_trace(s, mode, 2, 0, loc, adir, 8.0f, cam->far_, &t, &inst, &block, &voxel, st)) {
+        v3 sk = sky_radiance(sky, normalize3(ad));
+        pack_radiance(V3(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f, g->illuminance + pix * 4);
+        continue;
+      }
+      HashKey key; OrcSurfel sf; uint32_t alb;
+      brick_surfel(s, inst, block, t, V3(loc[0], loc[1], loc[2]), ad, &key, &sf, &alb);
+      v3 rad; uint32_t count;
+      hash_get(gi, key, frame_index, &rad, &count);
+      float prob = 1.0f / (float)(count + 2u);
+      float noise = (float)noise0[((size_t)((py + 21u + rnd) % 128u)) * 128 + ((px + 34u + rnd) % 128u)] / 255.0f;
+      if (noise > prob) gi->pool[(px + py * W) % gi->pool_size] = sf; /* final_gather.rchit:52-63 */
+      rad = modulate_by_avg_albedo(rad, alb);
+      pack_radiance(V3(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), t, g->illuminance + pix * 4);
+    }
+}
+
+/* surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27 */
+void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
+                     uint32_t frame_index, OrcGI* gi, OrcRayStats* st_sun, OrcRayStats* st_cos) {
+  const uint32_t N = gi->pool_size;
+  typedef struct { int kind; HashKey key; v3 value; int replace; OrcSurfel repl; } Req;
+  Req* req = (Req*)calloc(N, sizeof(Req));
+  for (uint32_t i = 0; i < N; ++i) { /* phase 1 */
+    OrcSurfel e = gi->pool[i];
+    if (e.direction >= 6u) continue;
+    v3 n = faceid2normal(e.direction);
+    uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+    float org[3] = {e.pos[0] + 2.01f * n.x, e.pos[1] + 2.01f * n.y, e.pos[2] + 2.01f * n.z};
+    const uint8_t* tex = noise5 + ((size_t)((ny0 + 47u + rnd) % 128u) * 128 + ((nx0 + 16u + rnd) % 128u)) * 4;
+    v3 ns = V3((float)tex[0] / 255.0f * 2.0f - 1.0f, (float)tex[1] / 255.0f * 2.0f - 1.0f, (float)tex[2] / 255.0f * 2.0f - 1.0f);
+    ns = rotate_by_normal(n, ns);
+    v3 sun = V3(sky->v[48], sky->v[49], sky->v[50]);
+    v3 payload = V3(0, 0, 0);
+    float t; uint32_t inst, block, voxel;
+    if (dot3(sun, n) > 0.0f) {
+      v3 sd = normalize3(sun);
+      float sdir[3] = {sd.x, sd.y, sd.z};
+      if (!orc_trace(s, mode, 3, 1, org, sdir, 0.1f, 10000.0f, &t, &inst, &block, &voxel, st_sun)) {
+        v3 sr = sun_radiance(sky, normalize3(sd));
+        float k = 1.0f - cosf(sky->v[55]);
+        float dn = dot3(n, sd);
+        payload = V3((sr.x * k) * dn, (sr.y * k) * dn, (sr.z * k) * dn);
+      }
+    }
+    HashKey skey = {f2i_sat(e.pos[0] / 4.0f), f2i_sat(e.pos[1] / 4.0f), f2i_sat(e.pos[2] / 4.0f), e.direction & 0xFFu};
+    v3 cd = normalize3(ns);
+    float cdir[3] = {cd.x, cd.y, cd.z};
+    if (!orc_trace(s, mode, 3, 0, org, cdir, 0.1f, 10000.0f, &t, &inst, &block, &voxel, st_cos)) {
+      v3 sk = sky_radiance(sky, normalize3(cd));
+      req[i].kind = 1; req[i].key = skey; req[i].value = V3(sk.x + payload.x, sk.y + payload.y, sk.z + payload.z);
+      continue;
+    }
+    HashKey key; OrcSurfel sf; uint32_t alb;
+    brick_surfel(s, inst, block, t, V3(org[0], org[1], org[2]), cd, &key, &sf, &alb);
+    v3 rad; uint32_t count = 0;
+    int found = hash_get(gi, key, frame_index, &rad, &count);
+    float rnd0 = (float)noise0[((size_t)((ny0 + 40u + rnd) % 128u)) * 128 + ((nx0 + 114u + rnd) % 128u)] / 255.0f;
+    if (found) {
+      rad = modulate_by_avg_albedo(rad, alb);
+      req[i].kind = 1; req[i].key = skey; req[i].value = V3(rad.x + payload.x, rad.y + payload.y, rad.z + payload.z);
+    } else {
+      float prob = 1.0f / (float)(count + 2u);
+      if (rnd0 > prob) { req[i].replace = 1; req[i].repl = sf; }
+    }
+  }
+  for (uint32_t i = 0; i < N; ++i) { /* phase 2: in surfel order */
+    if (req[i].kind == 1) hash_insert(gi, req[i].key, req[i].value, frame_index);
+    if (req[i].replace) gi->pool[i % N] = req[i].repl;
+  }
+  free(req);
+}

@@ -99,6 +99,24 @@ def lib():
                                        C.c_uint32, C.c_uint32, C.POINTER(OrcRayStats)]
         l.orc_pass_ao.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcCamera), C.POINTER(OrcSky), C.POINTER(OrcGBuffer),
                                   C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OrcRayStats), C.POINTER(OrcRayStats)]
+        l.orc_gi_new.restype = C.c_void_p
+        l.orc_gi_new.argtypes = [C.c_uint32, C.c_uint32]
+        l.orc_gi_free.argtypes = [C.c_void_p]
+        l.orc_gi_hash_ptr.restype = C.c_void_p
+        l.orc_gi_hash_ptr.argtypes = [C.c_void_p]
+        l.orc_gi_pool_ptr.restype = C.c_void_p
+        l.orc_gi_pool_ptr.argtypes = [C.c_void_p]
+        l.orc_hash_fingerprint.restype = C.c_uint32
+        l.orc_hash_fingerprint.argtypes = [C.POINTER(C.c_int32), C.c_uint32]
+        l.orc_hash_location.restype = C.c_uint32
+        l.orc_hash_location.argtypes = [C.POINTER(C.c_int32), C.c_uint32, C.c_uint32]
+        l.orc_hash_insert.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_float), C.c_uint32]
+        l.orc_hash_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        l.orc_pass_final_gather.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcCamera), C.POINTER(OrcSky), C.POINTER(OrcGBuffer),
+                                            C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.POINTER(OrcRayStats)]
+        l.orc_pass_surfel.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcSky), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                      C.c_void_p, C.POINTER(OrcRayStats), C.POINTER(OrcRayStats)]
         l.orc_pack_rgb10a2.restype = C.c_uint32
         l.orc_pack_rgb10a2.argtypes = [C.POINTER(C.c_float)]
         l.orc_unpack_rgb10a2.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
@@ -219,3 +237,36 @@ def sky_from(state):
     s = OrcSky()
     s.v[:] = np.asarray(state, np.float32).reshape(56).tolist()
     return s
+
+
+HASH_DTYPE = np.dtype([("fingerprint", "<u4"), ("radiance", "<u4"), ("last_accessed_frame", "<u2"), ("sample_count", "<u2")])
+SURFEL_DTYPE = np.dtype([("pos", "<f4", 3), ("direction", "<u4")])
+
+
+class GI:
+    """Oracle spatial hash + surfel pool."""
+
+    def __init__(self, capacity, pool_size):
+        self.l = lib()
+        self.capacity, self.pool_size = capacity, pool_size
+        self.h = self.l.orc_gi_new(capacity, pool_size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.orc_gi_free(self.h)
+            self.h = None
+
+    def hash(self):
+        n = (self.capacity + 2) * 12
+        return np.frombuffer(C.string_at(self.l.orc_gi_hash_ptr(self.h), n), HASH_DTYPE).copy()
+
+    def pool(self):
+        return np.frombuffer(C.string_at(self.l.orc_gi_pool_ptr(self.h), self.pool_size * 16), SURFEL_DTYPE).copy()
+
+    def insert(self, pos, direction, value, frame):
+        self.l.orc_hash_insert(self.h, (C.c_int32 * 3)(*pos), direction, f3(value), frame)
+
+    def get(self, pos, direction, frame):
+        out, cnt = (C.c_float * 3)(), C.c_uint32()
+        f = self.l.orc_hash_get(self.h, (C.c_int32 * 3)(*pos), direction, frame, out, C.byref(cnt))
+        return bool(f), list(out), cnt.value

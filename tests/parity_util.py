@@ -96,11 +96,12 @@ def camera_for(desc_or_eye, target=(0.0, 0.0, 0.0), proj=None):
     return api.make_camera(eye, api.look_at_rotation(eye, target), proj)
 
 
-def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.ORC_MODE_HIER, rows=None, stats=None):
-    g = O.GBuffer(w, h)
+def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.ORC_MODE_HIER, rows=None, stats=None,
+                  noise0=None, gi=None, frame_index=1, g=None):
+    g = g or O.GBuffer(w, h)
     oc, osky = O.camera_from(cam), O.sky_from(sky)
     y0, y1 = rows if rows else (0, h)
-    st = stats if stats is not None else [O.OrcRayStats(), O.OrcRayStats(), O.OrcRayStats()]
+    st = stats if stats is not None else [O.OrcRayStats() for _ in range(6)]
     l = O.lib()
     if passes & L.PASS_PRIMARY:
         l.orc_pass_primary(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), y0, y1, C.byref(st[0]))
@@ -108,6 +109,15 @@ def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.OR
         n5 = np.ascontiguousarray(noise5, np.uint8)
         l.orc_pass_ao(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), n5.ctypes.data_as(C.c_void_p), rand, y0, y1,
                       C.byref(st[1]), C.byref(st[2]))
+    if passes & (L.PASS_FINAL_GATHER | L.PASS_SURFEL):
+        n0 = np.ascontiguousarray(noise0, np.uint8)
+        n5 = np.ascontiguousarray(noise5, np.uint8)
+    if passes & L.PASS_FINAL_GATHER:
+        l.orc_pass_final_gather(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), n0.ctypes.data_as(C.c_void_p),
+                                n5.ctypes.data_as(C.c_void_p), rand, frame_index, gi.h, y0, y1, C.byref(st[3]))
+    if passes & L.PASS_SURFEL:
+        l.orc_pass_surfel(oscene.h, mode, C.byref(osky), n0.ctypes.data_as(C.c_void_p), n5.ctypes.data_as(C.c_void_p), rand,
+                          frame_index, gi.h, C.byref(st[4]), C.byref(st[5]))
     return g
 
 
