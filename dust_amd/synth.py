@@ -317,3 +317,64 @@ def splitmix32(x):
 def frame_rand(seed, frame_index):
     """`rand` push constant of a frame (standard.rs:449 uses thread_rng; SURVEY 8d fixes it to this)."""
     return splitmix32((seed ^ frame_index) & 0xFFFFFFFF)
+
+
+# ------------------------------------------------------------------ config 5: procedural deep tree (SURVEY 8d)
+def _mix32(x):
+    x = (x ^ (x >> 16)) * np.uint32(0x7FEB352D)
+    x = (x ^ (x >> 15)) * np.uint32(0x846CA68B)
+    return x ^ (x >> 16)
+
+
+def procedural_deep_blocks(seed=0xC5, occupancy=0.01, extent_log2=12, chunk=1 << 22, sample=False):
+    """Blocks of a single 4096^3 model (hierarchy (4,4,2,2)): brick (bx,by,bz) is occupied iff
+    hash(seed,bx,by,bz) < occupancy; its 64 voxels are set with p = 0.5. Returned in Tree::iter_leaf order
+    (depth-first, x slowest at every level) as (blocks, materials) ready for dust_hip_model_create.
+    sample=True draws occupancy * bricks random brick coordinates instead of hashing all 2^30 (for tests)."""
+    from .api import BLOCK_DTYPE
+    nb = 1 << (extent_log2 - 2)            # bricks per axis
+    thr = np.uint32(min(0xFFFFFFFF, int(occupancy * 4294967296.0)))
+    total = nb ** 3
+    keep = []
+    with np.errstate(over="ignore"):
+        if sample:
+            rng0 = np.random.default_rng(seed)
+            c = np.unique(rng0.integers(0, total, int(round(occupancy * total)), dtype=np.uint64))
+            bx, by, bz = (c // (nb * nb)).astype(np.uint32), ((c // nb) % nb).astype(np.uint32), (c % nb).astype(np.uint32)
+            h = _mix32(_mix32(_mix32(bx + np.uint32(seed)) ^ by * np.uint32(0x9E3779B1)) ^ bz * np.uint32(0x85EBCA77))
+            keep.append(np.stack([bx, by, bz, h], axis=1))
+        for start in range(0, 0 if sample else total, chunk):
+            idx = np.arange(start, min(total, start + chunk), dtype=np.uint64)
+            bx = (idx // (nb * nb)).astype(np.uint32)
+            by = ((idx // nb) % nb).astype(np.uint32)
+            bz = (idx % nb).astype(np.uint32)
+            h = _mix32(_mix32(_mix32(bx + np.uint32(seed)) ^ by * np.uint32(0x9E3779B1)) ^ bz * np.uint32(0x85EBCA77))
+            sel = h < thr
+            if sel.any():
+                keep.append(np.stack([bx[sel], by[sel], bz[sel], h[sel]], axis=1))
+        k = np.concatenate(keep) if keep else np.zeros((0, 4), np.uint32)
+        # depth-first key: per level (256-cell, 16-cell, 4-cell) the child index x<<2f | y<<f | z
+        bx, by, bz = (k[:, i].astype(np.uint64) for i in range(3))
+
+        def lv(v, shift, bits):
+            return (v >> np.uint64(shift)) & np.uint64((1 << bits) - 1)
+        key = np.zeros(len(k), np.uint64)
+        for shift, bits in ((6, 4), (2, 4), (0, 2)) if extent_log2 == 12 else ((2, 4), (0, 2)):
+            key = (key << np.uint64(3 * bits)) | (lv(bx, shift, bits) << np.uint64(2 * bits)) | (lv(by, shift, bits) << np.uint64(bits)) | lv(bz, shift, bits)
+        order = np.argsort(key, kind="stable")
+        k = k[order]
+        hh = k[:, 3]
+        lo = _mix32(hh ^ np.uint32(0xA5A5A5A5))
+        hi = _mix32(hh ^ np.uint32(0x5A5A5A5A))
+        mask = (hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)
+        mask[mask == 0] = 1
+    blocks = np.zeros(len(k), BLOCK_DTYPE)
+    blocks["x"], blocks["y"], blocks["z"] = k[:, 0] * 4, k[:, 1] * 4, k[:, 2] * 4
+    blocks["mask"] = mask
+    counts = np.array([bin(int(m)).count("1") for m in mask], np.uint32) if len(mask) < 200000 else \
+        np.unpackbits(mask.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1).astype(np.uint32)
+    blocks["material_ptr"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32) if len(k) else 0
+    rng = np.random.default_rng(seed)
+    materials = rng.integers(0, 255, int(counts.sum()), dtype=np.uint8)
+    blocks["avg_albedo"] = (hh & np.uint32(0xFFFFFFFC)) | np.uint32(3)
+    return blocks, materials

@@ -1,0 +1,104 @@
+"""The BASELINE.json configurations other than the bench one, as parity-test cases (sized to run in seconds):
+config 1 (teapot, 256x256, CPU) and config 5 (procedural 4096^3 deep tree, hierarchy (4,4,2,2))."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as P
+from dust_amd import _lib as L
+from dust_amd import api, synth
+
+
+def teapot_desc(n=64):
+    desc = P.SceneDesc.from_vox(synth.teapot_scene(n))
+    # examples/castle.rs:287-291 at t = 0: the teapot floats at (0, 200, 0)
+    m = desc.instances[0][1].reshape(3, 4).copy()
+    m[:, 3] += np.array([0.0, 200.0, 0.0], np.float32)
+    desc.instances[0] = (desc.instances[0][0], m.reshape(12))
+    return desc
+
+
+def test_config1_teapot_256_cpu():
+    """BASELINE config 1: teapot stand-in, 256x256, one primary ray per pixel, CPU traversal only."""
+    desc = teapot_desc(64)
+    s = P.oracle_scene(desc)
+    cam = P.camera_for((60.0, 250.0, 70.0), target=(0.0, 200.0, 0.0))
+    w = h = 256
+    a = P.render_oracle(s, cam, P.sky_state(), w, h, L.PASS_PRIMARY, mode=O.ORC_MODE_HIER)
+    hit = np.isfinite(a.depth)
+    assert 0.05 < hit.mean() < 0.9
+    # the semantic definition (closest over all bricks) on a centre crop
+    b = P.render_oracle(s, cam, P.sky_state(), w, h, L.PASS_PRIMARY, mode=O.ORC_MODE_BRUTE, rows=(96, 160))
+    for name in ("albedo", "normal", "depth", "motion", "voxel_id", "denoised"):
+        assert getattr(a, name)[96:160].tobytes() == getattr(b, name)[96:160].tobytes(), name
+
+
+@pytest.mark.gpu
+def test_config1_teapot_gpu_parity():
+    desc = teapot_desc(96)
+    ctx = api.Context(device=0)
+    cam = P.camera_for((60.0, 250.0, 70.0), target=(0.0, 200.0, 0.0))
+    noise5 = synth.stbn_unitvec3_cosine(layers=2)
+    pipe = api.StandardPipeline(ctx, 256, 256)
+    pipe.set_noise(5, noise5)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    pipe.render(P.hip_scene(ctx, desc), cam, sky, passes, frame_index=1, rand=99)
+    g = P.render_oracle(P.oracle_scene(desc), cam, sky, 256, 256, passes, noise5[1], 99)
+    P.assert_parity(P.compare_gbuffers(g, P.read_hip_gbuffer(pipe)))
+
+
+def deep_desc(occupancy):
+    blocks, mats = synth.procedural_deep_blocks(occupancy=occupancy, sample=True)
+    return blocks, mats, synth.make_palette(5)
+
+
+def test_config5_deep_tree_oracle_modes_agree():
+    blocks, mats, pal = deep_desc(3e-6)
+    assert 1500 < len(blocks) < 6000
+    s = O.Scene()
+    s.add_model(blocks, mats, pal, extent=4096)
+    s.add_instance(0, np.eye(3, 4, dtype=np.float32).reshape(12))
+    s.commit()
+    rng = np.random.default_rng(1)
+    hits = 0
+    for i in range(300):
+        o = rng.uniform(-500, 4600, 3)
+        tgt = blocks[int(rng.integers(0, len(blocks)))]
+        d = np.array([tgt["x"], tgt["y"], tgt["z"]], np.float64) + rng.uniform(0, 4, 3) - o
+        if i % 3 == 0:
+            d /= np.linalg.norm(d)
+        a = s.trace(O.ORC_MODE_BRUTE, 0, 0, o, d, 0.1, 10000.0)
+        b = s.trace(O.ORC_MODE_HIER, 0, 0, o, d, 0.1, 10000.0)
+        assert a == b, (i, o, d, a, b)
+        hits += a is not None
+    assert hits > 100
+
+
+@pytest.mark.gpu
+def test_config5_deep_tree_gpu_parity():
+    """hierarchy (4,4,2,2): root 16^3 in LDS, 16^3 level-2 nodes and 4^3 mid nodes in memory."""
+    blocks, mats, pal = deep_desc(1e-4)
+    assert len(blocks) > 50000
+    ctx = api.Context(device=0)
+    model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
+    scene = api.Scene(ctx)
+    xf = np.eye(3, 4, dtype=np.float32)
+    xf[:, 3] = (-2048.0, -2048.0, -2048.0)
+    scene.add_instance(model, xf.reshape(12))
+    scene.commit()
+    os_ = O.Scene()
+    os_.add_model(blocks, mats, pal, extent=4096)
+    os_.add_instance(0, xf.reshape(12))
+    os_.commit()
+    noise5 = synth.stbn_unitvec3_cosine(layers=2)
+    sky = P.sky_state()
+    for eye in ((2600.0, 1900.0, 2300.0), (300.0, 200.0, -150.0)):   # outside on the bounding sphere, and inside the volume
+        cam = P.camera_for(eye)
+        pipe = api.StandardPipeline(ctx, 160, 100)
+        pipe.set_noise(5, noise5)
+        passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+        pipe.render(scene, cam, sky, passes, frame_index=1, rand=5)
+        g = P.render_oracle(os_, cam, sky, 160, 100, passes, noise5[1], 5)
+        P.assert_parity(P.compare_gbuffers(g, P.read_hip_gbuffer(pipe)))
+        assert np.isfinite(g.depth).mean() > 0.05
