@@ -725,7 +725,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.accum_count = p->accum_count;
   if (const char* env = std::getenv("DUST_HIP_DEBUG")) a.debug = uint32_t(std::strtoul(env, nullptr, 10));
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
-  const uint32_t block = 512;
+  uint32_t block = 512;
+  if (const char* env = std::getenv("DUST_HIP_BLOCK")) block = uint32_t(std::strtoul(env, nullptr, 10));
   uint32_t bpc = 2;
   if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
   const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 32;

@@ -185,7 +185,7 @@ __device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, float& t_min, float
 // RT 0: primary/hit.rint:43-131. RT 1: ambient_occlusion.rint:46-134. RT 2,3: rough.rint:42-59.
 // o is brick-local (objOrigin - block.position). Returns true when reportIntersectionEXT is reached.
 template <int RT>
-__device__ bool brick_intersect(V3 o, V3 d, uint32_t m1, uint32_t m2, float tmin, float& t_out, uint32_t& voxel) {
+__device__ bool brick_intersect(V3 o, V3 d, V3 tc, uint32_t m1, uint32_t m2, float tmin, float& t_out, uint32_t& voxel) {
   float t0, t1;
   intersect_aabb04(o, d, t0, t1);
   if (t0 >= t1) return false;
@@ -206,7 +206,7 @@ __device__ bool brick_intersect(V3 o, V3 d, uint32_t m1, uint32_t m2, float tmin
   int px = f2i_clamp(floorf(o.x + d.x * hd), 0, 3), py = f2i_clamp(floorf(o.y + d.y * hd), 0, 3),
       pz = f2i_clamp(floorf(o.z + d.z * hd), 0, 3);
   V3 st = mk(gsign(d.x), gsign(d.y), gsign(d.z));
-  V3 tc = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  // tc = 1.0 / dir (hit.rint:88), hoisted: dir is the same for every brick of an instance
   V3 tb = mk(tc.x * o.x, tc.y * o.y, tc.z * o.z);
   V3 tm = mk(((float)px + fmaxf(st.x, 0.0f)) * tc.x - tb.x, ((float)py + fmaxf(st.y, 0.0f)) * tc.y - tb.y,
              ((float)pz + fmaxf(st.z, 0.0f)) * tc.z - tb.z);
@@ -326,12 +326,12 @@ __device__ __forceinline__ uint32_t resolve_block(const DevModel& m, uint32_t ke
 // (tmin <= t <= current tmax; equal t: lower (instance, block) wins -- see oracle/shade.c header)
 template <int RT, bool COUNT>
 __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_t key, int bx, int by, int bz, V3 o,
-                                           V3 d, float tmin, float tmax, Hit& best, LaneStats& st) {
+                                           V3 d, V3 inv_d, float tmin, float tmax, Hit& best, LaneStats& st) {
   V3 ol = mk(o.x - (float)bx, o.y - (float)by, o.z - (float)bz);  // hit.rint:137-140
   float t;
   uint32_t vox;
   if (COUNT) st.bricks_tested += 1;
-  if (!brick_intersect<RT>(ol, d, (uint32_t)mask, (uint32_t)(mask >> 32), tmin, t, vox)) return;
+  if (!brick_intersect<RT>(ol, d, inv_d, (uint32_t)mask, (uint32_t)(mask >> 32), tmin, t, vox)) return;
   const float cur = best.found ? best.t : tmax;
   if (!(t >= tmin && t <= cur)) return;
   if (best.found && t == best.t) {
@@ -392,35 +392,47 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
       {
         uint32_t cl2, key;
         const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
-        if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
+        if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
         if (pending != 0) continue;
       }
     }
     if (is_main) {
       uint32_t key;
       const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, key, mc, st, true);
-      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, tmin, tmax, best, st);
-      // which brick planes is the entry point within delta of?
-      near_neg = 0; near_pos = 0;
-      uint32_t unstepped_near = 0;
+      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      // Which further brick planes is the entry point within delta of? Cheap screen first: the distance of p to
+      // the nearest multiple of 4 on the axes that did not step (a superset of the exact test below), and exact
+      // ties on exit (more than one axis stepped). Almost every step ends here.
+      bool screen = __popc(stepped) > 1;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float p = oo[a] + dd[a] * t;
-        const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
-        const float q = p - (float)(ijk[a] & ~3);
-        const int b0 = ijk[a] & ~3;
-        // a plane only matters if bricks can exist on its far side
-        if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo[a]) near_neg |= 1u << a; } else if (b0 + 4 <= bhi[a]) near_pos |= 1u << a; }
-        else if (q <= delta) { if (b0 - 1 >= blo[a]) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
-        else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi[a]) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+        const float r = p * 0.25f;
+        const float f = fabsf(r - rintf(r));
+        if (!(stepped & (1u << a)) && f <= 2.6e-7f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f)) screen = true;
       }
-      const uint32_t nearm = near_neg | near_pos;
-      if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
-        pending = 0;
+      near_neg = 0; near_pos = 0;
+      if (screen) {
+        uint32_t unstepped_near = 0;
 #pragma unroll
-        for (uint32_t sub = 1; sub < 8; ++sub)
-          if ((sub & ~nearm) == 0 && !(stepped != 0 && sub == stepped)) pending |= 1u << (sub - 1);  // sub == stepped: the cell we came from
-        if (pending != 0) continue;
+        for (int a = 0; a < 3; ++a) {
+          const float p = oo[a] + dd[a] * t;
+          const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
+          const float q = p - (float)(ijk[a] & ~3);
+          const int b0 = ijk[a] & ~3;
+          // a plane only matters if bricks can exist on its far side
+          if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo[a]) near_neg |= 1u << a; } else if (b0 + 4 <= bhi[a]) near_pos |= 1u << a; }
+          else if (q <= delta) { if (b0 - 1 >= blo[a]) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
+          else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi[a]) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+        }
+        const uint32_t nearm = near_neg | near_pos;
+        if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
+          pending = 0;
+#pragma unroll
+          for (uint32_t sub = 1; sub < 8; ++sub)
+            if ((sub & ~nearm) == 0 && !(stepped != 0 && sub == stepped)) pending |= 1u << (sub - 1);  // sub == stepped: the cell we came from
+          if (pending != 0) continue;
+        }
       }
     }
     // leave the cell of size 2^cl_main that contains ijk
@@ -489,12 +501,14 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
   for (uint32_t base = 0; base < a.n_instances; base += 64) {
     const uint32_t i = base + lane;
     bool pass = false;
+    float t_lo = 0.0f;
     float wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
     if (i < a.n_instances) {
       const DevInstance& in = a.instances[i];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { wlo[k] = in.wmin[k]; whi[k] = in.wmax[k]; }
-      float t_lo = 0.0f, t_hi = T;
+      float t_hi = T;
+      t_lo = 0.0f;
       pass = true;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -515,13 +529,30 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
       const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
       if (pos < kMaxCand) {  // box + id travel with the candidate: the per-ray loop reads them with two ds_read_b128
         cand[pos * 2] = make_float4(wlo[0], wlo[1], wlo[2], __uint_as_float(i));
-        cand[pos * 2 + 1] = make_float4(whi[0], whi[1], whi[2], 0.0f);
+        cand[pos * 2 + 1] = make_float4(whi[0], whi[1], whi[2], t_lo);  // .w: earliest entry of any ray of the packet
       }
     }
     n += (uint32_t)__popcll(bal);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  // Front-to-back order: rank the survivors by the packet's earliest entry time (ties by instance id), so that rays
+  // which hit a near instance skip the far ones (te > best.t). Results do not depend on the order (deterministic
+  // tie-break in test_brick); only the amount of work does.
+  if (n > 1 && n <= kMaxCand) {
+    float4 c0 = make_float4(0, 0, 0, 0), c1 = make_float4(0, 0, 0, 0);
+    uint32_t rank = 0;
+    if (lane < n) { c0 = cand[lane * 2]; c1 = cand[lane * 2 + 1]; }
+    for (uint32_t k = 0; k < n; ++k) {
+      const float tk = cand[k * 2 + 1].w;  // LDS broadcast
+      rank += (tk < c1.w || (tk == c1.w && k < lane)) ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) { cand[rank * 2] = c0; cand[rank * 2 + 1] = c1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   return n;
 }
 
