@@ -91,15 +91,15 @@ def test_castle_standin_parity_and_stats(ctx, noise5):
     P.assert_parity(P.compare_gbuffers(g, hip))
     assert np.isfinite(g.depth).mean() > 0.5
     # algorithmic-bytes accounting: the counting build of the kernels issues the same rays and finds the same hits as
-    # the oracle; it visits instances front to back per packet (the oracle walks them in index order), so it may
-    # only do LESS traversal work than the oracle's count, never more, and never less than one brick per hit.
+    # the oracle; it visits instances front to back per packet (the oracle walks them in index order), so closest-hit
+    # rays do less traversal work than the oracle counts and any-hit rays about the same (a different first hit).
     for i in range(3):
         st = pipe.pass_stats(i)
         o = ostats[i]
         assert st.rays == o.rays and st.hits == o.hits, (i, st.rays, o.rays, st.hits, o.hits)
-        assert st.hits <= st.bricks_tested <= o.bricks_tested, (i, st.hits, st.bricks_tested, o.bricks_tested)
-        assert st.mid_descents <= o.mid_descents and st.upper_descents <= o.upper_descents
-        assert st.instances_tested <= o.instances_tested
+        assert st.hits <= st.bricks_tested <= o.bricks_tested * 1.02 + 8, (i, st.hits, st.bricks_tested, o.bricks_tested)
+        assert st.mid_descents <= o.mid_descents * 1.02 + 8 and st.upper_descents <= o.upper_descents * 1.02 + 8
+        assert st.instances_tested <= o.instances_tested * 1.02 + 8
 
 
 def test_row_bands_equal_full_frame(ctx, noise5):
