@@ -19,6 +19,7 @@
 namespace dust {
 hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
@@ -137,6 +138,7 @@ struct DustHipPipeline {
   bool slot_used[kArgSlots] = {};
   int next_slot = 0;
   bool stats_valid = false;
+  bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
   dust::DevStats host_stats[8] = {};
 };
 
@@ -744,7 +746,21 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.gi.requests = static_cast<dust::DevHashRequest*>(p->gi_requests.p);
   a.gi.replacement = static_cast<dust::DevSurfel*>(p->gi_replacement.p);
   if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 8 * sizeof(dust::DevStats), st));
-  if (fp->passes & DUST_PASS_PRIMARY) {
+  // primary + AO in one launch unless told otherwise (DUST_HIP_NO_FUSE=1 keeps the reference's one-launch-per-pass shape)
+  const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !std::getenv("DUST_HIP_NO_FUSE");
+  p->fused_last = fuse;
+  if (fuse) {
+    a.work_counters = static_cast<uint32_t*>(p->counters.p);
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    a.stats = static_cast<dust::DevStats*>(p->stats.p);
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
+    const dust::FrameArgs* d = nullptr;
+    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_primary_ao(a, d, grid, block, count, st));
+    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
+  }
+  if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p);
     HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
@@ -755,7 +771,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
-  if (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) {
+  if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p) + 8 * dust::kCounterStride;
     HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;

@@ -683,7 +683,113 @@ __device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, ui
 }  // namespace
 
 // ==================================================================== primary visibility
-// primary.rgen:8-22 + hit.rint + hit.rchit:16-95 + miss.rmiss:7-17
+// primary.rgen:8-22 + hit.rint + hit.rchit:16-95 + miss.rmiss:7-17 for one packet. Returns, per lane, what the later
+// passes read back from the G-buffer: the hit distance (INFINITY on a miss) and the packed normal texel.
+// store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
+// occlusion pass overwrites the texel of every hit pixel anyway.
+template <bool COUNT>
+__device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet& p, float4* cand, LaneStats& st,
+                                               bool store_illuminance, float& hitT, uint32_t& normal_packed) {
+  const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
+  const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+  const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, p.valid, o, d, a.cam.far_, cand);
+  Hit h;
+  h.found = false;
+  if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
+  __builtin_amdgcn_wave_barrier();
+  hitT = INFINITY;
+  normal_packed = 0;
+  if (!p.valid) return;
+  const size_t pix = (size_t)p.py * a.width + p.px;
+  if (!h.found) {
+    const V3 dir = normalize3(d);
+    const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
+    store_radiance(a.g.denoised, pix, mk((s0.x + s1.x) / 3.14f, (s0.y + s1.y) / 3.14f, (s0.z + s1.z) / 3.14f), 100000.0f);
+    a.g.albedo[pix] = 0xFFFFFFFFu;
+    a.g.depth[pix] = INFINITY;
+    store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+  const DevInstance& in = a.instances[h.inst];
+  const DevModel& m = a.models[in.model];
+  const uint32_t block = resolve_block(m, h.block);
+  const DustHipBlock b = m.blocks[block];
+  const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
+  const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
+  const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
+  const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
+  const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
+  const V3 nw = xform_dir(in.o2w, no);
+  if (store_illuminance) store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+  const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
+  const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
+  const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
+  const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
+  const uint32_t pal = m.materials[b.material_ptr + voff];
+  const uint32_t col = m.palette[pal];
+  a.g.albedo[pix] = pack_rgb10a2((float)(col & 255u) / 255.0f, (float)((col >> 8) & 255u) / 255.0f,
+                                 (float)((col >> 16) & 255u) / 255.0f, 1.0f);
+  a.g.depth[pix] = h.t;
+  hitT = h.t;
+  normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
+  a.g.normal[pix] = normal_packed;
+  a.g.voxel_id[pix] = (h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16);
+  const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
+  const V3 hpm = xform_point(in.w2o, hpw);
+  const float* P = in.prev;
+  const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
+  const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
+  const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
+  const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
+  store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
+}
+
+// ==================================================================== sun shadow + ambient occlusion
+// ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
+// hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
+template <bool COUNT>
+__device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, float4* cand, LaneStats& st_sun, LaneStats& st_ao,
+                                          float hitT, uint32_t normal_packed, V3 payload) {
+  const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
+  const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
+  const bool live = p.valid && !(hitT == INFINITY);
+  V3 n = mk(0, 0, 1), loc = mk(0, 0, 0), ad = mk(0, 0, 1);
+  if (live) {
+    n = nrd_unpack_normal(normal_packed);
+    const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+    loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
+             (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+    const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
+    const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
+    V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
+               (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+    ad = normalize3(rotate_by_normal(n, ns));
+  }
+  // two rays per pixel through the same code: k = 0 the sun shadow ray (any-hit, ambient_occlusion.rgen:33-50),
+  // k = 1 the ambient occlusion ray (closest hit within 8 units, ambient_occlusion.rgen:52-65)
+  const bool sun_live = live && dot3(sun, n) > 0.0f;
+  const V3 sd = normalize3(sun);
+  Hit h;
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const bool act = k == 0 ? sun_live : live;
+    const V3 dir = k == 0 ? sd : ad;
+    const float tmax = k == 0 ? 10000.0f : 8.0f;
+    const uint32_t ncand = cull_instances(a, act, loc, dir, tmax, cand);
+    LaneStats cur = {0, 0, 0, 0, 0, 0};
+    trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
+    if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
+    __builtin_amdgcn_wave_barrier();
+    if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22
+      const V3 sr = sun_radiance(a.sky, normalize3(sd));
+      const float kk = 1.0f - cosf(a.sky[55]);
+      const float dn = dot3(n, sd);
+      payload.x += (sr.x * kk) * dn; payload.y += (sr.y * kk) * dn; payload.z += (sr.z * kk) * dn;
+    }
+  }
+  if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
@@ -693,60 +799,13 @@ __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict_
   WorkCursor wc = {0, 0, 0};
   Packet p;
   while (next_packet(a, wc, p)) {
-    const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
-    const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
-    const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, p.valid, o, d, a.cam.far_, cand);
-    Hit h;
-    h.found = false;
-    if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
-    __builtin_amdgcn_wave_barrier();
-    if (!p.valid) continue;
-    const size_t pix = (size_t)p.py * a.width + p.px;
-    if (!h.found) {
-      const V3 dir = normalize3(d);
-      const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
-      store_radiance(a.g.denoised, pix, mk((s0.x + s1.x) / 3.14f, (s0.y + s1.y) / 3.14f, (s0.z + s1.z) / 3.14f), 100000.0f);
-      a.g.albedo[pix] = 0xFFFFFFFFu;
-      a.g.depth[pix] = INFINITY;
-      store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
-      continue;
-    }
-    const DevInstance& in = a.instances[h.inst];
-    const DevModel& m = a.models[in.model];
-    const uint32_t block = resolve_block(m, h.block);
-    const DustHipBlock b = m.blocks[block];
-    const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
-    const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
-    const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
-    const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
-    const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
-    const V3 nw = xform_dir(in.o2w, no);
-    store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
-    const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
-    const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
-    const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
-    const uint32_t pal = m.materials[b.material_ptr + voff];
-    const uint32_t col = m.palette[pal];
-    a.g.albedo[pix] = pack_rgb10a2((float)(col & 255u) / 255.0f, (float)((col >> 8) & 255u) / 255.0f,
-                                   (float)((col >> 16) & 255u) / 255.0f, 1.0f);
-    a.g.depth[pix] = h.t;
-    a.g.normal[pix] = nrd_pack_normal(nw, 1.0f, (float)pal);
-    a.g.voxel_id[pix] = (h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16);
-    const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
-    const V3 hpm = xform_point(in.w2o, hpw);
-    const float* P = in.prev;
-    const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
-    const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
-    const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
-    const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
-    store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
+    float hitT;
+    uint32_t npk;
+    primary_packet<COUNT>(a, p, cand, st, true, hitT, npk);
   }
   flush_stats<COUNT>(a, 0, st);
 }
 
-// ==================================================================== sun shadow + ambient occlusion
-// ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
@@ -755,51 +814,43 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* _
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
-  const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   while (next_packet(a, wc, p)) {
     const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
     const float hitT = p.valid ? a.g.depth[pix] : INFINITY;
-    const bool live = p.valid && !(hitT == INFINITY);
-    V3 n = mk(0, 0, 1), loc = mk(0, 0, 0), payload = mk(0, 0, 0), ad = mk(0, 0, 1);
-    if (live) {
-      n = nrd_unpack_normal(a.g.normal[pix]);
-      const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
-      loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
-               (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+    uint32_t npk = 0;
+    V3 payload = mk(0, 0, 0);
+    if (p.valid && !(hitT == INFINITY)) {
+      npk = a.g.normal[pix];
       float w;
       payload = load_radiance(a.g.illuminance, pix, w);
-      const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
-      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
-      V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
-                 (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
-      ad = normalize3(rotate_by_normal(n, ns));
     }
-    // two rays per pixel through the same code: k = 0 the sun shadow ray (any-hit, ambient_occlusion.rgen:33-50),
-    // k = 1 the ambient occlusion ray (closest hit within 8 units, ambient_occlusion.rgen:52-65)
-    const bool sun_live = live && dot3(sun, n) > 0.0f;
-    const V3 sd = normalize3(sun);
-    Hit h;
-#pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-      const bool act = k == 0 ? sun_live : live;
-      const V3 dir = k == 0 ? sd : ad;
-      const float tmax = k == 0 ? 10000.0f : 8.0f;
-      const uint32_t ncand = cull_instances(a, act, loc, dir, tmax, cand);
-      LaneStats cur = {0, 0, 0, 0, 0, 0};
-      trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
-      if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
-      __builtin_amdgcn_wave_barrier();
-      if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22
-        const V3 sr = sun_radiance(a.sky, normalize3(sd));
-        const float kk = 1.0f - cosf(a.sky[55]);
-        const float dn = dot3(n, sd);
-        payload.x += (sr.x * kk) * dn; payload.y += (sr.y * kk) * dn; payload.z += (sr.z * kk) * dn;
-      }
-    }
-    if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
+    ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, payload);
   }
   flush_stats<COUNT>(a, 0, st_sun);
   flush_stats<COUNT>(a, 1, st_ao);
+}
+
+// Fused primary + ambient occlusion passes: a pixel's AO pass reads only that pixel's own primary outputs, so the
+// wave that traced a packet's primary rays goes straight on to its shadow and AO rays with depth and normal still
+// in registers (as the quantised values the separate pass would load back). One launch, one LDS staging and one
+// work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
+template <bool COUNT>
+__global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs* __restrict__ ap) {
+  const FrameArgs& a = *ap;
+  stage_roots(a);
+  float4* cand = wave_cand_list(a);
+  LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = {0, 0, 0};
+  Packet p;
+  while (next_packet(a, wc, p)) {
+    float hitT;
+    uint32_t npk;
+    primary_packet<COUNT>(a, p, cand, st, false, hitT, npk);
+    ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
+  }
+  flush_stats<COUNT>(a, 0, st);
+  flush_stats<COUNT>(a, 1, st_sun);
+  flush_stats<COUNT>(a, 2, st_ao);
 }
 
 // ==================================================================== spatial hash (headers/spatial_hash.glsl)
@@ -1176,6 +1227,12 @@ hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t 
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, dev);
   return hipGetLastError();
 }
+hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(host, block);
+  if (count) hipLaunchKernelGGL(k_primary_ao<true>, dim3(grid), dim3(block), lds, s, dev);
+  else hipLaunchKernelGGL(k_primary_ao<false>, dim3(grid), dim3(block), lds, s, dev);
+  return hipGetLastError();
+}
 hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(host, block);
   if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, dev);
@@ -1205,6 +1262,7 @@ hipError_t configure_kernels(size_t max_lds) {
   hipError_t e;
   const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
                        (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>,
+                       (const void*)k_primary_ao<false>, (const void*)k_primary_ao<true>,
                        (const void*)k_final_gather<false>, (const void*)k_final_gather<true>,
                        (const void*)k_surfel_trace<false>, (const void*)k_surfel_trace<true>};
   for (const void* f : fns) {

@@ -222,7 +222,9 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const
  * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
-/* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays */
+/* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
+ * When primary and AO passes are requested together they run as ONE fused kernel: its time is reported under
+ * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
 DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline*, DustHipPlane, void** ptr, size_t* bytes);
 /* synchronous device-to-host copy of one plane */

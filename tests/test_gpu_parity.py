@@ -123,6 +123,28 @@ def test_row_bands_equal_full_frame(ctx, noise5):
         assert ref[k].tobytes() == got[k].tobytes(), k
 
 
+def test_fused_and_separate_launches_agree(ctx, noise5, monkeypatch):
+    """primary + AO run as one fused kernel by default; launched separately (as the reference's two trace calls)
+    they must leave bit-identical planes."""
+    desc = P.small_scene(seed=11)
+    sky = P.sky_state()
+    cam = P.camera_for((60.0, 90.0, 100.0))
+    scene = P.hip_scene(ctx, desc)
+    outs = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("DUST_HIP_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("DUST_HIP_NO_FUSE", raising=False)
+        pipe = api.StandardPipeline(ctx, 150, 90)
+        pipe.set_noise(5, noise5)
+        pipe.render(scene, cam, sky, L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION, frame_index=2, rand=31)
+        outs.append(P.read_hip_gbuffer(pipe))
+    monkeypatch.delenv("DUST_HIP_NO_FUSE", raising=False)
+    for k in outs[0]:
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
 def test_repeatable(ctx, noise5):
     desc = P.small_scene(seed=8)
     sky = P.sky_state()
