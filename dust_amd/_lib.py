@@ -28,8 +28,8 @@ PASS_COUNT_STATS = 1 << 16
 PASS_GI_ORDERED = 1 << 17
 CONTEXT_TIMING = 1
 
-PLANE_ILLUMINANCE, PLANE_DENOISED, PLANE_ALBEDO, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOTION, PLANE_VOXEL_ID, PLANE_ACCUM = range(8)
-PLANE_BYTES_PER_PIXEL = (8, 8, 4, 4, 4, 8, 4, 16)
+PLANE_ILLUMINANCE, PLANE_DENOISED, PLANE_ALBEDO, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOTION, PLANE_VOXEL_ID, PLANE_ACCUM, PLANE_OUTPUT = range(9)
+PLANE_BYTES_PER_PIXEL = (8, 8, 4, 4, 4, 8, 4, 16, 8)
 
 
 class Block(C.Structure):  # DustHipBlock, 24 bytes
@@ -63,6 +63,11 @@ class Sky(C.Structure):
 class FrameParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("passes", C.c_uint32), ("frame_index", C.c_uint32),
                 ("rand", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
+
+
+class ToneMapParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("transfer_function", C.c_uint32), ("color_space_conversion", C.c_float * 9),
+                ("min_log_luminance", C.c_float), ("max_log_luminance", C.c_float), ("time_coefficient", C.c_float)]
 
 
 class PassStats(C.Structure):
@@ -127,6 +132,8 @@ SYMBOLS = {
     "dust_hip_pipeline_read_plane": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "dust_hip_pipeline_configure_gi": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "dust_hip_pipeline_read_gi": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
+    "dust_hip_tone_map": (C.c_int, [_P, C.POINTER(ToneMapParams)]),
+    "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
 }
 

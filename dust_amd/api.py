@@ -20,7 +20,7 @@ SURFEL_DTYPE = np.dtype([("pos", "<f4", 3), ("direction", "<u4")])
 PLANE_DTYPES = {
     L.PLANE_ILLUMINANCE: (np.uint16, 4), L.PLANE_DENOISED: (np.uint16, 4), L.PLANE_ALBEDO: (np.uint32, 1),
     L.PLANE_NORMAL: (np.uint32, 1), L.PLANE_DEPTH: (np.float32, 1), L.PLANE_MOTION: (np.uint16, 4),
-    L.PLANE_VOXEL_ID: (np.uint32, 1), L.PLANE_ACCUM: (np.float32, 4),
+    L.PLANE_VOXEL_ID: (np.uint32, 1), L.PLANE_ACCUM: (np.float32, 4), L.PLANE_OUTPUT: (np.uint16, 4),
 }
 
 
@@ -197,6 +197,29 @@ def make_camera(eye, rotation_cols, projection: PinholeProjection):
     return cam
 
 
+# ColorSpacePrimaries (rhyolite/src/utils/format.rs:573-641): r, g, b, white point chromaticities
+BT709 = ((0.64, 0.33), (0.3, 0.6), (0.15, 0.06), (0.3127, 0.3290))
+ACES_AP1 = ((0.713, 0.293), (0.165, 0.830), (0.128, 0.044), (0.32168, 0.33767))
+DCI_P3 = ((0.68, 0.32), (0.265, 0.69), (0.15, 0.06), (0.3127, 0.3290))
+
+
+def primaries_to_xyz(p):
+    """ColorSpacePrimaries::to_xyz (format.rs:651-664)."""
+    x = np.array([p[0][0], p[1][0], p[2][0], p[3][0]], np.float64)
+    y = np.array([p[0][1], p[1][1], p[2][1], p[3][1]], np.float64)
+    X, Z = x / y, (1.0 - x - y) / y
+    mat = np.stack([X[:3], np.ones(3), Z[:3]])          # rows X, Y, Z; columns r, g, b
+    s = np.linalg.solve(mat, np.array([X[3], 1.0, Z[3]]))
+    return mat * s[None, :]
+
+
+def color_space_conversion(src=ACES_AP1, dst=BT709):
+    """ColorSpacePrimaries::to_color_space (format.rs:666-679), no chromatic adaptation; returned column-major
+    as the nine COLOR_SPACE_CONVERSION_* specialization constants of tone_map.comp."""
+    m = np.linalg.inv(primaries_to_xyz(dst)) @ primaries_to_xyz(src)
+    return m.T.reshape(9).astype(np.float32)
+
+
 class Context:
     def __init__(self, device=-1, timing=True, stream=None, lds_root_bytes=0):
         self._lib = L.load()
@@ -309,6 +332,21 @@ class StandardPipeline:
 
     def clear(self):
         L.check(self._lib.dust_hip_pipeline_clear(self._h))
+
+    def tone_map(self, transfer_function=1, conversion=None, min_log=-6.0, max_log=8.5, time_coefficient=0.2):
+        """AutoExposurePipeline + ToneMappingPipeline on the denoised plane -> PLANE_OUTPUT."""
+        tp = L.ToneMapParams()
+        tp.struct_size = C.sizeof(L.ToneMapParams)
+        tp.transfer_function = transfer_function
+        tp.color_space_conversion[:] = (color_space_conversion() if conversion is None else np.asarray(conversion, np.float32)).tolist()
+        tp.min_log_luminance, tp.max_log_luminance, tp.time_coefficient = min_log, max_log, time_coefficient
+        L.check(self._lib.dust_hip_tone_map(self._h, C.byref(tp)))
+
+    def exposure(self, set_to=None):
+        out = C.c_float()
+        s = None if set_to is None else C.byref(C.c_float(set_to))
+        L.check(self._lib.dust_hip_pipeline_exposure(self._h, C.byref(out), s))
+        return out.value
 
     def configure_gi(self, hash_capacity=32 * 1024 * 1024, surfel_pool_size=720 * 480):
         self._gi = (hash_capacity, surfel_pool_size)

@@ -23,6 +23,8 @@ hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32
 hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
+hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
+                           float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
 }  // namespace dust
 
@@ -123,6 +125,7 @@ struct DustHipPipeline {
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   DeviceBuffer noise0, noise5, counters, stats;
+  DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
@@ -142,7 +145,7 @@ struct DustHipPipeline {
   dust::DevStats host_stats[8] = {};
 };
 
-static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16};
+static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
 
 // ------------------------------------------------------------------ device hierarchy build
 namespace {
@@ -638,6 +641,8 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     }
     HIP_TRY(p->counters.alloc(4 * 8 * dust::kCounterStride * sizeof(uint32_t)));
     HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
+    HIP_TRY(p->exposure.alloc(257 * 4));
+    HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_args), sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots, hipHostMallocDefault));
     HIP_TRY(p->dev_args.alloc(sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots));
@@ -880,6 +885,29 @@ DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* d
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   HIP_TRY(hipMemcpy(dst, b.p, b.bytes, hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+DustStatus dust_hip_tone_map(DustHipPipeline* p, const DustHipToneMapParams* tp) {
+  if (!p || !tp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (tp->transfer_function > 8) return fail(DUST_ERR_INVALID_ARGUMENT, "transfer function must be 0..8");
+  if (!(tp->max_log_luminance > tp->min_log_luminance)) return fail(DUST_ERR_INVALID_ARGUMENT, "empty luminance range");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  uint32_t* hist = static_cast<uint32_t*>(p->exposure.p);
+  HIP_TRY(dust::launch_tone_map(static_cast<const uint16_t*>(p->planes[DUST_PLANE_DENOISED].p),
+                                static_cast<const uint32_t*>(p->planes[DUST_PLANE_ALBEDO].p),
+                                static_cast<uint16_t*>(p->planes[DUST_PLANE_OUTPUT].p), p->width * p->height, hist,
+                                reinterpret_cast<float*>(hist + 256), tp->min_log_luminance,
+                                tp->max_log_luminance - tp->min_log_luminance, tp->time_coefficient, tp->color_space_conversion,
+                                tp->transfer_function, p->ctx->stream));
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, const float* set_to) {
+  if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  float* avg = reinterpret_cast<float*>(static_cast<uint32_t*>(p->exposure.p) + 256);
+  if (set_to) HIP_TRY(hipMemcpy(avg, set_to, 4, hipMemcpyHostToDevice));
+  if (avg_luminance) HIP_TRY(hipMemcpy(avg_luminance, avg, 4, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {

@@ -1212,7 +1212,115 @@ __global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
     acc.x += (r.x - acc.x) * k; acc.y += (r.y - acc.y) * k; acc.z += (r.z - acc.z) * k;
     acc.w = (float)(a.accum_count + 1u);
     reinterpret_cast<float4*>(a.g.accum)[pix] = acc;
+    // what the denoiser would hand to auto exposure / tone mapping (img_illuminance_denoised, packed YCoCg);
+    // miss pixels already carry the sky there (miss.rmiss:13)
+    if (!miss) store_radiance(a.g.denoised, pix, mk(acc.x, acc.y, acc.z), w);
   }
+}
+
+// ==================================================================== auto exposure + tone map
+// auto_exposure.comp:20-74: 256-bin log2-luminance histogram of the (packed YCoCg) radiance image
+__global__ void __launch_bounds__(256) k_exposure_histogram(const uint16_t* __restrict__ src, uint32_t n_pixels, float min_log,
+                                                            float log_range, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t bins[256];
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += (size_t)gridDim.x * blockDim.x) {
+    float w;
+    const V3 c = load_radiance(src, i, w);
+    const float lum = (c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f;
+    uint32_t bin = 0;
+    if (!(lum < 0.005f)) {
+      const float logLum = gclamp((log2f(lum) - min_log) * (1.0f / log_range), 0.0f, 1.0f);
+      bin = (uint32_t)(logLum * 254.0f + 1.0f);
+    }
+    atomicAdd(&bins[bin], 1u);
+  }
+  __syncthreads();
+  if (bins[threadIdx.x]) atomicAdd(&hist[threadIdx.x], bins[threadIdx.x]);
+}
+// auto_exposure_avg.comp:19-53: weighted bin average -> luminance -> exponential adaptation; clears the histogram
+__global__ void __launch_bounds__(256) k_exposure_average(uint32_t* __restrict__ hist, float* __restrict__ avg, uint32_t n_pixels,
+                                                          float min_log, float log_range, float time_coeff) {
+  __shared__ uint32_t s[256];
+  s[threadIdx.x] = hist[threadIdx.x] * threadIdx.x;
+  __syncthreads();
+  hist[threadIdx.x] = 0;
+  for (uint32_t cutoff = 128; cutoff > 0; cutoff >>= 1) {
+    if (threadIdx.x < cutoff) s[threadIdx.x] += s[threadIdx.x + cutoff];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float num = fmaxf((float)n_pixels, 1.0f);
+    const float weighted_log_avg = ((float)s[0] / num) - 1.0f;
+    const float weighted_avg_lum = exp2f(((weighted_log_avg / 254.0f) * log_range) + min_log);
+    const float last = *avg;
+    *avg = last + (weighted_avg_lum - last) * time_coeff;
+  }
+}
+namespace {
+__device__ __forceinline__ float rrt_odt_fit(float v) {  // tone_map.comp:39-43
+  return (v * (v + 0.0245786f) - 0.000090537f) / (v * (0.983729f * v + 0.4329510f) + 0.238081f);
+}
+__device__ float oetf(uint32_t tf, float c) {  // tone_map.comp:72-181
+  switch (tf) {
+    case 1: return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    case 2: return c <= -0.0031308f ? -1.055f * powf(-c, 1.0f / 2.4f) + 0.055f
+                                    : (c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f);
+    case 3: return powf(c / 52.37f, 1.0f / 2.6f);
+    case 4: return c < 0.0030186f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    case 5: return c < 0.0181f ? 4.5f * c : 1.0993f * powf(c, 0.45f) - (1.0993f - 1.0f);
+    case 6: {
+      const float m1 = 2610.0f / 16384.0f, m2 = (2523.0f / 4096.0f) * 128.0f, c2 = (2413.0f / 4096.0f) * 32.0f,
+                  c3 = (2392.0f / 4096.0f) * 32.0f;
+      const float c1 = c3 - c2 + 1.0f;
+      const float Lm = powf(c, m1);
+      return powf((c1 + c2 * Lm) / (1.0f + c3 * Lm), m2);
+    }
+    case 7: return c < (1.0f / 12.0f) ? sqrtf(3.0f * c) : 0.17883277f * logf(12.0f * c - (1.0f - 4.0f * 0.17883277f)) + 0.55991073f;
+    case 8: return powf(c, 256.0f / 563.0f);
+    default: return c;
+  }
+}
+}  // namespace
+struct ToneMapArgs {
+  const uint16_t* src;
+  const uint32_t* albedo;
+  uint16_t* dst;
+  const float* avg;
+  uint32_t n_pixels, transfer_function;
+  float conv[9];
+};
+// tone_map.comp:184-220: radiance x albedo x exposure -> display primaries -> ACES fit -> OETF
+__global__ void __launch_bounds__(256) k_tone_map(ToneMapArgs t) {
+  const float avg = *t.avg;
+  float exposure = 1.0f / (9.6f * avg);
+  exposure *= 9.6f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n_pixels; i += (size_t)gridDim.x * blockDim.x) {
+    float w;
+    const V3 c = load_radiance(t.src, i, w);
+    const uint32_t ap = t.albedo[i];
+    V3 m = modulate_by_avg_albedo(c, ((ap & 1023u) << 22) | (((ap >> 10) & 1023u) << 12) | (((ap >> 20) & 1023u) << 2));
+    m = mk(m.x * exposure, m.y * exposure, m.z * exposure);
+    m = mk((t.conv[0] * m.x + t.conv[3] * m.y) + t.conv[6] * m.z, (t.conv[1] * m.x + t.conv[4] * m.y) + t.conv[7] * m.z,
+           (t.conv[2] * m.x + t.conv[5] * m.y) + t.conv[8] * m.z);
+    V3 r = mk((m.x * 0.59719f + m.y * 0.35458f) + m.z * 0.04823f, (m.x * 0.07600f + m.y * 0.90834f) + m.z * 0.01566f,
+              (m.x * 0.02840f + m.y * 0.13383f) + m.z * 0.83777f);
+    r = mk(rrt_odt_fit(r.x), rrt_odt_fit(r.y), rrt_odt_fit(r.z));
+    const V3 o = mk((r.x * 1.60475f + r.y * -0.53108f) + r.z * -0.07367f, (r.x * -0.10208f + r.y * 1.10813f) + r.z * -0.00605f,
+                    (r.x * -0.00327f + r.y * -0.07276f) + r.z * 1.07602f);
+    store_half4(t.dst, i, oetf(t.transfer_function, o.x), oetf(t.transfer_function, o.y), oetf(t.transfer_function, o.z), 1.0f);
+  }
+}
+hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
+                           float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s) {
+  hipLaunchKernelGGL(k_exposure_histogram, dim3(1024), dim3(256), 0, s, src, n_pixels, min_log, log_range, hist);
+  hipLaunchKernelGGL(k_exposure_average, dim3(1), dim3(256), 0, s, hist, avg, n_pixels, min_log, log_range, time_coeff);
+  ToneMapArgs t;
+  t.src = src; t.albedo = albedo; t.dst = dst; t.avg = avg; t.n_pixels = n_pixels; t.transfer_function = tf;
+  for (int i = 0; i < 9; ++i) t.conv[i] = conv[i];
+  hipLaunchKernelGGL(k_tone_map, dim3(2048), dim3(256), 0, s, t);
+  return hipGetLastError();
 }
 
 // ==================================================================== launchers (called from capi.cpp)

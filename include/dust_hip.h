@@ -181,7 +181,8 @@ typedef enum DustHipPlane {
   DUST_PLANE_MOTION = 5,      /* RGBA16F, 8 B/px */
   DUST_PLANE_VOXEL_ID = 6,    /* R32UI, 4 B/px */
   DUST_PLANE_ACCUM = 7,       /* RGBA32F, 16 B/px: N-frame mean of unpacked illuminance (stands in for NRD) */
-  DUST_PLANE_COUNT = 8
+  DUST_PLANE_OUTPUT = 8,      /* RGBA16F, 8 B/px: tone-mapped display image (ToneMappingPipeline's dst) */
+  DUST_PLANE_COUNT = 9
 } DustHipPlane;
 
 /* ray types (StandardPipeline::*_RAYTYPE, standard.rs:223-226) double as pass bits */
@@ -235,6 +236,19 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* ds
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline*, uint32_t hash_capacity, uint32_t surfel_pool_size);
 /* synchronous copy of GI state to the host: which = 0 spatial hash ((capacity+2) x 12 B), 1 surfel pool (16 B each) */
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline*, uint32_t which, void* dst, size_t dst_bytes);
+/* AutoExposurePipeline::render + ToneMappingPipeline::render (pipeline/auto_exposure.rs:96-248, tone_mapping.rs:76-200;
+ * auto_exposure.comp, auto_exposure_avg.comp, tone_map.comp): 256-bin log-luminance histogram of the denoised radiance
+ * (after DUST_PASS_ACCUMULATE: the N-frame mean), exponential adaptation of the average, then
+ * radiance x albedo / avg -> display primaries -> ACES fit -> transfer function into DUST_PLANE_OUTPUT. */
+typedef struct DustHipToneMapParams {
+  uint32_t struct_size;
+  uint32_t transfer_function;      /* ColorSpaceTransferFunction 0..8 (rhyolite utils/format.rs:683-693): 0 linear, 1 sRGB, ... */
+  float color_space_conversion[9]; /* COLOR_SPACE_CONVERSION_0..8, column-major: scene (ACES AP1) -> display primaries */
+  float min_log_luminance, max_log_luminance, time_coefficient; /* ExposureSettings (auto_exposure.rs:225-248): -6, 8.5, 0.2 */
+} DustHipToneMapParams;
+DustStatus dust_hip_tone_map(DustHipPipeline*, const DustHipToneMapParams*);
+/* reads (and optionally first overwrites) the adapted average luminance the tone mapper divides by */
+DustStatus dust_hip_pipeline_exposure(DustHipPipeline*, float* avg_luminance, const float* set_to);
 /* zero every plane and the accumulation count */
 DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
 

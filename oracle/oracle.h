@@ -183,6 +183,12 @@ void orc_pass_final_gather(const OrcScene*, int mode, const OrcCamera*, const Or
 void orc_pass_surfel(const OrcScene*, int mode, const OrcSky*, const uint8_t* noise0, const uint8_t* noise5, uint32_t rand,
                      uint32_t frame_index, OrcGI*, OrcRayStats* stats_sun, OrcRayStats* stats_cos);
 
+/* auto exposure + tone map (auto_exposure.comp, auto_exposure_avg.comp, tone_map.comp) */
+void orc_exposure_histogram(const uint16_t* illuminance, uint32_t w, uint32_t h, float min_log, float log_range, uint32_t hist[256]);
+float orc_exposure_average(uint32_t hist[256], uint32_t w, uint32_t h, float min_log, float log_range, float time_coeff, float avg);
+void orc_tone_map(const uint16_t* src, const uint32_t* albedo, uint32_t w, uint32_t h, float avg, const float conv[9], uint32_t tf,
+                  uint16_t* dst);
+
 /* encodings (headers/nrd.glsl, color.glsl, spatial_hash.glsl, normal.glsl) for unit tests */
 uint32_t orc_pack_rgb10a2(const float v[4]);
 void orc_unpack_rgb10a2(uint32_t p, float v[4]);

@@ -1091,3 +1091,78 @@ void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8
   }
   free(req);
 }
+
+
+/* ================================================================== auto exposure + tone map
+ * auto_exposure.comp:20-74, auto_exposure_avg.comp:19-53, tone_map.comp:39-220 */
+static uint32_t color_to_bin(v3 c, float min_log, float log_range) { /* auto_exposure.comp:20-35 */
+  float lum = (c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f;
+  if (lum < 0.005f) return 0;
+  float logLum = gclamp((log2f(lum) - min_log) * (1.0f / log_range), 0.0f, 1.0f);
+  return (uint32_t)(logLum * 254.0f + 1.0f);
+}
+void orc_exposure_histogram(const uint16_t* illuminance, uint32_t w, uint32_t h, float min_log, float log_range, uint32_t hist[256]) {
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    v3 c; float ww;
+    unpack_radiance(illuminance + i * 4, &c, &ww);
+    hist[color_to_bin(c, min_log, log_range)] += 1;
+  }
+}
+float orc_exposure_average(uint32_t hist[256], uint32_t w, uint32_t h, float min_log, float log_range, float time_coeff, float avg) {
+  uint32_t sum = 0; /* uint arithmetic, as histogramShared[] (auto_exposure_avg.comp:24-34) */
+  for (uint32_t i = 0; i < 256; ++i) { sum += hist[i] * i; hist[i] = 0; }
+  float num = fmaxf((float)(w * h), 1.0f);
+  float weighted_log_avg = ((float)sum / num) - 1.0f;
+  float weighted_avg_lum = exp2f(((weighted_log_avg / 254.0f) * log_range) + min_log);
+  return avg + (weighted_avg_lum - avg) * time_coeff;
+}
+static v3 rrt_odt_fit(v3 v) { /* tone_map.comp:39-43 */
+  v3 a = V3(v.x * (v.x + 0.0245786f) - 0.000090537f, v.y * (v.y + 0.0245786f) - 0.000090537f, v.z * (v.z + 0.0245786f) - 0.000090537f);
+  v3 b = V3(v.x * (0.983729f * v.x + 0.4329510f) + 0.238081f, v.y * (0.983729f * v.y + 0.4329510f) + 0.238081f,
+            v.z * (0.983729f * v.z + 0.4329510f) + 0.238081f);
+  return V3(a.x / b.x, a.y / b.y, a.z / b.z);
+}
+static v3 aces_fitted(v3 c) { /* tone_map.comp:45-71; `v *= M` is v * M: dot with the columns */
+  v3 r = V3((c.x * 0.59719f + c.y * 0.35458f) + c.z * 0.04823f, (c.x * 0.07600f + c.y * 0.90834f) + c.z * 0.01566f,
+            (c.x * 0.02840f + c.y * 0.13383f) + c.z * 0.83777f);
+  r = rrt_odt_fit(r);
+  return V3((r.x * 1.60475f + r.y * -0.53108f) + r.z * -0.07367f, (r.x * -0.10208f + r.y * 1.10813f) + r.z * -0.00605f,
+            (r.x * -0.00327f + r.y * -0.07276f) + r.z * 1.07602f);
+}
+static float oetf(uint32_t tf, float c) { /* tone_map.comp:72-181 */
+  switch (tf) {
+    case 1: return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    case 2: return c <= -0.0031308f ? -1.055f * powf(-c, 1.0f / 2.4f) + 0.055f : (c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f);
+    case 3: return powf(c / 52.37f, 1.0f / 2.6f);
+    case 4: return c < 0.0030186f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    case 5: return c < 0.0181f ? 4.5f * c : 1.0993f * powf(c, 0.45f) - (1.0993f - 1.0f);
+    case 6: {
+      const float m1 = 2610.0f / 16384.0f, m2 = (2523.0f / 4096.0f) * 128.0f, c2 = (2413.0f / 4096.0f) * 32.0f, c3 = (2392.0f / 4096.0f) * 32.0f;
+      const float c1 = c3 - c2 + 1.0f;
+      float Lm = powf(c, m1);
+      return powf((c1 + c2 * Lm) / (1.0f + c3 * Lm), m2);
+    }
+    case 7: return c < (1.0f / 12.0f) ? sqrtf(3.0f * c) : 0.17883277f * logf(12.0f * c - (1.0f - 4.0f * 0.17883277f)) + 0.55991073f;
+    case 8: return powf(c, 256.0f / 563.0f);
+    default: return c;
+  }
+}
+/* tone_map.comp:184-220. conv: the nine COLOR_SPACE_CONVERSION_* constants (column-major mat3) */
+void orc_tone_map(const uint16_t* src, const uint32_t* albedo, uint32_t w, uint32_t h, float avg, const float conv[9], uint32_t tf,
+                  uint16_t* dst) {
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    v3 c; float ww, al[4];
+    unpack_radiance(src + i * 4, &c, &ww);
+    orc_unpack_rgb10a2(albedo[i], al);
+    v3 alb = V3(srgb_to_linear(al[0]), srgb_to_linear(al[1]), srgb_to_linear(al[2]));
+    float exposure = 1.0f / (9.6f * avg);
+    exposure *= 9.6f;
+    v3 s = mat3_mul(M_ACEScg2sRGB, c);
+    v3 m = mat3_mul(M_sRGB2ACEScg, V3(s.x * alb.x, s.y * alb.y, s.z * alb.z));
+    m = V3(m.x * exposure, m.y * exposure, m.z * exposure);
+    m = mat3_mul(conv, m);
+    m = aces_fitted(m);
+    dst[i * 4 + 0] = orc_f32_to_f16(oetf(tf, m.x)); dst[i * 4 + 1] = orc_f32_to_f16(oetf(tf, m.y));
+    dst[i * 4 + 2] = orc_f32_to_f16(oetf(tf, m.z)); dst[i * 4 + 3] = orc_f32_to_f16(1.0f);
+  }
+}

@@ -117,6 +117,10 @@ def lib():
                                             C.POINTER(OrcRayStats)]
         l.orc_pass_surfel.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcSky), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.POINTER(OrcRayStats), C.POINTER(OrcRayStats)]
+        l.orc_exposure_histogram.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        l.orc_exposure_average.restype = C.c_float
+        l.orc_exposure_average.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]
+        l.orc_tone_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
         l.orc_pack_rgb10a2.restype = C.c_uint32
         l.orc_pack_rgb10a2.argtypes = [C.POINTER(C.c_float)]
         l.orc_unpack_rgb10a2.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
