@@ -246,19 +246,19 @@ def castle_scene(seed=0xD057, scale=1.0):
     towers = [add_model(model_tower(s(64 + 8 * k), s(200 - 10 * k), rng, stone + dark, wall=s(5, 2))) for k in range(4)]
     for k, (x, y) in enumerate(((384, 384), (-384, 384), (384, -384), (-384, -384), (128, 384), (-128, -384))):
         place(towers[k % 4], x, y, (200 - 10 * (k % 4)) / 2.0)
-    # keep: hollow box 200 x 200 x 220 with crenellations and windows
-    keep = add_model(model_box((s(200), s(200), s(220)), rng, stone, shell=s(6, 2), crenel=s(8), windows=12))
-    place(keep, 0, 0, 110)
-    keep_top = add_model(model_box((s(120), s(120), s(60)), rng, stone + roof, shell=s(5, 2), crenel=s(6)))
-    place(keep_top, 0, 0, 250, ROT_Z90)
+    # keep: hollow box 140 x 140 x 110 with crenellations and windows, a smaller turret on top
+    keep = add_model(model_box((s(140), s(140), s(110)), rng, stone, shell=s(6, 2), crenel=s(8), windows=12))
+    place(keep, 0, 0, 55)
+    keep_top = add_model(model_box((s(72), s(72), s(40)), rng, stone + roof, shell=s(5, 2), crenel=s(6)))
+    place(keep_top, 0, 0, 130, ROT_Z90)
     # stairs up to the keep
     st = s(96)
     stairs = np.zeros((st, s(48), s(64)), bool)
     for i in range(st):
         stairs[i, :, : max(1, int((i + 1) * s(64) / st))] = True
     stairs_m = add_model(((st, s(48), s(64)), _grid_to_xyzi(stairs, _colour_field(stairs.shape, rng, stone))))
-    place(stairs_m, -148, 0, 32)
-    place(stairs_m, 148, 0, 32, ROT_MIRROR_X)
+    place(stairs_m, -118, 0, 32)
+    place(stairs_m, 118, 0, 32, ROT_MIRROR_X)
     # houses: many seeded variants scattered in the bailey and outside the walls
     n_house_models = 85
     houses = []
@@ -268,7 +268,7 @@ def castle_scene(seed=0xD057, scale=1.0):
     rots = (ROT_IDENTITY, ROT_Z90, ROT_Z180, ROT_Z270)
     placed = 0
     grid = [(x, y) for x in range(-600, 601, 100) for y in range(-600, 601, 100)
-            if not (abs(x) < 150 and abs(y) < 150) and not (330 < max(abs(x), abs(y)) < 440)]
+            if not (abs(x) < 170 and abs(y) < 110) and not (330 < max(abs(x), abs(y)) < 440)]
     order = rng.permutation(len(grid))
     group_members = []
     for gi in order[:110]:
