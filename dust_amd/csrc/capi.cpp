@@ -639,7 +639,7 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
       HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
       HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
     }
-    HIP_TRY(p->counters.alloc(4 * 8 * dust::kCounterStride * sizeof(uint32_t)));
+    HIP_TRY(p->counters.alloc(4 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
     HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
     HIP_TRY(p->exposure.alloc(257 * 4));
     HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
@@ -756,7 +756,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   p->fused_last = fuse;
   if (fuse) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p);
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     const dust::FrameArgs* d = nullptr;
@@ -767,7 +767,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     a.work_counters = static_cast<uint32_t*>(p->counters.p);
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     const dust::FrameArgs* d = nullptr;
@@ -777,8 +777,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 8 * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 1 * dust::kRegions * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
     const dust::FrameArgs* d = nullptr;
@@ -788,8 +788,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 16 * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 2 * dust::kRegions * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
     const dust::FrameArgs* d = nullptr;
@@ -802,8 +802,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     dust::FrameArgs b = a;  // 64 consecutive surfels per wavefront: one row of "tiles"
     b.tiles_x = (p->gi_pool_size + 63) / 64;
     b.tiles_y = 1;
-    b.work_counters = static_cast<uint32_t*>(p->counters.p) + 24 * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(b.work_counters, 0, 8 * dust::kCounterStride * sizeof(uint32_t), st));
+    b.work_counters = static_cast<uint32_t*>(p->counters.p) + 3 * dust::kRegions * dust::kCounterStride;
+    HIP_TRY(hipMemsetAsync(b.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
     const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));

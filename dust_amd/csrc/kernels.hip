@@ -603,8 +603,9 @@ struct Packet {
   bool valid;
 };
 
-// Pulls the next 8x8 pixel packet for this wave. The tile list is cut into 8 contiguous regions, one per XCD
-// (block b runs on XCD b % 8); a wave drains its own region first, then helps the others. Tiles are taken
+// Pulls the next 8x8 pixel packet for this wave. The tile list is cut into 8 contiguous bands, one per XCD
+// (block b runs on XCD b % 8), each split into kSubRegions queues so that the 64 workgroups of an XCD do not
+// all hammer one counter; a wave drains its own queue first, then its XCD's band, then helps the others. Tiles are taken
 // kTileChunk at a time from the region's counter; each counter owns a 256-byte line (sharing one line across
 // XCDs serialised every grab: 0.77 ms -> 0.39 ms per pass when they were separated).
 struct WorkCursor {
@@ -615,11 +616,13 @@ constexpr uint32_t kTileChunk = 1;  // 2 measured slower (0.39 -> 0.44 ms): coar
 
 __device__ __forceinline__ bool next_packet(const FrameArgs& a, WorkCursor& w, Packet& p) {
   const uint32_t total = a.tiles_x * a.tiles_y;
-  const uint32_t per = (total + 7u) / 8u;
+  const uint32_t per = (total + kRegions - 1u) / kRegions;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t xcd = blockIdx.x & 7u, sub = (blockIdx.x >> 3) & (kSubRegions - 1u);
   for (;;) {
-    if (w.region_try >= 8u) return false;
-    const uint32_t region = (blockIdx.x + w.region_try) & 7u;
+    if (w.region_try >= kRegions) return false;
+    // own sub-region first, then the rest of this XCD's band, then the other XCDs' bands
+    const uint32_t region = ((xcd + w.region_try / kSubRegions) & 7u) * kSubRegions + ((sub + w.region_try) & (kSubRegions - 1u));
     if (w.next >= w.end) {
       uint32_t k = 0;
       if (lane == 0) k = atomicAdd(&a.work_counters[region * kCounterStride], kTileChunk);
