@@ -42,3 +42,41 @@ def assemble_bands(parts, height: int, align: int = 8):
         r0, r1 = band_rows(r, world, height, align)
         rows.append(p[: r1 - r0])
     return torch.cat(rows, dim=0)
+
+
+class AsyncGather:
+    """Double-buffered gather to rank 0: the gather of step k overlaps the rendering of step k+1.
+    `fill(buf)` must enqueue the copy of this rank's finished frame into `buf` on the current stream."""
+
+    def __init__(self, dist, like, depth: int = 2, dst: int = 0):
+        import torch
+        self.dist, self.dst = dist, dst
+        self.active = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        self.bufs = [torch.empty_like(like) for _ in range(depth)]
+        self.works = [None] * depth
+        self.out = None
+        if self.active and dist.get_rank() == dst:
+            self.out = [[torch.empty_like(like) for _ in range(dist.get_world_size())] for _ in range(depth)]
+        self.k = 0
+
+    def submit(self, fill):
+        b = self.k % len(self.bufs)
+        if self.works[b] is not None:
+            self.works[b].wait()          # the send that last used this buffer is done (stream-ordered for NCCL)
+        fill(self.bufs[b])
+        if self.active:
+            self.works[b] = self.dist.gather(self.bufs[b], self.out[b] if self.out is not None else None, dst=self.dst,
+                                             async_op=True)
+        self.k += 1
+        return b
+
+    def finish(self):
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+
+    def last(self):
+        """Frames gathered by the most recent submit (rank dst only; [own buffer] when not distributed)."""
+        b = (self.k - 1) % len(self.bufs)
+        return self.out[b] if self.out is not None else [self.bufs[b]]

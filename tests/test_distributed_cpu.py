@@ -46,6 +46,15 @@ WORKER = textwrap.dedent('''
             ref = P.render_oracle(s, cam, sky, W, H, passes, noise[f % 4], synth.frame_rand(1, f))
             assert np.array_equal(frames[r].numpy().astype(np.uint16), ref.illuminance), f"sample {r} differs"
         assert not np.array_equal(frames[0].numpy(), frames[1].numpy()), "samples must differ (different noise slice / rand)"
+    # --- the double-buffered asynchronous gather bench.py uses (step k's gather overlaps step k+1)
+    ag = sharding.AsyncGather(dist, torch.zeros(4, dtype=torch.int32))
+    for k in range(5):
+        ag.submit(lambda buf, k=k: buf.fill_(100 * k + rank))
+        if rank == 0 and k >= 1:
+            pass
+    ag.finish()
+    if rank == 0:
+        assert [int(x[0]) for x in ag.last()] == [400 + r for r in range(world)]
         print("distributed ok")
     dist.barrier()
     dist.destroy_process_group()
