@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale", type=float, default=1.0, help="castle stand-in scale (1.0 = BASELINE config)")
+    ap.add_argument("--workload", choices=["primary_ao", "gi"], default="primary_ao",
+                    help="primary_ao = BASELINE configs[1] (the headline); gi = configs[2]: all four passes + accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
     return ap.parse_args()
@@ -99,6 +101,11 @@ def main():
     cam = api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), proj)
     rows = (0, H)
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    gi_mode = args.workload == "gi"
+    if gi_mode:  # configs[2]: diffuse GI through the surfel-fed spatial hash (concurrent apply, as the reference)
+        passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
+        pipe.set_noise(0, synth.stbn_scalar())
+        args.no_cpu_baseline = True
 
     # framebuffer gather target: the illuminance plane lives in a torch tensor so RCCL can move it
     band_px = W * Hband
@@ -128,13 +135,13 @@ def main():
     # untimed counting frame: rays per class and algorithmic bytes per launch
     step(0, count=True)
     barrier()
-    st = [pipe.pass_stats(i) for i in range(3)]
+    st = [pipe.pass_stats(i) for i in range(6 if gi_mode else 3)]
     rays_rank = sum(x.rays for x in st)
     # self-check of the plumbing the gather relies on (untimed): the torch tensor sees the library's plane
     fill(band)
     torch.cuda.synchronize()
     assert torch.equal(band.cpu().view(torch.int16), torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE).view(np.int16)))
-    names = ("primary", "sun_shadow", "ambient_occlusion")
+    names = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_sun", "surfel_cosine")
     hit_px = st[0].hits
     miss_px = st[0].rays - st[0].hits
     bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
@@ -177,7 +184,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    if ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
+    kernels_ms_extra = {}
+    if gi_mode:
+        ms_fg, ms_sf = pipe.pass_stats(3).ms, pipe.pass_stats(4).ms
+        # final gather: depth 4 + normal 4 + illuminance 8 read, 8 written, one 12-byte hash entry + 16-byte surfel per hit
+        bytes_fg = algorithmic_bytes(st[3], st[3].rays * 24 + st[3].hits * 28) - st[3].hits * 5
+        # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
+        bytes_sf = (algorithmic_bytes(st[4], 0) + algorithmic_bytes(st[5], st[5].rays * (16 + 48 + 24)) - (st[4].hits + st[5].hits) * 5)
+        kernels_ms_extra = {"k_final_gather": round(ms_fg, 4), "k_surfel_trace+apply": round(ms_sf, 4)}
+    if gi_mode and max(ms_fg, ms_sf) > ms_primary:
+        dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
+    elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
         dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)
     else:
         dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
@@ -194,8 +211,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
-                "kernels_ms": ({"k_primary_ao": round(ms_primary, 4)} if ms_ao == 0.0 else
-                               {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}),
+                "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if ms_ao == 0.0 else
+                                   {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
                 "bytes_per_ray": {"primary": round(bytes_primary / max(1, st[0].rays), 1),
                                   "ao_pass": round(bytes_ao / max(1, st[1].rays + st[2].rays), 1)}}
 
@@ -231,7 +248,8 @@ def main():
                          f"{cores} threads; tree build + flatten of the whole scene took {t_load:.2f} s on the same cores"}
 
     out = {
-        "metric": "Mrays/s at 1920x1080 1spp castle.vox (primary + sun-shadow + AO rays)",
+        "metric": "Mrays/s at 1920x1080 1spp castle.vox (primary + sun-shadow + AO rays)" if not gi_mode else
+                  "Mrays/s at 1920x1080 castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
         "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
