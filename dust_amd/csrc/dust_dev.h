@@ -22,7 +22,7 @@ constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base 
 constexpr uint32_t kSubRegions = 1;      // work queues per XCD band (power of two); 4 measured 2.5 % slower (more empty-queue probes at the tail)
 constexpr uint32_t kRegions = 8 * kSubRegions;
 constexpr uint32_t kCounterStride = 64;  // u32s between the per-region work counters (256 B: no two share a cache line)
-constexpr uint32_t kMaxCand = 40;        // per-wave candidate instance list capacity (32 B per entry in LDS)
+constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
 constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
 

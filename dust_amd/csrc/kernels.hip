@@ -484,7 +484,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // Bounds the packet's rays by per-axis origin and direction intervals, tests all instance boxes
 // against that bundle 64 at a time and compacts the survivors (ascending instance id) into `cand`.
 // Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
-__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, float4* cand) {
+__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, uint32_t* cand) {
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   float omin[3], omax[3], dmin[3], dmax[3];
 #pragma unroll
@@ -527,10 +527,9 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
     const uint64_t bal = __ballot(pass);
     if (pass) {
       const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      if (pos < kMaxCand) {  // box + id travel with the candidate: the per-ray loop reads them with two ds_read_b128
-        cand[pos * 2] = make_float4(wlo[0], wlo[1], wlo[2], __uint_as_float(i));
-        cand[pos * 2 + 1] = make_float4(whi[0], whi[1], whi[2], t_lo);  // .w: earliest entry of any ray of the packet
-      }
+      // one word per candidate: earliest entry of any ray of the packet (upper 16 bits of the float, i.e. rounded
+      // DOWN: stays conservative) above the 16-bit instance id -- unsigned compare orders by entry time, then id
+      if (pos < kMaxCand) cand[pos] = (__float_as_uint(fmaxf(t_lo, 0.0f)) & 0xFFFF0000u) | (i & 0xFFFFu);
     }
     n += (uint32_t)__popcll(bal);
   }
@@ -539,17 +538,17 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
   // Front-to-back order: rank the survivors by the packet's earliest entry time (ties by instance id), so that rays
   // which hit a near instance skip the far ones (te > best.t). Results do not depend on the order (deterministic
   // tie-break in test_brick); only the amount of work does.
-  if (n > 1 && n <= kMaxCand) {
-    float4 c0 = make_float4(0, 0, 0, 0), c1 = make_float4(0, 0, 0, 0);
-    uint32_t rank = 0;
-    if (lane < n) { c0 = cand[lane * 2]; c1 = cand[lane * 2 + 1]; }
-    for (uint32_t k = 0; k < n; ++k) {
-      const float tk = cand[k * 2 + 1].w;  // LDS broadcast
-      rank += (tk < c1.w || (tk == c1.w && k < lane)) ? 1u : 0u;
+  if (n > 1 && n <= kMaxCand) {  // front to back: rank = number of smaller keys (keys are unique)
+    for (uint32_t base = 0; base < n; base += 64u) {
+      const uint32_t me = base + lane;
+      const uint32_t c = me < n ? cand[me] : 0xFFFFFFFFu;
+      uint32_t rank = 0;
+      for (uint32_t k = 0; k < n; ++k) rank += cand[k] < c ? 1u : 0u;  // LDS broadcast reads
+      if (me < n) cand[kMaxCand + rank] = c;  // sorted copy staged behind the list (later rounds still read the original)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < n) { cand[rank * 2] = c0; cand[rank * 2 + 1] = c1; }
+    for (uint32_t i = lane; i < n; i += 64u) cand[i] = cand[kMaxCand + i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -559,7 +558,7 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
 // any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
 template <int RT, bool COUNT>
 __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
-                          const float4* cand, uint32_t ncand, Hit& best, LaneStats& st) {
+                          const uint32_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
   best.found = false;
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
@@ -569,15 +568,21 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     uint32_t ii;
     float lo[3], hi[3];
-    if (all) {
+    if (all) {  // more instances than the list holds: walk every instance box in index order
       ii = ci;
+    } else {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[ci]);  // same address in every lane: LDS broadcast
+      ii = c & 0xFFFFu;
+      // the list is sorted by earliest possible entry: once every ray of the packet has a hit in front of this
+      // candidate's earliest entry, no later candidate can matter either
+      const float t_lo = __uint_as_float(c & 0xFFFF0000u);
+      const bool settled = !active || (best.found && (any_hit || best.t < t_lo * (1.0f - 1e-5f) - 1e-4f));
+      if (__all(settled)) break;
+    }
+    {
       const DevInstance& in = a.instances[ii];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { lo[k] = in.wmin[k]; hi[k] = in.wmax[k]; }
-    } else {
-      const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];  // same address in every lane: LDS broadcast
-      ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c0.w));
-      lo[0] = c0.x; lo[1] = c0.y; lo[2] = c0.z; hi[0] = c1.x; hi[1] = c1.y; hi[2] = c1.z;
     }
     bool go = active && !(any_hit && best.found);
     float te, tx;
@@ -652,8 +657,8 @@ __device__ __forceinline__ void stage_roots(const FrameArgs& a) {
   for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<uint4*>(g_lds)[i] = src[i];
   __syncthreads();
 }
-__device__ __forceinline__ float4* wave_cand_list(const FrameArgs& a) {
-  return reinterpret_cast<float4*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * (kMaxCand * 2);
+__device__ __forceinline__ uint32_t* wave_cand_list(const FrameArgs& a) {  // kMaxCand entries + kMaxCand of sort staging
+  return reinterpret_cast<uint32_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * (kMaxCand * 2);
 }
 
 __device__ __forceinline__ void add_stats(LaneStats& d, const LaneStats& s) {
@@ -691,7 +696,7 @@ __device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, ui
 // store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
 // occlusion pass overwrites the texel of every hit pixel anyway.
 template <bool COUNT>
-__device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet& p, float4* cand, LaneStats& st,
+__device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
   const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
@@ -751,7 +756,7 @@ __device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet&
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
 template <bool COUNT>
-__device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, float4* cand, LaneStats& st_sun, LaneStats& st_ao,
+__device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, uint32_t* cand, LaneStats& st_sun, LaneStats& st_ao,
                                           float hitT, uint32_t normal_packed, V3 payload) {
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
@@ -797,7 +802,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  float4* cand = wave_cand_list(a);
+  uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
@@ -813,7 +818,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  float4* cand = wave_cand_list(a);
+  uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
@@ -841,7 +846,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  float4* cand = wave_cand_list(a);
+  uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
@@ -1004,7 +1009,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  float4* cand = wave_cand_list(a);
+  uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
@@ -1077,7 +1082,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __restrict__ ap) {
   const FrameArgs& a = *ap;
   stage_roots(a);
-  float4* cand = wave_cand_list(a);
+  uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = {0, 0, 0};
   Packet p;
@@ -1329,7 +1334,7 @@ hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t
 // ==================================================================== launchers (called from capi.cpp)
 // `host` describes the launch (LDS size); `dev` is the same struct already copied to device memory.
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
-  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 32u;
+  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 8u;
 }
 
 hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
