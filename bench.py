@@ -253,7 +253,8 @@ def main():
         "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "castle.vox stand-in (synth.castle_scene seed 0xD057), 1920x1080 per GPU, 1spp primary+shadow+AO"
+        "config": {"workload": ("castle.vox stand-in (synth.castle_scene seed 0xD057), 1920x1080 per GPU, "
+                                + ("1 GI frame: primary+shadow+AO+final gather+surfel" if gi_mode else "1spp primary+shadow+AO"))
                    if args.scale == 1.0 else f"castle stand-in at scale {args.scale}",
                    "frame": [W, H], "spp_per_step": world,
                    "parallelism": f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",

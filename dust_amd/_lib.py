@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdust_hip.so")
+# DUST_HIP_LIB selects another build of the SAME library (tools/kernel_sections.py uses its -DDUST_PROFILE build)
+LIB_PATH = os.environ.get("DUST_HIP_LIB") or os.path.join(_HERE, "libdust_hip.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1

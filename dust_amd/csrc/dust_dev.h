@@ -15,12 +15,27 @@
 
 #include "../../include/dust_hip.h"
 
+// Address spaces. The kernels take their launch descriptor by device pointer, so every pointer inside it would be a
+// generic ("flat") pointer to the compiler: flat_load for everything, no scalar loads (it cannot prove the scene is
+// not written by the G-buffer stores). In the device pass the read-only scene pointers are therefore declared in the
+// constant address space (uniform index -> s_load into SGPRs, divergent index -> global_load off a scalar base) and
+// the written planes in the global one (global_store). Same 64-bit representation: the host (and every translation
+// unit other than kernels.hip, which opts in) sees plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DUST_DEVICE_ADDRESS_SPACES)
+#define DUST_CONST_AS __attribute__((address_space(4)))
+#define DUST_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define DUST_CONST_AS
+#define DUST_GLOBAL_AS
+#endif
+#define DUST_RO(T) const DUST_CONST_AS T*
+#define DUST_RW(T) DUST_GLOBAL_AS T*
+
 namespace dust {
 
 constexpr uint32_t kN16Bytes = 656;      // 512 mask + 128 prefix + 4 base + 12 pad
 constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base is 0)
-constexpr uint32_t kSubRegions = 1;      // work queues per XCD band (power of two); 4 measured 2.5 % slower (more empty-queue probes at the tail)
-constexpr uint32_t kRegions = 8 * kSubRegions;
+constexpr uint32_t kRegions = 8;          // work bands = XCDs (finer sub-queues per band measured 2.5 % slower: more empty-queue probes at the tail)
 constexpr uint32_t kCounterStride = 64;  // u32s between the per-region work counters (256 B: no two share a cache line)
 constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
@@ -33,13 +48,13 @@ struct DevN4 {
 };
 
 struct DevModel {
-  const uint8_t* root;          // N16
-  const uint8_t* l2;            // N16[] or null
-  const DevN4* mid;
-  const uint64_t* dense_mask;   // [mid node][64 child bits] -> brick occupancy, 0 = no brick
-  const DustHipBlock* blocks;
-  const uint8_t* materials;
-  const uint32_t* palette;      // RGBA8 packed little-endian, 255 entries (+1 pad)
+  DUST_RO(uint8_t) root;          // N16
+  DUST_RO(uint8_t) l2;            // N16[] or null
+  DUST_RO(DevN4) mid;
+  DUST_RO(uint64_t) dense_mask;   // [mid node][64 child bits] -> brick occupancy, 0 = no brick
+  DUST_RO(DustHipBlock) blocks;
+  DUST_RO(uint8_t) materials;
+  DUST_RO(uint32_t) palette;      // RGBA8 packed little-endian, 255 entries (+1 pad)
   float bmin[3], bmax[3];       // tight object-space bounds of the bricks
   uint32_t extent;              // 256 or 4096
   uint32_t n_levels;            // internal levels: 2 (root,mid) or 3 (root,l2,mid)
@@ -66,14 +81,14 @@ struct DevStats {
 };
 
 struct DevGBuffer {
-  uint16_t* illuminance;  // 4 halves / px
-  uint16_t* denoised;     // 4 halves / px
-  uint32_t* albedo;
-  uint32_t* normal;
-  float* depth;
-  uint16_t* motion;       // 4 halves / px
-  uint32_t* voxel_id;
-  float* accum;           // 4 floats / px
+  DUST_RW(uint16_t) illuminance;  // 4 halves / px
+  DUST_RW(uint16_t) denoised;    // 4 halves / px
+  DUST_RW(uint32_t) albedo;
+  DUST_RW(uint32_t) normal;
+  DUST_RW(float) depth;
+  DUST_RW(uint16_t) motion;      // 4 halves / px
+  DUST_RW(uint32_t) voxel_id;
+  DUST_RW(float) accum;          // 4 floats / px
 };
 
 // SpatialHashEntry, 12 bytes, scalar layout (layout.playout:13-18): {u32 fingerprint, u32 LogLuv radiance,
@@ -97,22 +112,22 @@ struct DevGI {
 };
 
 struct FrameArgs {
-  const DevModel* models;
-  const DevInstance* instances;
+  DUST_RO(DevModel) models;
+  DUST_RO(DevInstance) instances;
   uint32_t n_models, n_instances;
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
-  const uint8_t* root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
+  DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DevCamera cam;
   float sky[56];
   DevGBuffer g;
   uint32_t width, height;
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
-  uint32_t* work_counters;    // 8 per-region tile counters, kCounterStride apart (zeroed before launch)
-  const uint8_t* noise0;      // 128*128 R8 slice for this frame, or null
-  const uint8_t* noise5;      // 128*128 RGBA8 slice for this frame, or null
+  DUST_RW(uint32_t) work_counters;    // 8 per-region tile counters, kCounterStride apart (zeroed before launch)
+  DUST_RO(uint8_t) noise0;     // 128*128 R8 slice for this frame, or null
+  DUST_RO(uint8_t) noise5;     // 128*128 RGBA8 slice for this frame, or null
   uint32_t rand, frame_index;
-  DevStats* stats;            // [2]: per pass kind, only written by the counting build
+  DUST_RW(DevStats) stats;           // [2]: per pass kind, only written by the counting build
   uint32_t accum_count;       // frames already in `accum`
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;

@@ -16,13 +16,43 @@
 // oracle's. No MFMA: this is pointer chasing, not a contraction.
 #include <hip/hip_runtime.h>
 
+#define DUST_DEVICE_ADDRESS_SPACES 1
 #include "dust_dev.h"
 
 namespace dust {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
+// Section timers for tools/kernel_sections.py: compiled in only with -DDUST_PROFILE (a separate, never shipped
+// .so). PROF_ENTER/PROF_LEAVE add -/+ s_memtime to a per-wave LDS bucket (fire-and-forget ds_add by the first
+// active lane), so a bucket ends up holding the wave's inclusive cycles in that section.
+#ifdef DUST_PROFILE
+constexpr int kProfBuckets = 16;
+__shared__ unsigned long long g_prof[16][kProfBuckets];
+__device__ unsigned long long g_prof_out[kProfBuckets];
+__device__ __forceinline__ void prof_mark(int idx, bool leave) {
+  const unsigned long long now = __builtin_amdgcn_s_memtime();
+  const unsigned long long ex = __ballot(1);
+  if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)ex) - 1))
+    atomicAdd(&g_prof[threadIdx.x >> 6][idx], leave ? now : (0ull - now));
+}
+#define PROF_ENTER(i) prof_mark(i, false)
+#define PROF_LEAVE(i) prof_mark(i, true)
+#else
+#define PROF_ENTER(i)
+#define PROF_LEAVE(i)
+#endif
+enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE };
+
 namespace {
+
+// launch descriptor, models and instances live in the constant address space (see dust_dev.h)
+typedef const DUST_CONST_AS FrameArgs& ArgsRef;
+typedef const DUST_CONST_AS DevModel& ModelRef;
+typedef const DUST_CONST_AS DevInstance& InstanceRef;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -44,11 +74,11 @@ __device__ __forceinline__ int f2i_trunc(float f) {  // ivec3(float): toward zer
   if (f <= -2147483648.0f) return (-2147483647 - 1);
   return (int)f;
 }
-__device__ __forceinline__ V3 xform_point(const float* m, V3 p) {
+__device__ __forceinline__ V3 xform_point(DUST_RO(float) m, V3 p) {
   return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
             ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
 }
-__device__ __forceinline__ V3 xform_dir(const float* m, V3 d) {
+__device__ __forceinline__ V3 xform_dir(DUST_RO(float) m, V3 d) {
   return mk((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z,
             (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
 }
@@ -64,11 +94,11 @@ __device__ __forceinline__ uint32_t unorm(float v, float scale) {
 __device__ __forceinline__ uint32_t pack_rgb10a2(float r, float g, float b, float a) {
   return unorm(r, 1023.0f) | (unorm(g, 1023.0f) << 10) | (unorm(b, 1023.0f) << 20) | (unorm(a, 3.0f) << 30);
 }
-__device__ __forceinline__ void store_half4(uint16_t* plane, size_t pix, float a, float b, float c, float d) {
-  uint2 v;
+__device__ __forceinline__ void store_half4(DUST_RW(uint16_t) plane, size_t pix, float a, float b, float c, float d) {
+  u32x2 v;
   v.x = (uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16);
   v.y = (uint32_t)f2h(c) | ((uint32_t)f2h(d) << 16);
-  *reinterpret_cast<uint2*>(plane + pix * 4) = v;
+  *(DUST_GLOBAL_AS u32x2*)(plane + pix * 4) = v;
 }
 
 // ------------------------------------------------------------------ headers/normal.glsl, nrd.glsl
@@ -107,15 +137,21 @@ __device__ __forceinline__ V3 nrd_unpack_normal(uint32_t p) {  // nrd.glsl:54-94
   n.y -= t * (gstep(0.0f, n.y) * 2.0f - 1.0f);
   return normalize3(n);
 }
-__device__ __forceinline__ void store_radiance(uint16_t* plane, size_t pix, V3 r, float hitdist) {  // nrd.glsl:127-147
+__device__ __forceinline__ void store_radiance(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {  // nrd.glsl:127-147
   if (hitdist != 0.0f) hitdist = fmaxf(hitdist, 1e-7f);
   float Y = (r.x * 0.25f + r.y * 0.5f) + r.z * 0.25f;
   float Co = (r.x * 0.5f + r.y * 0.0f) + r.z * -0.5f;
   float Cg = (r.x * -0.25f + r.y * 0.5f) + r.z * -0.25f;
   store_half4(plane, pix, Y, Co, Cg, hitdist);
 }
-__device__ __forceinline__ V3 load_radiance(const uint16_t* plane, size_t pix, float& w) {  // nrd.glsl:107-125
-  uint2 v = *reinterpret_cast<const uint2*>(plane + pix * 4);
+__device__ __forceinline__ V3 decode_radiance(u32x2 v, float& w);
+__device__ __forceinline__ V3 load_radiance(DUST_RW(uint16_t) plane, size_t pix, float& w) {  // a G-buffer plane
+  return decode_radiance(*(const DUST_GLOBAL_AS u32x2*)(plane + pix * 4), w);
+}
+__device__ __forceinline__ V3 load_radiance(const uint16_t* plane, size_t pix, float& w) {     // a kernel argument
+  return decode_radiance(*reinterpret_cast<const u32x2*>(plane + pix * 4), w);
+}
+__device__ __forceinline__ V3 decode_radiance(u32x2 v, float& w) {  // nrd.glsl:107-125
   float Y = h2f((uint16_t)v.x), Co = h2f((uint16_t)(v.x >> 16)), Cg = h2f((uint16_t)v.y);
   w = h2f((uint16_t)(v.y >> 16));
   float t = Y - Cg;
@@ -128,7 +164,7 @@ __device__ __forceinline__ V3 xyz_to_acescg(V3 v) {  // color.glsl:24-31 (column
             (-0.66366285f * v.x + 1.6153315f * v.y) + 0.016756356f * v.z,
             (0.011721907f * v.x + -0.0082844375f * v.y) + 0.9883947f * v.z);
 }
-__device__ float sky_internal(const float* c, float cos_theta, float gamma, float cos_gamma) {  // sky.glsl:1-15
+__device__ float sky_internal(DUST_RO(float) c, float cos_theta, float gamma, float cos_gamma) {  // sky.glsl:1-15
   float expM = expf(c[4] * gamma);
   float rayM = cos_gamma * cos_gamma;
   float mieM = (1.0f + rayM) / powf((1.0f + c[8] * c[8]) - (2.0f * c[8]) * cos_gamma, 1.5f);
@@ -136,7 +172,7 @@ __device__ float sky_internal(const float* c, float cos_theta, float gamma, floa
   return (1.0f + c[0] * expf(c[1] / (cos_theta + 0.01f))) *
          ((((c[2] + c[3] * expM) + c[5] * rayM) + c[6] * mieM) + c[7] * zenith);
 }
-__device__ V3 sky_radiance(const float* s, V3 dir) {  // sky.glsl:18-79
+__device__ V3 sky_radiance(DUST_RO(float) s, V3 dir) {  // sky.glsl:18-79
   if (s[49] <= 0.0f) return mk(0, 0, 0);
   float cos_theta = gclamp(dir.y, 0.0f, 1.0f);
   float cos_gamma = dot3(dir, mk(s[48], s[49], s[50]));
@@ -146,7 +182,7 @@ __device__ V3 sky_radiance(const float* s, V3 dir) {  // sky.glsl:18-79
   float z = sky_internal(s + 32, cos_theta, gamma, cos_gamma) * s[41];
   return xyz_to_acescg(mk(x * 683.0f, y * 683.0f, z * 683.0f));
 }
-__device__ V3 sun_radiance(const float* s, V3 dir) {  // sky.glsl:81-113
+__device__ V3 sun_radiance(DUST_RO(float) s, V3 dir) {  // sky.glsl:81-113
   float cos_gamma = dot3(dir, mk(s[48], s[49], s[50]));
   if (cos_gamma < 0.0f || dir.y < 0.0f) return mk(0, 0, 0);
   float sol_rad_sin = sinf(s[55]);
@@ -246,7 +282,8 @@ struct MidCache {  // the 16-cell the ray was last in and its mid-node index (sa
 };
 
 // inv = 1/d per component (IEEE divide; +-inf for zero components, which take the other branch)
-__device__ __forceinline__ bool slab_box(V3 o, V3 d, V3 inv_d, const float* lo, const float* hi, float& te, float& tx) {
+template <class PLo, class PHi>
+__device__ __forceinline__ bool slab_box(V3 o, V3 d, V3 inv_d, PLo lo, PHi hi, float& te, float& tx) {
   te = -INFINITY; tx = INFINITY;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, iv[3] = {inv_d.x, inv_d.y, inv_d.z};
 #pragma unroll
@@ -265,7 +302,7 @@ __device__ __forceinline__ bool slab_box(V3 o, V3 d, V3 inv_d, const float* lo, 
 }
 
 // N16 lookup: bit test + rank. Root nodes staged in LDS are read with ds_read, the rest from memory.
-__device__ __forceinline__ bool n16_child(const uint8_t* node, int lds_slot, uint32_t idx, uint32_t& child) {
+__device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, uint32_t idx, uint32_t& child) {
   uint32_t w = idx >> 6, bit = idx & 63u;
   uint64_t word;
   uint32_t pre;
@@ -274,9 +311,9 @@ __device__ __forceinline__ bool n16_child(const uint8_t* node, int lds_slot, uin
     if (!((word >> bit) & 1ull)) return false;
     pre = reinterpret_cast<const uint16_t*>(g_lds + (uint32_t)lds_slot * kN16LdsBytes + 512)[w];
   } else {
-    word = reinterpret_cast<const uint64_t*>(node)[w];
+    word = ((DUST_RO(uint64_t))node)[w];
     if (!((word >> bit) & 1ull)) return false;
-    pre = reinterpret_cast<const uint16_t*>(node + 512)[w] + *reinterpret_cast<const uint32_t*>(node + 640);
+    pre = ((DUST_RO(uint16_t))(node + 512))[w] + *(DUST_RO(uint32_t))(node + 640);
   }
   child = pre + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
   return true;
@@ -287,7 +324,7 @@ __device__ __forceinline__ bool n16_child(const uint8_t* node, int lds_slot, uin
 // which orders bricks exactly like the block index does (both are depth-first).
 // One dependent memory access per call: root in LDS -> mid index -> dense_mask[mid*64 + bit].
 template <bool COUNT>
-__device__ __forceinline__ uint64_t find_brick(const DevModel& m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
+__device__ __forceinline__ uint64_t find_brick(ModelRef m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
                                                MidCache& mc, LaneStats& st, bool count) {
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
   if (k16 != mc.key) {
@@ -316,10 +353,21 @@ __device__ __forceinline__ uint64_t find_brick(const DevModel& m, int x, int y, 
 }
 
 // block index (gl_PrimitiveID) of a brick key: first_block of its mid node + rank of the child bit
-__device__ __forceinline__ uint32_t resolve_block(const DevModel& m, uint32_t key) {
-  const uint4 n = *reinterpret_cast<const uint4*>(m.mid + (key >> 6));
+__device__ __forceinline__ uint32_t resolve_block(ModelRef m, uint32_t key) {
+  const u32x4 n = *(DUST_RO(u32x4))(m.mid + (key >> 6));
   const uint64_t mm = ((uint64_t)n.y << 32) | n.x;
   return n.z + (uint32_t)__popcll(mm & ((1ull << (key & 63u)) - 1ull));
+}
+
+// the 24-byte Block record as three 8-byte loads
+__device__ __forceinline__ DustHipBlock load_block(DUST_RO(DustHipBlock) p) {
+  DUST_RO(u32x2) q = (DUST_RO(u32x2))p;
+  const u32x2 q0 = q[0], q1 = q[1], q2 = q[2];
+  DustHipBlock b;
+  b.x = (uint16_t)q0.x; b.y = (uint16_t)(q0.x >> 16); b.z = (uint16_t)q0.y; b.w = (uint16_t)(q0.y >> 16);
+  b.mask = ((uint64_t)q1.y << 32) | q1.x;
+  b.material_ptr = q2.x; b.avg_albedo = q2.y;
+  return b;
 }
 
 // run the ray type's intersection routine on one brick and apply Vulkan's accept rule
@@ -348,7 +396,7 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
 // delta of other brick planes, the bricks across those planes are queued in `pending` (a 7-bit set of
 // axis subsets) and visited by the same code before the walk advances.
 template <int RT, bool COUNT>
-__device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
+__device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                                Hit& best, LaneStats& st) {
   const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   float te, tx;
@@ -391,15 +439,26 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
         }
       {
         uint32_t cl2, key;
+        PROF_ENTER(P_FIND);
         const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
-        if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+        const bool have = mask != 0;
+        PROF_LEAVE(P_FIND);
+        PROF_ENTER(P_BRICK);
+        if (have) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+        PROF_LEAVE(P_BRICK);
         if (pending != 0) continue;
       }
     }
     if (is_main) {
       uint32_t key;
+      PROF_ENTER(P_FIND);
       const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, key, mc, st, true);
-      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      const bool have = mask != 0;
+      PROF_LEAVE(P_FIND);
+      PROF_ENTER(P_BRICK);
+      if (have) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      PROF_LEAVE(P_BRICK);
+      PROF_ENTER(P_SCREEN);
       // Which further brick planes is the entry point within delta of? Cheap screen first: the distance of p to
       // the nearest multiple of 4 on the axes that did not step (a superset of the exact test below), and exact
       // ties on exit (more than one axis stepped). Almost every step ends here.
@@ -412,6 +471,7 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
         if (!(stepped & (1u << a)) && f <= 2.6e-7f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f)) screen = true;
       }
       near_neg = 0; near_pos = 0;
+      bool queued = false;
       if (screen) {
         uint32_t unstepped_near = 0;
 #pragma unroll
@@ -431,11 +491,14 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
 #pragma unroll
           for (uint32_t sub = 1; sub < 8; ++sub)
             if ((sub & ~nearm) == 0 && !(stepped != 0 && sub == stepped)) pending |= 1u << (sub - 1);  // sub == stepped: the cell we came from
-          if (pending != 0) continue;
+          queued = pending != 0;
         }
       }
+      PROF_LEAVE(P_SCREEN);
+      if (queued) continue;
     }
     // leave the cell of size 2^cl_main that contains ijk
+    PROF_ENTER(P_ADVANCE);
     const int S = 1 << cl_main;
     float ta[3], tn = INFINITY;
     int cc[3];
@@ -450,7 +513,7 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
       }
       tn = fminf(tn, ta[a]);
     }
-    if (!(tn < INFINITY)) return;
+    if (!(tn < INFINITY)) { PROF_LEAVE(P_ADVANCE); return; }
     stepped = 0;
     bool outside = false;
 #pragma unroll
@@ -463,6 +526,7 @@ __device__ void trace_instance(const DevModel& m, uint32_t inst, V3 o, V3 d, flo
         ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * tn), cc[a], cc[a] + S - 1);
       }
     }
+    PROF_LEAVE(P_ADVANCE);
     if (outside) return;
     t = fmaxf(t, tn);
     if (t * (1.0f - 2e-6f) > tx_stop) return;
@@ -484,9 +548,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // Bounds the packet's rays by per-axis origin and direction intervals, tests all instance boxes
 // against that bundle 64 at a time and compacts the survivors (ascending instance id) into `cand`.
 // Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
-__device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, float tmax, uint32_t* cand) {
+__device__ uint32_t cull_instances(ArgsRef a, bool active, V3 o, V3 d, float tmax, uint32_t* cand) {
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   float omin[3], omax[3], dmin[3], dmax[3];
+  PROF_ENTER(P_CULL);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     omin[k] = wave_min(active ? oo[k] : INFINITY);
@@ -495,7 +560,7 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
     dmax[k] = wave_max(active ? dd[k] : -INFINITY);
   }
   const float T = wave_max(active ? tmax : 0.0f);
-  if (!(omin[0] <= omax[0])) return 0;  // no active lane
+  if (!(omin[0] <= omax[0])) { PROF_LEAVE(P_CULL); return 0; }  // no active lane
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n = 0;
   for (uint32_t base = 0; base < a.n_instances; base += 64) {
@@ -504,7 +569,7 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
     float t_lo = 0.0f;
     float wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
     if (i < a.n_instances) {
-      const DevInstance& in = a.instances[i];
+      InstanceRef in = a.instances[i];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { wlo[k] = in.wmin[k]; whi[k] = in.wmax[k]; }
       float t_hi = T;
@@ -552,13 +617,15 @@ __device__ uint32_t cull_instances(const FrameArgs& a, bool active, V3 o, V3 d, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  PROF_LEAVE(P_CULL);
   return n;
 }
 
 // any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
 template <int RT, bool COUNT>
-__device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
+__device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                           const uint32_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
+  PROF_ENTER(P_TRACE_RAY);
   best.found = false;
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
@@ -579,8 +646,9 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
       const bool settled = !active || (best.found && (any_hit || best.t < t_lo * (1.0f - 1e-5f) - 1e-4f));
       if (__all(settled)) break;
     }
-    {
-      const DevInstance& in = a.instances[ii];
+    ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)ii);  // wave-uniform by construction: say so, so that the
+    {                                                         // instance and model records come through scalar loads
+      InstanceRef in = a.instances[ii];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { lo[k] = in.wmin[k]; hi[k] = in.wmax[k]; }
     }
@@ -594,12 +662,15 @@ __device__ void trace_ray(const FrameArgs& a, bool active, V3 o, V3 d, float tmi
     if (!__any(go)) continue;
     if (go) {
       if (COUNT) st.instances_tested += 1;
-      const DevInstance& in = a.instances[ii];
-      const DevModel& m = a.models[in.model];
+      InstanceRef in = a.instances[ii];
+      ModelRef m = a.models[in.model];
+      PROF_ENTER(P_INSTANCE);
       trace_instance<RT, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
+      PROF_LEAVE(P_INSTANCE);
     }
   }
   if (COUNT && best.found) st.hits += 1;
+  PROF_LEAVE(P_TRACE_RAY);
 }
 
 // ------------------------------------------------------------------ work distribution
@@ -608,56 +679,83 @@ struct Packet {
   bool valid;
 };
 
-// Pulls the next 8x8 pixel packet for this wave. The tile list is cut into 8 contiguous bands, one per XCD
-// (block b runs on XCD b % 8), each split into kSubRegions queues so that the 64 workgroups of an XCD do not
-// all hammer one counter; a wave drains its own queue first, then its XCD's band, then helps the others. Tiles are taken
-// kTileChunk at a time from the region's counter; each counter owns a 256-byte line (sharing one line across
-// XCDs serialised every grab: 0.77 ms -> 0.39 ms per pass when they were separated).
+// Work distribution. The tile list is cut into 8 contiguous bands, one per XCD (block b runs on XCD b % 8, so a band
+// stays in one L2). A wave's first tile in its own band is assigned statically (its index among the band's waves:
+// no 512-deep queue on the counter at kernel start); after that tiles come from the band's atomic counter, whose
+// tickets therefore start at "number of waves in the band". A wave drains its own band first, then helps the
+// others. Each counter owns a 256-byte line (sharing one line across XCDs serialised every grab: 0.77 ms -> 0.39 ms
+// per pass when they were separated). Measured and rejected: requesting the NEXT ticket before tracing the current
+// packet (+7 %: returns are in order, so the first load of the packet waits for the device-scope atomic anyway),
+// chunks of 2 tiles (+13 %), static striding, 4 sub-queues per band (+2.5 %).
 struct WorkCursor {
-  uint32_t region_try;  // regions given up on so far
-  uint32_t next, end;   // tiles [next, end) of the current chunk, region-relative
+  uint32_t region_try;  // bands given up on so far
+  uint32_t ticket;      // band-relative tile index, kNoTicket = ask the counter
 };
-constexpr uint32_t kTileChunk = 1;  // 2 measured slower (0.39 -> 0.44 ms): coarser grabs lose more to the tail than they save in atomics
-
-__device__ __forceinline__ bool next_packet(const FrameArgs& a, WorkCursor& w, Packet& p) {
+constexpr uint32_t kNoTicket = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t band_static_tickets(uint32_t band) {  // waves whose own band this is
+  return ((gridDim.x + 7u - band) >> 3) * (blockDim.x >> 6);
+}
+__device__ __forceinline__ WorkCursor cursor_begin() {
+  WorkCursor w;
+  w.region_try = 0;
+  w.ticket = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  return w;
+}
+__device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) {
   const uint32_t total = a.tiles_x * a.tiles_y;
   const uint32_t per = (total + kRegions - 1u) / kRegions;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t xcd = blockIdx.x & 7u, sub = (blockIdx.x >> 3) & (kSubRegions - 1u);
+  PROF_ENTER(P_GRAB);
   for (;;) {
-    if (w.region_try >= kRegions) return false;
-    // own sub-region first, then the rest of this XCD's band, then the other XCDs' bands
-    const uint32_t region = ((xcd + w.region_try / kSubRegions) & 7u) * kSubRegions + ((sub + w.region_try) & (kSubRegions - 1u));
-    if (w.next >= w.end) {
-      uint32_t k = 0;
-      if (lane == 0) k = atomicAdd(&a.work_counters[region * kCounterStride], kTileChunk);
+    if (w.region_try >= kRegions) { PROF_LEAVE(P_GRAB); return false; }
+    const uint32_t band = ((blockIdx.x & 7u) + w.region_try) & 7u;
+    uint32_t k = w.ticket;
+    if (k == kNoTicket) {
+      if (lane == 0) k = band_static_tickets(band) + atomicAdd((uint32_t*)&a.work_counters[band * kCounterStride], 1u);
       k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-      w.next = k;
-      w.end = min(k + kTileChunk, per);
     }
-    const uint32_t tile = region * per + w.next;
-    if (w.next < w.end && tile < total) {
-      w.next += 1;
+    w.ticket = kNoTicket;
+    const uint32_t tile = band * per + k;
+    if (k < per && tile < total) {
       const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
       p.px = tx * 8u + (lane & 7u);
       p.py = a.row_begin + ty * 8u + (lane >> 3);
       p.valid = p.px < a.width && p.py < a.row_end;
+      PROF_LEAVE(P_GRAB);
       return true;
     }
-    w.region_try += 1;  // region exhausted
-    w.next = w.end = 0;
+    w.region_try += 1;  // band exhausted
   }
 }
 
-__device__ __forceinline__ void stage_roots(const FrameArgs& a) {
+__device__ __forceinline__ void prof_begin() {
+#ifdef DUST_PROFILE
+  if ((threadIdx.x & 63u) == 0)
+    for (int i = 0; i < kProfBuckets; ++i) g_prof[threadIdx.x >> 6][i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  PROF_ENTER(P_TOTAL);
+  PROF_ENTER(P_STAGE);
+#endif
+}
+__device__ __forceinline__ void prof_end() {
+#ifdef DUST_PROFILE
+  PROF_LEAVE(P_TOTAL);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if ((threadIdx.x & 63u) == 0)
+    for (int i = 0; i < kProfBuckets; ++i) atomicAdd(&g_prof_out[i], g_prof[threadIdx.x >> 6][i]);
+#endif
+}
+__device__ __forceinline__ void stage_roots(ArgsRef a) {
+  prof_begin();
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
   const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
-  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.root_table);
-  for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<uint4*>(g_lds)[i] = src[i];
+  DUST_RO(u32x4) src = (DUST_RO(u32x4))a.root_table;
+  for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<u32x4*>(g_lds)[i] = src[i];
   __syncthreads();
+  PROF_LEAVE(P_STAGE);
 }
-__device__ __forceinline__ uint32_t* wave_cand_list(const FrameArgs& a) {  // kMaxCand entries + kMaxCand of sort staging
+__device__ __forceinline__ uint32_t* wave_cand_list(ArgsRef a) {  // kMaxCand entries + kMaxCand of sort staging
   return reinterpret_cast<uint32_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * (kMaxCand * 2);
 }
 
@@ -666,17 +764,17 @@ __device__ __forceinline__ void add_stats(LaneStats& d, const LaneStats& s) {
   d.mid_descents += s.mid_descents; d.bricks_tested += s.bricks_tested; d.hits += s.hits;
 }
 template <bool COUNT>
-__device__ __forceinline__ void flush_stats(const FrameArgs& a, int slot, const LaneStats& st) {
+__device__ __forceinline__ void flush_stats(ArgsRef a, int slot, const LaneStats& st) {
   if (!COUNT) return;
-  atomicAdd(&a.stats[slot].rays, (unsigned long long)st.rays);
-  atomicAdd(&a.stats[slot].instances_tested, (unsigned long long)st.instances_tested);
-  atomicAdd(&a.stats[slot].upper_descents, (unsigned long long)st.upper_descents);
-  atomicAdd(&a.stats[slot].mid_descents, (unsigned long long)st.mid_descents);
-  atomicAdd(&a.stats[slot].bricks_tested, (unsigned long long)st.bricks_tested);
-  atomicAdd(&a.stats[slot].hits, (unsigned long long)st.hits);
+  atomicAdd((unsigned long long*)&a.stats[slot].rays, (unsigned long long)st.rays);
+  atomicAdd((unsigned long long*)&a.stats[slot].instances_tested, (unsigned long long)st.instances_tested);
+  atomicAdd((unsigned long long*)&a.stats[slot].upper_descents, (unsigned long long)st.upper_descents);
+  atomicAdd((unsigned long long*)&a.stats[slot].mid_descents, (unsigned long long)st.mid_descents);
+  atomicAdd((unsigned long long*)&a.stats[slot].bricks_tested, (unsigned long long)st.bricks_tested);
+  atomicAdd((unsigned long long*)&a.stats[slot].hits, (unsigned long long)st.hits);
 }
 
-__device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
+__device__ __forceinline__ V3 camera_ray_dir(const DUST_CONST_AS DevCamera& c, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
   // camera.glsl:4-16
   float nx = ((float)px + 0.5f) / (float)w, ny = ((float)py + 0.5f) / (float)h;
   float cx = 2.0f * nx - 1.0f, cy = 2.0f * ny - 1.0f;
@@ -696,7 +794,7 @@ __device__ __forceinline__ V3 camera_ray_dir(const DevCamera& c, uint32_t px, ui
 // store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
 // occlusion pass overwrites the texel of every hit pixel anyway.
 template <bool COUNT>
-__device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet& p, uint32_t* cand, LaneStats& st,
+__device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
   const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
@@ -718,10 +816,10 @@ __device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet&
     store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
-  const DevInstance& in = a.instances[h.inst];
-  const DevModel& m = a.models[in.model];
+  InstanceRef in = a.instances[h.inst];
+  ModelRef m = a.models[in.model];
   const uint32_t block = resolve_block(m, h.block);
-  const DustHipBlock b = m.blocks[block];
+  const DustHipBlock b = load_block(m.blocks + block);
   const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
   const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
   const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
@@ -744,7 +842,7 @@ __device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet&
   a.g.voxel_id[pix] = (h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16);
   const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
   const V3 hpm = xform_point(in.w2o, hpw);
-  const float* P = in.prev;
+  DUST_RO(float) P = in.prev;
   const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
   const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
   const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
@@ -756,7 +854,7 @@ __device__ __forceinline__ void primary_packet(const FrameArgs& a, const Packet&
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
 template <bool COUNT>
-__device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, uint32_t* cand, LaneStats& st_sun, LaneStats& st_ao,
+__device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st_sun, LaneStats& st_ao,
                                           float hitT, uint32_t normal_packed, V3 payload) {
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
@@ -768,7 +866,7 @@ __device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, u
     loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
              (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
     const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
-    const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
+    const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
     V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
                (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
     ad = normalize3(rotate_by_normal(n, ns));
@@ -800,27 +898,28 @@ __device__ __forceinline__ void ao_packet(const FrameArgs& a, const Packet& p, u
 
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = {0, 0, 0};
+  WorkCursor wc = cursor_begin();
   Packet p;
   while (next_packet(a, wc, p)) {
     float hitT;
     uint32_t npk;
     primary_packet<COUNT>(a, p, cand, st, true, hitT, npk);
   }
+  prof_end();
   flush_stats<COUNT>(a, 0, st);
 }
 
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = {0, 0, 0};
+  WorkCursor wc = cursor_begin();
   Packet p;
   while (next_packet(a, wc, p)) {
     const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
@@ -834,6 +933,7 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* _
     }
     ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, payload);
   }
+  prof_end();
   flush_stats<COUNT>(a, 0, st_sun);
   flush_stats<COUNT>(a, 1, st_ao);
 }
@@ -844,11 +944,11 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* _
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = {0, 0, 0};
+  WorkCursor wc = cursor_begin();
   Packet p;
   while (next_packet(a, wc, p)) {
     float hitT;
@@ -856,6 +956,7 @@ __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs* __restri
     primary_packet<COUNT>(a, p, cand, st, false, hitT, npk);
     ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
   }
+  prof_end();
   flush_stats<COUNT>(a, 0, st);
   flush_stats<COUNT>(a, 1, st_sun);
   flush_stats<COUNT>(a, 2, st_ao);
@@ -919,7 +1020,7 @@ __device__ V3 logluv_decode(uint32_t p) {  // spatial_hash.glsl:64-93
   return mk(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f));
 }
 // SpatialHashGet (spatial_hash.glsl:200-219): stamps last_accessed_frame of the entry it finds
-__device__ bool hash_get(const DevGI& gi, HashKey key, uint32_t frame_index, V3& value, uint32_t& count) {
+__device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t frame_index, V3& value, uint32_t& count) {
   const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
   value = mk(0, 0, 0);
   count = 0;
@@ -937,7 +1038,7 @@ __device__ bool hash_get(const DevGI& gi, HashKey key, uint32_t frame_index, V3&
   return false;
 }
 // SpatialHashInsert (spatial_hash.glsl:147-195)
-__device__ void hash_insert(const DevGI& gi, HashKey key, V3 value, uint32_t frame_index) {
+__device__ void hash_insert(const DUST_CONST_AS DevGI& gi, HashKey key, V3 value, uint32_t frame_index) {
   const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
   uint32_t i_min = 0, min_frame = 0;
   for (uint32_t i = 0; i < 3; ++i) {
@@ -986,10 +1087,10 @@ __device__ __forceinline__ V3 faceid2normal(uint32_t face) {  // normal.glsl:20-
   return mk(ax == 0 ? s : 0.0f, ax == 1 ? s : 0.0f, ax == 2 ? s : 0.0f);
 }
 // world-space surfel (brick centre + face) and hash key of a rough hit: final_gather.rchit:35-45, surfel.rchit:35-45
-__device__ void brick_surfel(const FrameArgs& a, const Hit& h, V3 o, V3 d, HashKey& key, DevSurfel& sf, uint32_t& avg_albedo) {
-  const DevInstance& in = a.instances[h.inst];
-  const DevModel& m = a.models[in.model];
-  const DustHipBlock b = m.blocks[resolve_block(m, h.block)];
+__device__ void brick_surfel(ArgsRef a, const Hit& h, V3 o, V3 d, HashKey& key, DevSurfel& sf, uint32_t& avg_albedo) {
+  InstanceRef in = a.instances[h.inst];
+  ModelRef m = a.models[in.model];
+  const DustHipBlock b = load_block(m.blocks + resolve_block(m, h.block));
   const V3 ctr = mk((float)b.x + 2.0f, (float)b.y + 2.0f, (float)b.z + 2.0f);
   const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
   const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
@@ -1007,11 +1108,11 @@ __device__ void brick_surfel(const FrameArgs& a, const Hit& h, V3 o, V3 d, HashK
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = {0, 0, 0};
+  WorkCursor wc = cursor_begin();
   Packet p;
   while (next_packet(a, wc, p)) {
     const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
@@ -1029,7 +1130,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
       loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
                (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
       const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
-      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[ny * 128u + nx];
+      const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
       const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
                        (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
       ad = normalize3(rotate_by_normal(n, ns));
@@ -1061,12 +1162,13 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
     rad = modulate_by_avg_albedo(rad, alb);
     store_radiance(a.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
   }
+  prof_end();
   flush_stats<COUNT>(a, 0, st);
 }
 
 // the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
 __global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
     const uint32_t o = a.gi.slot_owner[s];
     if (o != 0u) {
@@ -1080,11 +1182,11 @@ __global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
 // surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = {0, 0, 0};
+  WorkCursor wc = cursor_begin();
   Packet p;
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   while (next_packet(a, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
@@ -1103,7 +1205,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
     const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
     V3 cd = mk(0, 0, 1);
     if (live) {
-      const uint32_t tex = reinterpret_cast<const uint32_t*>(a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
+      const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
       const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
                        (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
       cd = normalize3(rotate_by_normal(n, ns));
@@ -1158,6 +1260,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
       a.gi.replacement[i] = repl;
     }
   }
+  prof_end();
   flush_stats<COUNT>(a, 0, st_sun);
   flush_stats<COUNT>(a, 1, st_cos);
 }
@@ -1165,7 +1268,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
 // ==================================================================== surfel pass, phase 2: apply in surfel order
 // Deterministic mode: one wavefront scans the requests 64 at a time and lane 0 applies them in index order.
 __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   const uint32_t lane = threadIdx.x;
   for (uint32_t base = 0; base < a.gi.pool_size; base += 64u) {
     const uint32_t i = base + lane;
@@ -1191,7 +1294,7 @@ __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs* __
 // Throughput mode: every surfel applies its own insert concurrently, as the reference's shaders do (racy by design,
 // spatial_hash.glsl:147-195 only claims the fingerprint atomically); results are statistically, not bitwise, repeatable.
 __global__ void k_surfel_apply_racy(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
     const DevHashRequest rq = a.gi.requests[j];
     if (rq.dir_flags & 0x100u) {
@@ -1206,7 +1309,7 @@ __global__ void k_surfel_apply_racy(const FrameArgs* __restrict__ ap) {
 
 // ==================================================================== N-frame mean (stands in for NRD)
 __global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
-  const FrameArgs& a = *ap;
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
   const uint32_t rows = a.row_end - a.row_begin;
   const size_t n = (size_t)rows * a.width;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1214,12 +1317,12 @@ __global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
     float w;
     const bool miss = a.g.depth[pix] == INFINITY;
     const V3 r = load_radiance(miss ? a.g.denoised : a.g.illuminance, pix, w);  // miss.rmiss writes the denoised target
-    float4 acc = reinterpret_cast<float4*>(a.g.accum)[pix];
+    f32x4 acc = ((DUST_GLOBAL_AS f32x4*)a.g.accum)[pix];
     const float k = 1.0f / (float)(a.accum_count + 1u);
-    if (a.accum_count == 0u) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.accum_count == 0u) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     acc.x += (r.x - acc.x) * k; acc.y += (r.y - acc.y) * k; acc.z += (r.z - acc.z) * k;
     acc.w = (float)(a.accum_count + 1u);
-    reinterpret_cast<float4*>(a.g.accum)[pix] = acc;
+    ((DUST_GLOBAL_AS f32x4*)a.g.accum)[pix] = acc;
     // what the denoiser would hand to auto exposure / tone mapping (img_illuminance_denoised, packed YCoCg);
     // miss pixels already carry the sky there (miss.rmiss:13)
     if (!miss) store_radiance(a.g.denoised, pix, mk(acc.x, acc.y, acc.z), w);
@@ -1317,7 +1420,7 @@ __global__ void __launch_bounds__(256) k_tone_map(ToneMapArgs t) {
     r = mk(rrt_odt_fit(r.x), rrt_odt_fit(r.y), rrt_odt_fit(r.z));
     const V3 o = mk((r.x * 1.60475f + r.y * -0.53108f) + r.z * -0.07367f, (r.x * -0.10208f + r.y * 1.10813f) + r.z * -0.00605f,
                     (r.x * -0.00327f + r.y * -0.07276f) + r.z * 1.07602f);
-    store_half4(t.dst, i, oetf(t.transfer_function, o.x), oetf(t.transfer_function, o.y), oetf(t.transfer_function, o.z), 1.0f);
+    store_half4((DUST_RW(uint16_t))t.dst, i, oetf(t.transfer_function, o.x), oetf(t.transfer_function, o.y), oetf(t.transfer_function, o.z), 1.0f);
   }
 }
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
@@ -1376,6 +1479,9 @@ hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t s) {
 }
 hipError_t configure_kernels(size_t max_lds) {
   hipError_t e;
+#ifdef DUST_PROFILE
+  max_lds -= sizeof(g_prof);  // the profiling build's static buckets come out of the same 160 KB
+#endif
   const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
                        (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>,
                        (const void*)k_primary_ao<false>, (const void*)k_primary_ao<true>,
@@ -1389,3 +1495,14 @@ hipError_t configure_kernels(size_t max_lds) {
 }
 
 }  // namespace dust
+
+#ifdef DUST_PROFILE
+// profiling build only (tools/kernel_sections.py): read and clear the section cycle counters
+extern "C" int dust_hip_profile_read(unsigned long long* out, int n) {
+  unsigned long long h[dust::kProfBuckets] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dust::g_prof_out), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < dust::kProfBuckets; ++i) out[i] = h[i];
+  unsigned long long z[dust::kProfBuckets] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_prof_out), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Where the traversal kernels' wave cycles go, by code section (s_memtime buckets compiled in with -DDUST_PROFILE).
+
+  python tools/kernel_sections.py --build      # here (cross-compiles dust_amd/libdust_hip_prof.so, which travels with gpurun)
+  gpurun -- 'python tools/kernel_sections.py'  # on the GPU box
+
+Buckets are INCLUSIVE wave cycles summed over all waves; the table prints exclusive shares. The timers themselves
+cost ~10 instructions per mark, so treat the shares as relative, not as absolute kernel time.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF_LIB = os.path.join(ROOT, "dust_amd", "libdust_hip_prof.so")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+if "--build" in sys.argv:
+    import __graft_entry__ as G
+    srcs = [os.path.join(G.CSRC, s) for s in G.HIP_SOURCES]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + G.HIPCC_FLAGS + ["-DDUST_PROFILE", "-I", G.CSRC] + srcs + ["-o", PROF_LIB],
+                          cwd=G.CSRC)
+    print("built", PROF_LIB)
+    sys.exit(0)
+
+os.environ["DUST_HIP_LIB"] = PROF_LIB
+import parity_util as P  # noqa: E402
+from dust_amd import _lib as L, api, synth  # noqa: E402
+
+NAMES = ["total", "grab", "cull", "trace_ray", "instance", "find_brick", "brick_test", "screen", "advance", "stage_roots"]
+
+
+def read(lib):
+    buf = (ctypes.c_ulonglong * 16)()
+    assert lib.dust_hip_profile_read(buf, 16) == 0
+    return [int(x) for x in buf]
+
+
+def report(title, b, ms):
+    tot = b[0] or 1
+    v = dict(zip(NAMES, b))
+    excl = {
+        "stage_roots": v["stage_roots"], "grab (work counters)": v["grab"], "cull (bundle vs instance boxes, sort)": v["cull"],
+        "candidate loop (slab tests, early exit)": v["trace_ray"] - v["instance"],
+        "instance setup + loop control": v["instance"] - v["find_brick"] - v["brick_test"] - v["screen"] - v["advance"],
+        "find_brick (root/mid lookup, mask load)": v["find_brick"], "brick test (4^3 DDA)": v["brick_test"],
+        "near-plane screen / neighbour queue": v["screen"], "advance (exit planes, cell step)": v["advance"],
+        "ray setup, shading, G-buffer stores": v["total"] - v["stage_roots"] - v["grab"] - v["cull"] - v["trace_ray"],
+    }
+    print(f"\n== {title}: {ms:.3f} ms (instrumented), {tot / 1e9:.2f} G wave-cycles")
+    for k, x in excl.items():
+        print(f"  {k:44s}{100.0 * x / tot:6.1f} %")
+
+
+def main():
+    lib = L.load()
+    lib.dust_hip_profile_read.restype = ctypes.c_int
+    lib.dust_hip_profile_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    W, H = 1920, 1080
+    ctx = api.Context(device=0)
+    data, info = synth.castle_scene()
+    desc = P.SceneDesc.from_vox(data)
+    scene = P.hip_scene(ctx, desc)
+    pipe = api.StandardPipeline(ctx, W, H)
+    pipe.set_noise(0, synth.stbn_scalar())
+    pipe.set_noise(5, synth.stbn_unitvec3_cosine())
+    eye = (122.0, 300.61, 54.45)
+    cam = api.make_camera(eye, api.look_at_rotation(eye, (0, 0, 0)), api.PinholeProjection())
+    sky = P.sky_state()
+    full = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
+    for f in range(1, 5):  # warm the surfel pool and the hash
+        pipe.render(scene, cam, sky, full, f, synth.frame_rand(1, f))
+    ctx.sync()
+    read(lib)
+    for title, passes, slot in (("k_primary_ao (fused primary + sun + AO)", L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION, 0),
+                                ("k_final_gather", L.PASS_FINAL_GATHER, 3), ("k_surfel_trace", L.PASS_SURFEL, 4)):
+        pipe.render(scene, cam, sky, passes, 5, synth.frame_rand(1, 5))
+        ctx.sync()
+        report(title, read(lib), pipe.pass_stats(slot).ms)
+
+
+if __name__ == "__main__":
+    main()
