@@ -281,23 +281,36 @@ struct MidCache {  // the 16-cell the ray was last in and its mid-node index (sa
   uint32_t mid;
 };
 
-// inv = 1/d per component (IEEE divide; +-inf for zero components, which take the other branch)
+// Ray against an axis-aligned box, conservative (slack on both ends). inv = 1/d per component (IEEE divide). A zero
+// direction component constrains nothing along t and instead requires the origin to lie in the slab (1e-3 margin);
+// it is handled with selects, not branches: this runs once per (ray, candidate instance) in a wave-uniform loop, and
+// divergent branches there cost more exec-mask bookkeeping than the arithmetic they skip.
 template <class PLo, class PHi>
 __device__ __forceinline__ bool slab_box(V3 o, V3 d, V3 inv_d, PLo lo, PHi hi, float& te, float& tx) {
   te = -INFINITY; tx = INFINITY;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, iv[3] = {inv_d.x, inv_d.y, inv_d.z};
+  bool ok = true;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    if (dd[a] != 0.0f) {
-      float inv = iv[a];
-      float t0 = (lo[a] - oo[a]) * inv, t1 = (hi[a] - oo[a]) * inv;
-      te = fmaxf(te, fminf(t0, t1));
-      tx = fminf(tx, fmaxf(t0, t1));
-    } else if (oo[a] < lo[a] - 1e-3f || oo[a] > hi[a] + 1e-3f) {
-      return false;
-    }
+    const float l = lo[a], h = hi[a];
+    const float t0 = (l - oo[a]) * iv[a], t1 = (h - oo[a]) * iv[a];
+    const bool nz = dd[a] != 0.0f;
+    te = fmaxf(te, nz ? fminf(t0, t1) : -INFINITY);
+    tx = fminf(tx, nz ? fmaxf(t0, t1) : INFINITY);
+    ok = ok && (nz || !(oo[a] < l - 1e-3f || oo[a] > h + 1e-3f));
   }
-  float slack = 1e-5f * (fabsf(te) + fabsf(tx)) + 1e-5f;
+  const float slack = 1e-5f * (fabsf(te) + fabsf(tx)) + 1e-5f;
+  return ok && !(te > tx + slack) && !(tx + slack < 0.0f);
+}
+// the same test when no ray of the wave has a zero direction component (the caller checked): 8 operations per axis
+template <class PLo, class PHi>
+__device__ __forceinline__ bool slab_box_nonzero(V3 o, V3 inv_d, PLo lo, PHi hi, float& te, float& tx) {
+  const float t0x = (lo[0] - o.x) * inv_d.x, t1x = (hi[0] - o.x) * inv_d.x;
+  const float t0y = (lo[1] - o.y) * inv_d.y, t1y = (hi[1] - o.y) * inv_d.y;
+  const float t0z = (lo[2] - o.z) * inv_d.z, t1z = (hi[2] - o.z) * inv_d.z;
+  te = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  tx = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+  const float slack = 1e-5f * (fabsf(te) + fabsf(tx)) + 1e-5f;
   return !(te > tx + slack) && !(tx + slack < 0.0f);
 }
 
@@ -629,9 +642,11 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   best.found = false;
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
+  ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // popcounts of ballots: uniform, but only we know
   const bool all = ncand > kMaxCand;
   const uint32_t n = all ? a.n_instances : ncand;
   const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const bool zero_axis = __any(active && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));  // e.g. the default sun (x == 0)
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     uint32_t ii;
     float lo[3], hi[3];
@@ -654,11 +669,11 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
     }
     bool go = active && !(any_hit && best.found);
     float te, tx;
-    if (go) go = slab_box(o, d, inv_d, lo, hi, te, tx);
-    if (go) {
-      const float limit = best.found ? best.t : tmax;
-      if (te * (1.0f - 2e-6f) > limit) go = false;
-    }
+    bool box;
+    if (zero_axis) box = slab_box(o, d, inv_d, lo, hi, te, tx);
+    else box = slab_box_nonzero(o, inv_d, lo, hi, te, tx);
+    const float limit = best.found ? best.t : tmax;
+    go = go & box & !(te * (1.0f - 2e-6f) > limit);
     if (!__any(go)) continue;
     if (go) {
       if (COUNT) st.instances_tested += 1;
