@@ -114,7 +114,7 @@ struct DustHipScene {
   DustHipContext* ctx = nullptr;
   std::vector<HostInstance> instances;
   std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
-  DeviceBuffer d_models, d_instances, d_root_table;
+  DeviceBuffer d_models, d_instances, d_root_table, d_boxes;
   std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
   uint32_t n_lds_models = 0;
   bool committed = false;
@@ -621,6 +621,14 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     HIP_TRY(s->d_root_table.upload(s->root_table.data(), s->root_table.size()));
     HIP_TRY(s->d_models.upload(dm.data(), dm.size() * sizeof(dust::DevModel)));
     HIP_TRY(s->d_instances.upload(di.data(), di.size() * sizeof(dust::DevInstance)));
+    // the world boxes again, packed 32 bytes apiece: what the packet culling streams through (coalesced) and the
+    // candidate loop reads with one scalar load
+    std::vector<dust::DevBox> boxes(di.size() + 1);
+    for (size_t i = 0; i < di.size(); ++i) {
+      for (int a = 0; a < 3; ++a) { boxes[i].lo[a] = di[i].wmin[a]; boxes[i].hi[a] = di[i].wmax[a]; }
+      boxes[i].pad0 = boxes[i].pad1 = 0.0f;
+    }
+    HIP_TRY(s->d_boxes.upload(boxes.data(), boxes.size() * sizeof(dust::DevBox)));
     s->committed = true;
     return DUST_OK;
   });
@@ -707,6 +715,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.n_instances = uint32_t(s->instances.size());
   a.n_lds_models = s->n_lds_models;
   a.root_table = static_cast<const uint8_t*>(s->d_root_table.p);
+  a.boxes = static_cast<const dust::DevBox*>(s->d_boxes.p);
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
   a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;

@@ -71,6 +71,11 @@ struct DevInstance {
   uint32_t pad;
 };
 
+struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, pad, hi.xyz, pad}
+  float lo[3], pad0;
+  float hi[3], pad1;
+};
+
 struct DevCamera {
   float col0[3], col1[3], col2[3], pos[3];
   float tan_half_fov, far_, near_;
@@ -117,6 +122,7 @@ struct FrameArgs {
   uint32_t n_models, n_instances;
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
+  DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DevCamera cam;
   float sky[56];
   DevGBuffer g;

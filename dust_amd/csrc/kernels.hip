@@ -547,67 +547,99 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
 }
 
 // ------------------------------------------------------------------ packet-level instance culling
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
-  return v;
+// Wave-wide min/max on the VALU cross-lane paths: four DPP steps leave each 16-lane row holding its own result,
+// v_readlane picks the four rows up. No LDS round trips (the ds_bpermute butterfly this replaces made six).
+// Call with all 64 lanes executing.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+  auto op = [](float x, float y) { return MAX ? fmaxf(x, y) : fminf(x, y); };
+  auto dpp = [](float x, int ctrl_is) {
+    const int xi = __float_as_int(x);
+    int r;
+    switch (ctrl_is) {
+      case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+      case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+      case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+      default: r = __builtin_amdgcn_update_dpp(xi, xi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __int_as_float(r);
+  };
+  v = op(v, dpp(v, 0));
+  v = op(v, dpp(v, 1));
+  v = op(v, dpp(v, 2));
+  v = op(v, dpp(v, 3));
+  const int vi = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s));
-  return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce<false>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<true>(v); }
 
-// Bounds the packet's rays by per-axis origin and direction intervals, tests all instance boxes
-// against that bundle 64 at a time and compacts the survivors (ascending instance id) into `cand`.
-// Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
-__device__ uint32_t cull_instances(ArgsRef a, bool active, V3 o, V3 d, float tmax, uint32_t* cand) {
-  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-  float omin[3], omax[3], dmin[3], dmax[3];
-  PROF_ENTER(P_CULL);
+// per-axis interval of a per-lane vector over the wave's active rays
+struct Range3 { float lo[3], hi[3]; };
+__device__ __forceinline__ Range3 wave_range(bool active, V3 v) {
+  const float vv[3] = {v.x, v.y, v.z};
+  Range3 r;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    omin[k] = wave_min(active ? oo[k] : INFINITY);
-    omax[k] = wave_max(active ? oo[k] : -INFINITY);
-    dmin[k] = wave_min(active ? dd[k] : INFINITY);
-    dmax[k] = wave_max(active ? dd[k] : -INFINITY);
+    r.lo[k] = wave_min(active ? vv[k] : INFINITY);
+    r.hi[k] = wave_max(active ? vv[k] : -INFINITY);
   }
-  const float T = wave_max(active ? tmax : 0.0f);
-  if (!(omin[0] <= omax[0])) { PROF_LEAVE(P_CULL); return 0; }  // no active lane
+  return r;
+}
+__device__ __forceinline__ Range3 point_range(V3 v) {  // every ray shares v (the camera position, the sun direction)
+  Range3 r;
+  r.lo[0] = r.hi[0] = v.x; r.lo[1] = r.hi[1] = v.y; r.lo[2] = r.hi[2] = v.z;
+  return r;
+}
+
+// Tests all instance boxes, 64 at a time, against the bundle of rays {o in org, d in dir, 0 <= t <= tmax} and
+// compacts the survivors into `cand`, sorted by the earliest time any ray of the bundle can enter them.
+// Returns the number of survivors; a count above kMaxCand means "list overflowed, walk every instance".
+// Per axis:  exists o, d:  lo <= o + d t <= hi   <=>   org.lo + dir.lo t <= hi  and  org.hi + dir.hi t >= lo   (t >= 0).
+// The interval ends are the same in every lane, so each case split below is a select on precomputed per-packet
+// values (reciprocals included): no division and no branch inside the loop.
+__device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org, const Range3& dir, float tmax, uint32_t* cand) {
+  PROF_ENTER(P_CULL);
+  if (!any_active) { PROF_LEAVE(P_CULL); return 0; }
+  // r1/r2: reciprocal of the direction interval's ends (0 where the end is 0); s*: which bound the quotient feeds
+  float r1[3], r2[3];
+  bool up1[3], lo1[3], z1[3], lo2[3], up2[3], z2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float d1 = dir.lo[k], d2 = dir.hi[k];
+    z1[k] = d1 == 0.0f; up1[k] = d1 > 0.0f; lo1[k] = d1 < 0.0f;
+    z2[k] = d2 == 0.0f; lo2[k] = d2 > 0.0f; up2[k] = d2 < 0.0f;
+    r1[k] = z1[k] ? 0.0f : 1.0f / d1;
+    r2[k] = z2[k] ? 0.0f : 1.0f / d2;
+  }
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_inst = a.n_instances;
   uint32_t n = 0;
-  for (uint32_t base = 0; base < a.n_instances; base += 64) {
+  for (uint32_t base = 0; base < n_inst; base += 64) {
     const uint32_t i = base + lane;
-    bool pass = false;
-    float t_lo = 0.0f;
-    float wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
-    if (i < a.n_instances) {
-      InstanceRef in = a.instances[i];
+    const uint32_t ic = i < n_inst ? i : n_inst - 1u;  // clamp instead of branching around the loads
+    const f32x4 blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]), bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]);
+    const float wlo[3] = {blo.x, blo.y, blo.z}, whi[3] = {bhi.x, bhi.y, bhi.z};
+    float t_lo = 0.0f, t_hi = tmax;
+    bool pass = i < n_inst;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { wlo[k] = in.wmin[k]; whi[k] = in.wmax[k]; }
-      float t_hi = T;
-      t_lo = 0.0f;
-      pass = true;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        // exists o in [omin,omax], d in [dmin,dmax]: lo <= o + d t <= hi
-        //   <=>  omin + dmin t <= hi  and  omax + dmax t >= lo      (t >= 0)
-        const float c1 = whi[k] - omin[k], c2 = wlo[k] - omax[k];
-        if (dmin[k] > 0.0f) t_hi = fminf(t_hi, c1 / dmin[k]);
-        else if (dmin[k] < 0.0f) t_lo = fmaxf(t_lo, c1 / dmin[k]);
-        else if (c1 < 0.0f) pass = false;
-        if (dmax[k] > 0.0f) t_lo = fmaxf(t_lo, c2 / dmax[k]);
-        else if (dmax[k] < 0.0f) t_hi = fminf(t_hi, c2 / dmax[k]);
-        else if (c2 > 0.0f) pass = false;
-      }
-      if (t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f) pass = false;
+    for (int k = 0; k < 3; ++k) {
+      const float c1 = whi[k] - org.lo[k], c2 = wlo[k] - org.hi[k];
+      const float q1 = c1 * r1[k], q2 = c2 * r2[k];
+      t_hi = fminf(t_hi, fminf(up1[k] ? q1 : INFINITY, up2[k] ? q2 : INFINITY));
+      t_lo = fmaxf(t_lo, fmaxf(lo1[k] ? q1 : 0.0f, lo2[k] ? q2 : 0.0f));
+      pass = pass & !(z1[k] & (c1 < 0.0f)) & !(z2[k] & (c2 > 0.0f));
     }
+    pass = pass & !(t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f);
     const uint64_t bal = __ballot(pass);
     if (pass) {
       const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
       // one word per candidate: earliest entry of any ray of the packet (upper 16 bits of the float, i.e. rounded
-      // DOWN: stays conservative) above the 16-bit instance id -- unsigned compare orders by entry time, then id
-      if (pos < kMaxCand) cand[pos] = (__float_as_uint(fmaxf(t_lo, 0.0f)) & 0xFFFF0000u) | (i & 0xFFFFu);
+      // DOWN: stays conservative, and absorbs the reciprocal's rounding) above the 16-bit instance id -- unsigned
+      // compare orders by entry time, then id
+      if (pos < kMaxCand) cand[pos] = (__float_as_uint(t_lo) & 0xFFFF0000u) | (i & 0xFFFFu);
     }
     n += (uint32_t)__popcll(bal);
   }
@@ -662,10 +694,10 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
       if (__all(settled)) break;
     }
     ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)ii);  // wave-uniform by construction: say so, so that the
-    {                                                         // instance and model records come through scalar loads
-      InstanceRef in = a.instances[ii];
+    {                                                         // box, instance and model records come through scalar loads
+      const DUST_CONST_AS DevBox& bx = a.boxes[ii];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { lo[k] = in.wmin[k]; hi[k] = in.wmax[k]; }
+      for (int k = 0; k < 3; ++k) { lo[k] = bx.lo[k]; hi[k] = bx.hi[k]; }
     }
     bool go = active && !(any_hit && best.found);
     float te, tx;
@@ -813,7 +845,7 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
   const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
-  const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, p.valid, o, d, a.cam.far_, cand);
+  const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
   Hit h;
   h.found = false;
   if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
@@ -890,13 +922,14 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   // k = 1 the ambient occlusion ray (closest hit within 8 units, ambient_occlusion.rgen:52-65)
   const bool sun_live = live && dot3(sun, n) > 0.0f;
   const V3 sd = normalize3(sun);
+  const Range3 org = wave_range(live, loc);  // both rays leave from the same points (sun_live is a subset of live)
   Hit h;
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
     const bool act = k == 0 ? sun_live : live;
     const V3 dir = k == 0 ? sd : ad;
     const float tmax = k == 0 ? 10000.0f : 8.0f;
-    const uint32_t ncand = cull_instances(a, act, loc, dir, tmax, cand);
+    const uint32_t ncand = cull_instances(a, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
     LaneStats cur = {0, 0, 0, 0, 0, 0};
     trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
@@ -1151,7 +1184,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
       ad = normalize3(rotate_by_normal(n, ns));
     }
     Hit h;
-    const uint32_t ncand = cull_instances(a, live, loc, ad, a.cam.far_, cand);
+    const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
     trace_ray<2, COUNT>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
     __builtin_amdgcn_wave_barrier();
     if (!live) continue;
@@ -1229,11 +1262,12 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
     const bool sun_live = live && dot3(sun, n) > 0.0f;
     const V3 sd = normalize3(sun);
     Hit h;
+    const Range3 orgs = wave_range(live, org);
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
       const bool act = k == 0 ? sun_live : live;
       const V3 dir = k == 0 ? sd : cd;
-      const uint32_t ncand = cull_instances(a, act, org, dir, 10000.0f, cand);
+      const uint32_t ncand = cull_instances(a, __any(act), orgs, k == 0 ? point_range(sd) : wave_range(live, cd), 10000.0f, cand);
       LaneStats cur = {0, 0, 0, 0, 0, 0};
       trace_ray<3, COUNT>(a, act, org, dir, 0.1f, 10000.0f, k == 0, cand, ncand, h, cur);
       if (COUNT) add_stats(k == 0 ? st_sun : st_cos, cur);
