@@ -677,7 +677,9 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // popcounts of ballots: uniform, but only we know
   const bool all = ncand > kMaxCand;
   const uint32_t n = all ? a.n_instances : ncand;
-  const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
+  // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
+  const V3 inv_d = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
   const bool zero_axis = __any(active && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));  // e.g. the default sun (x == 0)
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     uint32_t ii;
