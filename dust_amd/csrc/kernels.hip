@@ -164,12 +164,17 @@ __device__ __forceinline__ V3 xyz_to_acescg(V3 v) {  // color.glsl:24-31 (column
             (-0.66366285f * v.x + 1.6153315f * v.y) + 0.016756356f * v.z,
             (0.011721907f * v.x + -0.0082844375f * v.y) + 0.9883947f * v.z);
 }
+// The sky model is radiance (fp16 planes, 1e-3 parity tolerance), not geometry: it runs on the hardware's 1-ulp
+// transcendentals (v_exp_f32, v_rcp_f32, v_sqrt_f32) instead of the correctly rounded library routines, and
+// pow(x, 1.5) is x * sqrt(x). About a fifth of the instructions of the libm version per sky evaluation.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ float sky_internal(DUST_RO(float) c, float cos_theta, float gamma, float cos_gamma) {  // sky.glsl:1-15
-  float expM = expf(c[4] * gamma);
+  float expM = __expf(c[4] * gamma);
   float rayM = cos_gamma * cos_gamma;
-  float mieM = (1.0f + rayM) / powf((1.0f + c[8] * c[8]) - (2.0f * c[8]) * cos_gamma, 1.5f);
-  float zenith = sqrtf(cos_theta);
-  return (1.0f + c[0] * expf(c[1] / (cos_theta + 0.01f))) *
+  float base = (1.0f + c[8] * c[8]) - (2.0f * c[8]) * cos_gamma;
+  float mieM = fast_div(1.0f + rayM, base * __builtin_amdgcn_sqrtf(base));
+  float zenith = __builtin_amdgcn_sqrtf(cos_theta);
+  return (1.0f + c[0] * __expf(fast_div(c[1], cos_theta + 0.01f))) *
          ((((c[2] + c[3] * expM) + c[5] * rayM) + c[6] * mieM) + c[7] * zenith);
 }
 __device__ V3 sky_radiance(DUST_RO(float) s, V3 dir) {  // sky.glsl:18-79
@@ -211,9 +216,21 @@ __device__ __forceinline__ bool grid_clear(uint32_t m1, uint32_t m2, uint32_t hi
 __device__ __forceinline__ uint32_t encode_index(int px, int py, int pz) {  // hit.rint:30-32 on u8vec3
   return (((uint32_t)px << 4) | ((uint32_t)py << 2) | ((uint32_t)pz & 0xFFu)) & 0xFFu;
 }
-__device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, float& t_min, float& t_max) {  // hit.rint:20-28
-  float ax = (0.0f - o.x) / d.x, ay = (0.0f - o.y) / d.y, az = (0.0f - o.z) / d.z;
-  float bx = (4.0f - o.x) / d.x, by = (4.0f - o.y) / d.y, bz = (4.0f - o.z) / d.z;
+// a / b, correctly rounded, given y = RN(1 / b) (an IEEE division done once per instance and axis): Markstein's
+// sequence q0 = RN(a y), r = a - b q0 (exact in an FMA), q = RN(q0 + r y) yields RN(a / b) whenever nothing under- or
+// overflows. b == 0 (y infinite) takes q0 = a * (+-inf), which is what a / (+-0) is, NaN for a == 0 included.
+// Four instructions against the ten of the hardware division sequence, bit for bit the same quotient; direction
+// components in the denormal range (1 / b overflowing) are the one input class where it would differ.
+__device__ __forceinline__ float div_by(float a, float b, float y, bool y_inf) {
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-b, q0, a);
+  const float q = __builtin_fmaf(r, y, q0);
+  return y_inf ? q0 : q;
+}
+__device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, V3 rd, float& t_min, float& t_max) {  // hit.rint:20-28, rd = 1 / d
+  const bool ix = fabsf(rd.x) == INFINITY, iy = fabsf(rd.y) == INFINITY, iz = fabsf(rd.z) == INFINITY;
+  float ax = div_by(0.0f - o.x, d.x, rd.x, ix), ay = div_by(0.0f - o.y, d.y, rd.y, iy), az = div_by(0.0f - o.z, d.z, rd.z, iz);
+  float bx = div_by(4.0f - o.x, d.x, rd.x, ix), by = div_by(4.0f - o.y, d.y, rd.y, iy), bz = div_by(4.0f - o.z, d.z, rd.z, iz);
   t_min = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
   t_max = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 }
@@ -223,7 +240,7 @@ __device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, float& t_min, float
 template <int RT>
 __device__ bool brick_intersect(V3 o, V3 d, V3 tc, uint32_t m1, uint32_t m2, float tmin, float& t_out, uint32_t& voxel) {
   float t0, t1;
-  intersect_aabb04(o, d, t0, t1);
+  intersect_aabb04(o, d, tc, t0, t1);
   if (t0 >= t1) return false;
   if (RT >= 2) {
     if (m1 == 0 && m2 == 0) return false;

@@ -54,3 +54,15 @@ def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path):
     assert np.array_equal(depth.view(np.uint32), pipe.read_plane(L.PLANE_DEPTH).view(np.uint32))
     assert np.array_equal(vid, pipe.read_plane(L.PLANE_VOXEL_ID))
     assert np.array_equal(ill, pipe.read_plane(L.PLANE_ILLUMINANCE))
+
+
+def test_shared_reciprocal_division_is_ieee_division():
+    """kernels.hip div_by (Markstein's sequence on an exactly rounded reciprocal) == IEEE a / b, bit for bit."""
+    src = os.path.join(ROOT, "tests", "cpp", "division_identity_test.c")
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "division_identity_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", src, "-o", exe, "-lm"])
+    out = subprocess.run([exe, "20000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "bad 0" in out.stdout
