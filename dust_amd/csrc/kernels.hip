@@ -36,13 +36,20 @@ __device__ __forceinline__ void prof_mark(int idx, bool leave) {
   if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)ex) - 1))
     atomicAdd(&g_prof[threadIdx.x >> 6][idx], leave ? now : (0ull - now));
 }
+__device__ __forceinline__ void prof_count(int idx, unsigned long long n) {
+  const unsigned long long ex = __ballot(1);
+  if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)ex) - 1)) atomicAdd(&g_prof[threadIdx.x >> 6][idx], n);
+}
 #define PROF_ENTER(i) prof_mark(i, false)
 #define PROF_LEAVE(i) prof_mark(i, true)
+#define PROF_COUNT(i, n) prof_count(i, n)
 #else
 #define PROF_ENTER(i)
 #define PROF_LEAVE(i)
+#define PROF_COUNT(i, n)
 #endif
-enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE };
+enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
+       P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };  // the P_N_* buckets count events, not cycles
 
 namespace {
 
@@ -453,6 +460,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   mc.key = -1;
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   for (int guard = 0; guard < 200000; ++guard) {
+    PROF_COUNT(P_N_STEPS, 1);
     const bool is_main = pending == 0;
     int c[3] = {ijk[0], ijk[1], ijk[2]};
     if (is_main) {
@@ -692,6 +700,8 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   if (COUNT && active) st.rays += 1;
   ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // popcounts of ballots: uniform, but only we know
+  PROF_COUNT(P_N_TRACES, 1);
+  PROF_COUNT(P_N_CAND, ncand);
   const bool all = ncand > kMaxCand;
   const uint32_t n = all ? a.n_instances : ncand;
   // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
@@ -725,7 +735,9 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
     else box = slab_box_nonzero(o, inv_d, lo, hi, te, tx);
     const float limit = best.found ? best.t : tmax;
     go = go & box & !(te * (1.0f - 2e-6f) > limit);
+    PROF_COUNT(P_N_CAND_ITER, 1);
     if (!__any(go)) continue;
+    PROF_COUNT(P_N_VISITS, 1);
     if (go) {
       if (COUNT) st.instances_tested += 1;
       InstanceRef in = a.instances[ii];
