@@ -125,6 +125,7 @@ struct DustHipPipeline {
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   DeviceBuffer noise0, noise5, counters, stats;
+  uint32_t counter_parity[4] = {0, 0, 0, 0};  // per pass kind: which of its two counter sets the next launch uses
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
@@ -647,7 +648,8 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
       HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
       HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
     }
-    HIP_TRY(p->counters.alloc(4 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
+    HIP_TRY(p->counters.alloc(8 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(p->counters.p, 0, 8 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
     HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
     HIP_TRY(p->exposure.alloc(257 * 4));
     HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
@@ -688,6 +690,16 @@ static DustStatus upload_args(DustHipPipeline* p, const dust::FrameArgs& a, hipS
   p->next_slot = (slot + 1) % DustHipPipeline::kArgSlots;
   *dev = d;
   return DUST_OK;
+}
+
+// Work counters without a memset per launch: every pass kind owns two sets; a launch pulls tiles from one and its
+// first workgroup zeroes the other, which is the set the next launch of that kind (stream-ordered behind it) will use.
+static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a) {
+  uint32_t* base = static_cast<uint32_t*>(p->counters.p) + size_t(kind) * 2 * dust::kRegions * dust::kCounterStride;
+  const uint32_t par = p->counter_parity[kind];
+  a.work_counters = base + size_t(par) * dust::kRegions * dust::kCounterStride;
+  a.next_work_counters = base + size_t(par ^ 1u) * dust::kRegions * dust::kCounterStride;
+  p->counter_parity[kind] = par ^ 1u;
 }
 
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
@@ -764,8 +776,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !std::getenv("DUST_HIP_NO_FUSE");
   p->fused_last = fuse;
   if (fuse) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p);
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
+    take_counters(p, 0, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     const dust::FrameArgs* d = nullptr;
@@ -775,8 +786,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p);
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
+    take_counters(p, 0, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     const dust::FrameArgs* d = nullptr;
@@ -786,8 +796,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 1 * dust::kRegions * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
+    take_counters(p, 1, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
     const dust::FrameArgs* d = nullptr;
@@ -797,8 +806,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
-    a.work_counters = static_cast<uint32_t*>(p->counters.p) + 2 * dust::kRegions * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(a.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
+    take_counters(p, 2, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
     const dust::FrameArgs* d = nullptr;
@@ -811,8 +819,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     dust::FrameArgs b = a;  // 64 consecutive surfels per wavefront: one row of "tiles"
     b.tiles_x = (p->gi_pool_size + 63) / 64;
     b.tiles_y = 1;
-    b.work_counters = static_cast<uint32_t*>(p->counters.p) + 3 * dust::kRegions * dust::kCounterStride;
-    HIP_TRY(hipMemsetAsync(b.work_counters, 0, dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
+    take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
     const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));

@@ -129,7 +129,8 @@ struct FrameArgs {
   uint32_t width, height;
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
-  DUST_RW(uint32_t) work_counters;    // 8 per-region tile counters, kCounterStride apart (zeroed before launch)
+  DUST_RW(uint32_t) work_counters;    // 8 per-band tile counters, kCounterStride apart, zero at launch
+  DUST_RW(uint32_t) next_work_counters;  // the set the next launch of this pass kind uses: this launch zeroes it
   DUST_RO(uint8_t) noise0;     // 128*128 R8 slice for this frame, or null
   DUST_RO(uint8_t) noise5;     // 128*128 RGBA8 slice for this frame, or null
   uint32_t rand, frame_index;

@@ -825,6 +825,7 @@ __device__ __forceinline__ void prof_end() {
 }
 __device__ __forceinline__ void stage_roots(ArgsRef a) {
   prof_begin();
+  if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
   const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
