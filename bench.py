@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="castle stand-in scale (1.0 = BASELINE config)")
     ap.add_argument("--workload", choices=["primary_ao", "gi"], default="primary_ao",
                     help="primary_ao = BASELINE configs[1] (the headline); gi = configs[2]: all four passes + accumulation")
+    ap.add_argument("--gi-shard", choices=["samples", "bands"], default="samples",
+                    help="--workload gi on N GPUs: samples = one whole frame per GPU, independent GI state per GPU; bands = ONE "
+                         "frame cut into row bands, hash and surfel pool kept identical on every GPU by the exchange of "
+                         "dust_hip_pipeline_gi_exchange (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
     return ap.parse_args()
@@ -106,6 +110,13 @@ def main():
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
         pipe.set_noise(0, synth.stbn_scalar())
         args.no_cpu_baseline = True
+    gi_bands = gi_mode and args.gi_shard == "bands"
+    if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
+        per_rows = sharding.gi_band_rows(world, H)
+        rows = (min(H, rank * per_rows), min(H, (rank + 1) * per_rows))
+        Hband = per_rows
+        ex = pipe.gi_exchange(world * per_rows)
+        ex_owner, ex_touched, ex_merged = sharding.alias_exchange_buffers(ex)
 
     # framebuffer gather target: the illuminance plane lives in a torch tensor so RCCL can move it
     band_px = W * Hband
@@ -114,15 +125,32 @@ def main():
     gather = sharding.AsyncGather(dist, band)  # step k's gather overlaps step k+1's rendering
     hip = ctypes.CDLL("libamdhip64.so.7")  # resolves to the copy torch / libdust_hip already loaded (same SONAME)
 
-    def fill(buf):  # device-to-device copy of the finished frame into a torch tensor, on the launch stream
-        rc = hip.hipMemcpyAsync(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ill_ptr), ctypes.c_size_t(band_px * 8),
-                                ctypes.c_int(3), ctypes.c_void_p(stream))
+    own_rows = rows[1] - rows[0]
+
+    def fill(buf):  # device-to-device copy of the finished frame (or band) into a torch tensor, on the launch stream
+        rc = hip.hipMemcpyAsync(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ill_ptr + rows[0] * W * 8),
+                                ctypes.c_size_t(own_rows * W * 8), ctypes.c_int(3), ctypes.c_void_p(stream))
         assert rc == 0, rc
 
+    pix_stats = []
+
     def step(k, count=False):
-        frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
-        pipe.render(scene, cam, sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=frame_index,
-                    rand=synth.frame_rand(1, frame_index))
+        cs = L.PASS_COUNT_STATS if count else 0
+        if gi_bands:
+            frame_index = 1 + k  # every rank works on the same frame
+            rnd = synth.frame_rand(1, frame_index)
+            pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_GI_SHARDED
+            pipe.render(scene, cam, sky, pix | cs, frame_index=frame_index, rand=rnd, rows=rows)
+            if count:  # the second call restarts the counters: keep the pixel passes' now
+                torch.cuda.synchronize()
+                pix_stats[:] = [pipe.pass_stats(i) for i in range(4)]
+            sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
+                                      lambda: pipe.gi_export(*rows), lambda: pipe.gi_import(rows[0], rows[1], frame_index))
+            pipe.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_ACCUMULATE | L.PASS_GI_SHARDED | cs, frame_index=frame_index,
+                        rand=rnd, rows=rows)
+        else:
+            frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
+            pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         if world > 1:
             gather.submit(fill)  # copy + asynchronous gather to rank 0
 
@@ -136,11 +164,16 @@ def main():
     step(0, count=True)
     barrier()
     st = [pipe.pass_stats(i) for i in range(6 if gi_mode else 3)]
+    if gi_bands:
+        st[:4] = pix_stats
     rays_rank = sum(x.rays for x in st)
+    if gi_bands and rank != 0:
+        rays_rank -= st[4].rays + st[5].rays  # the replicated surfel pass counts once
     # self-check of the plumbing the gather relies on (untimed): the torch tensor sees the library's plane
     fill(band)
     torch.cuda.synchronize()
-    assert torch.equal(band.cpu().view(torch.int16), torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE).view(np.int16)))
+    assert torch.equal(band[:own_rows].cpu().view(torch.int16),
+                       torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE)[rows[0]:rows[1]].view(np.int16)))
     names = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_sun", "surfel_cosine")
     hit_px = st[0].hits
     miss_px = st[0].rays - st[0].hits
@@ -251,13 +284,16 @@ def main():
         "metric": "Mrays/s at 1920x1080 1spp castle.vox (primary + sun-shadow + AO rays)" if not gi_mode else
                   "Mrays/s at 1920x1080 castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
         "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if gi_bands else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("castle.vox stand-in (synth.castle_scene seed 0xD057), 1920x1080 per GPU, "
                                 + ("1 GI frame: primary+shadow+AO+final gather+surfel" if gi_mode else "1spp primary+shadow+AO"))
                    if args.scale == 1.0 else f"castle stand-in at scale {args.scale}",
-                   "frame": [W, H], "spp_per_step": world,
-                   "parallelism": f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",
+                   "frame": [W, H], "spp_per_step": 1 if gi_bands else world,
+                   "parallelism": (f"bands x{world}: one frame in {world} row bands, identical hash + surfel pool on every GPU "
+                                   "(all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of winning surfels), "
+                                   "surfel pass replicated, RCCL gather of the bands to rank 0") if gi_bands else
+                                  f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",
                    "models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": desc.n_bricks(), "scene_build_s": round(t_load, 3),
                    "rays_per_step": {n: int(x.rays) for n, x in zip(names, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},

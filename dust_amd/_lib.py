@@ -27,6 +27,7 @@ PASS_SURFEL = 1 << 3
 PASS_ACCUMULATE = 1 << 4
 PASS_COUNT_STATS = 1 << 16
 PASS_GI_ORDERED = 1 << 17
+PASS_GI_SHARDED = 1 << 18
 CONTEXT_TIMING = 1
 
 PLANE_ILLUMINANCE, PLANE_DENOISED, PLANE_ALBEDO, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOTION, PLANE_VOXEL_ID, PLANE_ACCUM, PLANE_OUTPUT = range(9)
@@ -69,6 +70,11 @@ class FrameParams(C.Structure):
 class ToneMapParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("transfer_function", C.c_uint32), ("color_space_conversion", C.c_float * 9),
                 ("min_log_luminance", C.c_float), ("max_log_luminance", C.c_float), ("time_coefficient", C.c_float)]
+
+
+class GiExchange(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("pool_size", C.c_uint32), ("width", C.c_uint32), ("touched_rows", C.c_uint32),
+                ("slot_owner", C.c_void_p), ("touched", C.c_void_p), ("merged", C.c_void_p)]
 
 
 class PassStats(C.Structure):
@@ -133,6 +139,9 @@ SYMBOLS = {
     "dust_hip_pipeline_read_plane": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "dust_hip_pipeline_configure_gi": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "dust_hip_pipeline_read_gi": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
+    "dust_hip_pipeline_gi_exchange": (C.c_int, [_P, C.c_uint32, C.POINTER(GiExchange)]),
+    "dust_hip_gi_export": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "dust_hip_gi_import": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "dust_hip_tone_map": (C.c_int, [_P, C.POINTER(ToneMapParams)]),
     "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),

@@ -352,6 +352,20 @@ class StandardPipeline:
         self._gi = (hash_capacity, surfel_pool_size)
         L.check(self._lib.dust_hip_pipeline_configure_gi(self._h, hash_capacity, surfel_pool_size))
 
+    def gi_exchange(self, padded_rows=None):
+        """Device buffers of the multi-GPU GI exchange (dust_hip.h): a _lib.GiExchange with raw device pointers."""
+        out = L.GiExchange()
+        out.struct_size = C.sizeof(L.GiExchange)
+        L.check(self._lib.dust_hip_pipeline_gi_exchange(self._h, padded_rows or self.height, C.byref(out)))
+        self._gi = (self._gi[0] if getattr(self, "_gi", None) else 32 * 1024 * 1024, out.pool_size)
+        return out
+
+    def gi_export(self, row_begin, row_end):
+        L.check(self._lib.dust_hip_gi_export(self._h, row_begin, row_end))
+
+    def gi_import(self, row_begin, row_end, frame_index):
+        L.check(self._lib.dust_hip_gi_import(self._h, row_begin, row_end, frame_index))
+
     def read_gi(self):
         """(hash entries as uint32[capacity+2, 3], surfel pool as structured array)"""
         cap, pool = self._gi

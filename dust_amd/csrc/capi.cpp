@@ -20,7 +20,9 @@ namespace dust {
 hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
+hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t);
+hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t);
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
@@ -66,7 +68,8 @@ struct DeviceBuffer {
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-  ~DeviceBuffer() { if (p) (void)hipFree(p); }
+  ~DeviceBuffer() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
   hipError_t alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
     bytes = n;
@@ -129,6 +132,8 @@ struct DustHipPipeline {
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
+  DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
+  uint32_t gi_touched_rows = 0;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
   uint32_t noise0_layers = 0, noise5_layers = 0;
   uint32_t accum_count = 0;
@@ -712,8 +717,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     return fail(DUST_ERR_NOT_READY, "blue-noise texture 5 (unitvec3_cosine) not loaded");  // standard.rs:254
   if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->noise0.p)
     return fail(DUST_ERR_NOT_READY, "blue-noise texture 0 (scalar) not loaded");
-  if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && (fp->row_begin != 0 || (fp->row_end != 0 && fp->row_end != p->height)))
-    return fail(DUST_ERR_UNSUPPORTED, "the hash-fed GI passes need the whole frame on one device (surfel pool exchange not built)");
+  const bool sharded = (fp->passes & DUST_PASS_GI_SHARDED) != 0;
+  if (!sharded && (fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && (fp->row_begin != 0 || (fp->row_end != 0 && fp->row_end != p->height)))
+    return fail(DUST_ERR_UNSUPPORTED, "a GI pass on a row band needs DUST_PASS_GI_SHARDED and the exchange of dust_hip_pipeline_gi_exchange");
+  if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && (fp->passes & DUST_PASS_SURFEL))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "DUST_PASS_GI_SHARDED: the surfel pass runs after the exchange, in its own call");
+  if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && !p->gi_touched.p)
+    return fail(DUST_ERR_NOT_READY, "DUST_PASS_GI_SHARDED: call dust_hip_pipeline_gi_exchange first");
   if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->gi_hash.p) {
     DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
     if (gs != DUST_OK) return gs;
@@ -806,12 +816,17 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
+    if (sharded) {  // pixels that stamp nothing must read 0 after the all-gather
+      a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
+      a.gi.merged = static_cast<dust::DevSurfel*>(p->gi_merged.p);
+      HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
+    }
     take_counters(p, 2, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
     const dust::FrameArgs* d = nullptr;
     { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_final_gather(a, d, grid, block, count, st));
+    HIP_TRY(dust::launch_final_gather(a, d, grid, block, count, !sharded, st));
     HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
   }
@@ -892,7 +907,61 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;
+  p->gi_touched_rows = 0;  // the exchange buffers follow the pool size: dust_hip_pipeline_gi_exchange re-creates them
+  p->gi_touched.release();
+  p->gi_merged.release();
   return DUST_OK;
+}
+DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_rows, DustHipGiExchange* out) {
+  if (!p || !out || padded_rows < p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "padded_rows must cover the frame");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  if (!p->gi_hash.p) {
+    DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
+    if (gs != DUST_OK) return gs;
+  }
+  if (!p->gi_touched.p || p->gi_touched_rows != padded_rows) {
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(p->gi_touched.alloc(size_t(padded_rows) * p->width * 4));
+    HIP_TRY(hipMemset(p->gi_touched.p, 0, size_t(padded_rows) * p->width * 4));
+    HIP_TRY(p->gi_merged.alloc(size_t(p->gi_pool_size) * 16));
+    HIP_TRY(hipMemset(p->gi_merged.p, 0, size_t(p->gi_pool_size) * 16));
+    p->gi_touched_rows = padded_rows;
+  }
+  out->pool_size = p->gi_pool_size;
+  out->width = p->width;
+  out->touched_rows = padded_rows;
+  out->slot_owner = p->gi_owner.p;
+  out->touched = p->gi_touched.p;
+  out->merged = p->gi_merged.p;
+  return DUST_OK;
+}
+static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uint32_t row_end, uint32_t frame_index, bool import) {
+  if (!p || !p->gi_touched.p) return fail(DUST_ERR_NOT_READY, "call dust_hip_pipeline_gi_exchange first");
+  if (row_begin >= row_end || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  dust::FrameArgs a{};
+  a.width = p->width; a.height = p->height;
+  a.row_begin = row_begin; a.row_end = row_end;
+  a.frame_index = frame_index;
+  a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);
+  a.gi.hash_capacity = p->gi_capacity;
+  a.gi.pool = static_cast<dust::DevSurfel*>(p->gi_pool.p);
+  a.gi.pool_size = p->gi_pool_size;
+  a.gi.slot_owner = static_cast<uint32_t*>(p->gi_owner.p);
+  a.gi.pixel_surfel = static_cast<dust::DevSurfel*>(p->gi_pixel_surfel.p);
+  a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
+  a.gi.merged = static_cast<dust::DevSurfel*>(p->gi_merged.p);
+  const dust::FrameArgs* d = nullptr;
+  { DustStatus us = upload_args(p, a, p->ctx->stream, &d); if (us != DUST_OK) return us; }
+  HIP_TRY(import ? dust::launch_gi_import(d, p->ctx->stream) : dust::launch_gi_export(d, p->ctx->stream));
+  HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], p->ctx->stream));
+  return DUST_OK;
+}
+DustStatus dust_hip_gi_export(DustHipPipeline* p, uint32_t row_begin, uint32_t row_end) {
+  return gi_exchange_launch(p, row_begin, row_end, 0, false);
+}
+DustStatus dust_hip_gi_import(DustHipPipeline* p, uint32_t row_begin, uint32_t row_end, uint32_t frame_index) {
+  return gi_exchange_launch(p, row_begin, row_end, frame_index, true);
 }
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* dst, size_t dst_bytes) {
   if (!p || !dst || which > 1 || !p->gi_hash.p) return fail(DUST_ERR_INVALID_ARGUMENT, "GI state not configured");

@@ -114,6 +114,8 @@ struct DevGI {
   DevSurfel* pixel_surfel;  // width*height: the surfel each pixel wants to enqueue
   DevHashRequest* requests; // pool_size
   DevSurfel* replacement;   // pool_size: direction == 0xFFFFFFFF means "keep"
+  uint32_t* touched;        // multi-GPU: per pixel, 1 + index of the hash entry its final gather stamped (null otherwise)
+  DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
 };
 
 struct FrameArgs {

@@ -1100,10 +1100,12 @@ __device__ V3 logluv_decode(uint32_t p) {  // spatial_hash.glsl:64-93
   return mk(fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f), fmaxf(r.z, 0.0f));
 }
 // SpatialHashGet (spatial_hash.glsl:200-219): stamps last_accessed_frame of the entry it finds
-__device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t frame_index, V3& value, uint32_t& count) {
+// entry: 1 + index of the entry that was found (and stamped), 0 when there is none
+__device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t frame_index, V3& value, uint32_t& count, uint32_t& entry) {
   const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
   value = mk(0, 0, 0);
   count = 0;
+  entry = 0;
   for (uint32_t i = 0; i < 3; ++i) {
     uint32_t* e = gi.hash + (size_t)(loc + i) * 3;
     const uint32_t cur = e[0];
@@ -1112,6 +1114,7 @@ __device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t fr
       reinterpret_cast<uint16_t*>(e)[4] = (uint16_t)frame_index;  // every reader stores the same value
       value = logluv_decode(e[1]);
       count = e[2] >> 16;
+      entry = loc + i + 1u;
       return true;
     }
   }
@@ -1231,7 +1234,9 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
     brick_surfel(a, h, loc, ad, key, sf, alb);
     V3 rad;
     uint32_t count;
-    hash_get(a.gi, key, a.frame_index, rad, count);
+    uint32_t entry;
+    hash_get(a.gi, key, a.frame_index, rad, count, entry);
+    if (a.gi.touched) a.gi.touched[p.px + p.py * a.width] = entry;  // multi-GPU: the other ranks repeat this stamp
     const float prob = 1.0f / (float)(count + 2u);
     const float noise = (float)a.noise0[((p.py + 21u + a.rand) % 128u) * 128u + ((p.px + 34u + a.rand) % 128u)] / 255.0f;
     if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
@@ -1253,6 +1258,40 @@ __global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
     const uint32_t o = a.gi.slot_owner[s];
     if (o != 0u) {
       a.gi.pool[s] = a.gi.pixel_surfel[o - 1u];
+      a.gi.slot_owner[s] = 0u;
+    }
+  }
+}
+
+// ==================================================================== multi-GPU exchange of the final gather's side effects
+// (dust_hip.h, dust_hip_pipeline_gi_exchange). slot_owner holds the all-reduced (MAX) owners when these run.
+// export: this rank's share of the winning surfels -- the slots whose winning pixel lies in rows [row_begin, row_end)
+__global__ void k_gi_export(const FrameArgs* __restrict__ ap) {
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    const uint32_t o = a.gi.slot_owner[s];
+    DevSurfel v;
+    v.x = v.y = v.z = 0.0f; v.direction = 0u;
+    if (o != 0u) {
+      const uint32_t row = (o - 1u) / a.width;
+      if (row >= a.row_begin && row < a.row_end) v = a.gi.pixel_surfel[o - 1u];
+    }
+    a.gi.merged[s] = v;
+  }
+}
+// import: repeat the last_accessed_frame stamps of the other bands' final gather, commit the merged winners
+__global__ void k_gi_import(const FrameArgs* __restrict__ ap) {
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+  const uint32_t n_px = a.width * a.height;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += gridDim.x * blockDim.x) {
+    const uint32_t row = i / a.width;
+    if (row >= a.row_begin && row < a.row_end) continue;  // this rank's own final gather already stamped those
+    const uint32_t e = a.gi.touched[i];
+    if (e != 0u) reinterpret_cast<uint16_t*>(a.gi.hash + (size_t)(e - 1u) * 3)[4] = (uint16_t)a.frame_index;
+  }
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    if (a.gi.slot_owner[s] != 0u) {
+      a.gi.pool[s] = a.gi.merged[s];
       a.gi.slot_owner[s] = 0u;
     }
   }
@@ -1325,7 +1364,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
         brick_surfel(a, h, org, cd, key, sf, alb);
         V3 rad;
         uint32_t count = 0;
-        const bool found = hash_get(a.gi, key, a.frame_index, rad, count);
+        uint32_t entry;
+        const bool found = hash_get(a.gi, key, a.frame_index, rad, count, entry);
         const float rnd0 = (float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)] / 255.0f;
         if (found) {
           rad = modulate_by_avg_albedo(rad, alb);
@@ -1539,11 +1579,19 @@ hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev,
   else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, dev);
   return hipGetLastError();
 }
-hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_export, dim3(512), dim3(256), 0, s, dev);
+  return hipGetLastError();
+}
+hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_import, dim3(1024), dim3(256), 0, s, dev);
+  return hipGetLastError();
+}
+hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
   const size_t lds = lds_bytes(host, block);
   if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, dev);
   else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, dev);
-  hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, dev);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, dev);
   return hipGetLastError();
 }
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {

@@ -80,3 +80,51 @@ class AsyncGather:
         """Frames gathered by the most recent submit (rank dst only; [own buffer] when not distributed)."""
         b = (self.k - 1) % len(self.bufs)
         return self.out[b] if self.out is not None else [self.bufs[b]]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Multi-GPU diffuse GI (SURVEY 8e option i; the protocol is spelled out in include/dust_hip.h at
+# dust_hip_pipeline_gi_exchange): pixel passes on row bands, identical hash + surfel pool on every GPU, the final
+# gather's side effects exchanged with two small all-reduces and one all-gather per frame.
+
+class DeviceArray:
+    """A raw device pointer dressed as a CUDA-array-interface object so torch can alias it (no copy)."""
+
+    def __init__(self, ptr: int, n_items: int, typestr: str = "<i4"):
+        self.__cuda_array_interface__ = {"shape": (n_items,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def alias_exchange_buffers(ex, device="cuda"):
+    """torch int32 views of the three buffers of a _lib.GiExchange: (slot_owner[pool], touched[rows*width], merged[pool*4])."""
+    import torch
+    owner = torch.as_tensor(DeviceArray(ex.slot_owner, ex.pool_size), device=device)
+    touched = torch.as_tensor(DeviceArray(ex.touched, ex.touched_rows * ex.width), device=device)
+    merged = torch.as_tensor(DeviceArray(ex.merged, ex.pool_size * 4), device=device)
+    return owner, touched, merged
+
+
+def gi_band_rows(world: int, height: int, align: int = 8) -> int:
+    """Rows per band (the last band may be shorter); `touched` is allocated with world * gi_band_rows rows."""
+    per = -(-height // world)
+    return -(-per // align) * align
+
+
+def gi_exchange_step(dist, rank, world, owner, touched, merged, band_items, export_fn, import_fn):
+    """Steps 2-5 of the per-frame protocol. owner/touched/merged are int32 tensors on the exchange buffers (device
+    tensors aliasing the library's buffers under RCCL; CPU tensors under gloo in the tests). band_items = items of
+    `touched` per band (band_rows * width). export_fn / import_fn launch dust_hip_gi_export / dust_hip_gi_import
+    (stream-ordered with the collectives: the context must use torch's current stream)."""
+    import torch
+    if dist is not None and dist.is_initialized() and world > 1:
+        dist.all_reduce(owner, op=dist.ReduceOp.MAX)
+        mine = touched[rank * band_items:(rank + 1) * band_items]
+        if touched.is_cuda:
+            dist.all_gather_into_tensor(touched, mine)          # in place: band r sits at offset r * band_items
+        else:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine.clone())
+            touched.copy_(torch.cat(parts))
+    export_fn()
+    if dist is not None and dist.is_initialized() and world > 1:
+        dist.all_reduce(merged, op=dist.ReduceOp.SUM)            # one contributor per slot, zeros elsewhere: exact
+    import_fn()

@@ -195,6 +195,9 @@ typedef enum DustHipPlane {
 #define DUST_PASS_GI_ORDERED (1u << 17)        /* apply the surfel pass's hash inserts in surfel-index order (bitwise
                                                   repeatable, serial); default: concurrently, as the reference's racy
                                                   shaders do (spatial_hash.glsl:147-195), statistically repeatable */
+#define DUST_PASS_GI_SHARDED (1u << 18)        /* multi-GPU GI (see dust_hip_pipeline_gi_exchange): the final gather may
+                                                  run on a row band; it records which hash entries it stamped and
+                                                  leaves the surfel enqueues uncommitted for the exchange */
 
 typedef struct DustHipFrameParams {
   uint32_t struct_size;
@@ -236,6 +239,33 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* ds
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline*, uint32_t hash_capacity, uint32_t surfel_pool_size);
 /* synchronous copy of GI state to the host: which = 0 spatial hash ((capacity+2) x 12 B), 1 surfel pool (16 B each) */
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline*, uint32_t which, void* dst, size_t dst_bytes);
+/* Multi-GPU GI: every GPU keeps an identical spatial hash and surfel pool, the pixel passes run on row bands and the
+ * (small) surfel pass is replicated. The reference has no multi-device path; the merge rule is this library's defined
+ * order (final_gather.rchit:52-63 leaves the winner among the pixels aliasing a slot to a race): the highest pixel
+ * index wins a surfel slot, as on one GPU. Per frame, on every rank:
+ *   1. dust_hip_render_frame(PRIMARY | AMBIENT_OCCLUSION | FINAL_GATHER | DUST_PASS_GI_SHARDED, own row band)
+ *   2. all-reduce MAX  of slot_owner (u32 x pool_size)                       -- the caller's collective (RCCL)
+ *      all-gather      of the bands of `touched` (u32 per pixel, band r at row r * band_rows)
+ *   3. dust_hip_gi_export(own band): merged[s] = the enqueued surfel if the winning pixel of slot s is in this band, else 0
+ *   4. all-reduce SUM  of merged as i32 (16 B x pool_size; exactly one rank contributes per slot)
+ *   5. dust_hip_gi_import(own band, frame_index): stamps last_accessed_frame of the entries the OTHER bands' final
+ *      gather read, commits the winning surfels to the pool, clears slot_owner
+ *   6. dust_hip_render_frame(SURFEL [| ACCUMULATE] | DUST_PASS_GI_SHARDED, rows as in 1 for ACCUMULATE)
+ * With DUST_PASS_GI_ORDERED in step 6 every rank's hash and pool stay bit-identical to the single-GPU run.
+ * dust_hip_pipeline_gi_exchange allocates (once) and returns the three device buffers the collectives run on;
+ * padded_rows >= height is the row count of `touched` (world_size x band_rows). */
+typedef struct DustHipGiExchange {
+  uint32_t struct_size;
+  uint32_t pool_size;      /* surfel slots */
+  uint32_t width;          /* pixels per row of `touched` */
+  uint32_t touched_rows;   /* rows of `touched` */
+  void* slot_owner;        /* u32[pool_size]: 1 + highest pixel index that enqueued into the slot this frame, 0 = none */
+  void* touched;           /* u32[touched_rows * width]: 1 + index of the hash entry the pixel's final gather stamped, 0 = none */
+  void* merged;            /* 16 B x pool_size: SurfelEntry per slot */
+} DustHipGiExchange;
+DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline*, uint32_t padded_rows, DustHipGiExchange* out);
+DustStatus dust_hip_gi_export(DustHipPipeline*, uint32_t row_begin, uint32_t row_end);
+DustStatus dust_hip_gi_import(DustHipPipeline*, uint32_t row_begin, uint32_t row_end, uint32_t frame_index);
 /* AutoExposurePipeline::render + ToneMappingPipeline::render (pipeline/auto_exposure.rs:96-248, tone_mapping.rs:76-200;
  * auto_exposure.comp, auto_exposure_avg.comp, tone_map.comp): 256-bin log-luminance histogram of the denoised radiance
  * (after DUST_PASS_ACCUMULATE: the N-frame mean), exponential adaptation of the average, then

@@ -46,6 +46,58 @@ WORKER = textwrap.dedent('''
             ref = P.render_oracle(s, cam, sky, W, H, passes, noise[f % 4], synth.frame_rand(1, f))
             assert np.array_equal(frames[r].numpy().astype(np.uint16), ref.illuminance), f"sample {r} differs"
         assert not np.array_equal(frames[0].numpy(), frames[1].numpy()), "samples must differ (different noise slice / rand)"
+    # --- multi-GPU GI exchange (sharding.gi_exchange_step; dust_hip.h dust_hip_pipeline_gi_exchange): the collectives
+    # run for real over gloo, the two library kernels between them are restated in numpy (k_gi_export / k_gi_import)
+    Wg, Hg, pool = 40, 27, 61
+    per_rows = sharding.gi_band_rows(world, Hg)
+    b0, b1 = min(Hg, rank * per_rows), min(Hg, (rank + 1) * per_rows)
+    rng = np.random.default_rng(99)                       # same stream on every rank: the "whole frame" truth
+    wants = rng.random(Wg * Hg) < 0.3                     # pixels whose final gather enqueues a surfel
+    surf = rng.integers(1, 2**31 - 1, size=(Wg * Hg, 4)).astype(np.int32)
+    stamp = np.where(rng.random(Wg * Hg) < 0.4, rng.integers(1, 500, Wg * Hg), 0).astype(np.int32)
+    pix = np.arange(Wg * Hg)
+    in_band = (pix // Wg >= b0) & (pix // Wg < b1)
+    owner = np.zeros(pool, np.int32)
+    for i in pix[wants & in_band]:                        # atomicMax(slot_owner[i % pool], i + 1) over this band only
+        owner[i % pool] = max(owner[i % pool], i + 1)
+    touched = np.zeros(world * per_rows * Wg, np.int32)
+    touched[pix[in_band]] = stamp[in_band]
+    merged = np.zeros(pool * 4, np.int32)
+    t_owner, t_touched, t_merged = torch.from_numpy(owner), torch.from_numpy(touched), torch.from_numpy(merged)
+    pool_state = np.full((pool, 4), -1, np.int32)
+    stamped = set(stamp[in_band][stamp[in_band] != 0].tolist())   # what this rank's own final gather stamped
+
+    def export_fn():
+        o = t_owner.numpy()
+        m = t_merged.numpy().reshape(pool, 4)
+        m[:] = 0
+        for sl in range(pool):
+            if o[sl] and b0 <= (o[sl] - 1) // Wg < b1:
+                m[sl] = surf[o[sl] - 1]
+
+    def import_fn():
+        t = t_touched.numpy()
+        for i in pix[~in_band]:
+            if t[i]:
+                stamped.add(int(t[i]))
+        o = t_owner.numpy()
+        m = t_merged.numpy().reshape(pool, 4)
+        for sl in range(pool):
+            if o[sl]:
+                pool_state[sl] = m[sl]
+                o[sl] = 0
+
+    sharding.gi_exchange_step(dist, rank, world, t_owner, t_touched, t_merged, per_rows * Wg, export_fn, import_fn)
+    want_owner = np.zeros(pool, np.int64)
+    for i in pix[wants]:
+        want_owner[i % pool] = max(want_owner[i % pool], i + 1)
+    want_pool = np.full((pool, 4), -1, np.int32)
+    for sl in range(pool):
+        if want_owner[sl]:
+            want_pool[sl] = surf[want_owner[sl] - 1]
+    assert np.array_equal(pool_state, want_pool), "merged surfel pool != single-process pool"
+    assert stamped == set(stamp[stamp != 0].tolist()), "stamps of the other bands were not repeated"
+    assert not t_owner.numpy().any()
     # --- the double-buffered asynchronous gather bench.py uses (step k's gather overlaps step k+1)
     ag = sharding.AsyncGather(dist, torch.zeros(4, dtype=torch.int32))
     for k in range(5):
