@@ -368,7 +368,7 @@ class StandardPipeline:
 
     def read_gi(self):
         """(hash entries as uint32[capacity+2, 3], surfel pool as structured array)"""
-        cap, pool = self._gi
+        cap, pool = getattr(self, "_gi", None) or (32 * 1024 * 1024, 720 * 480)  # the defaults of an implicit configuration
         h = np.zeros((cap + 2, 3), np.uint32)
         L.check(self._lib.dust_hip_pipeline_read_gi(self._h, 0, _ptr(h), h.nbytes))
         s = np.zeros(pool, SURFEL_DTYPE)

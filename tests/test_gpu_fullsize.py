@@ -1,0 +1,144 @@
+"""BASELINE.json configs[1] at its full size (castle stand-in, scale 1.0, 1920 x 1080): direct parity against the oracle
+(hierarchical mode over the host's cores: seconds on a GPU box) and the size-independent properties the domain offers --
+band union == frame, fused == separate launches, sharded GI == single-device GI."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as P
+from dust_amd import _lib as L, api, sharding, synth
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+EYE = (122.0, 300.61, 54.45)  # examples/castle.rs:126
+
+
+@pytest.fixture(scope="module")
+def castle():
+    data, info = synth.castle_scene()
+    desc = P.SceneDesc.from_vox(data)
+    ctx = api.Context(device=0)
+    return ctx, desc, P.hip_scene(ctx, desc), info
+
+
+def _oracle_frame(desc, cam, sky, noise5, rand, passes):
+    oscene = P.oracle_scene(desc)
+    g = O.GBuffer(W, H)
+    n = max(1, min(os.cpu_count() or 1, H // 4))
+    cuts = [H * i // n for i in range(n + 1)]
+    th = [threading.Thread(target=P.render_oracle, args=(oscene, cam, sky, W, H, passes, noise5, rand),
+                           kwargs={"rows": (cuts[i], cuts[i + 1]), "g": g}) for i in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return g
+
+
+def test_full_size_primary_ao_matches_oracle(castle):
+    ctx, desc, scene, info = castle
+    assert info["n_voxels"] > 10_000_000 and info["n_instances"] > 100
+    noise5 = synth.stbn_unitvec3_cosine()
+    cam, sky = P.camera_for(EYE), P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    pipe = api.StandardPipeline(ctx, W, H)
+    pipe.set_noise(5, noise5)
+    rnd = synth.frame_rand(1, 1)
+    pipe.render(scene, cam, sky, passes, frame_index=1, rand=rnd)
+    hip = P.read_hip_gbuffer(pipe)
+    g = _oracle_frame(desc, cam, sky, noise5[1 % len(noise5)], rnd, passes)
+    res = P.compare_gbuffers(g, hip)
+    P.assert_parity(res)
+    assert res["illuminance_rel_l2"] <= 1e-3 and res.get("denoised_rel_l2", 0.0) <= 1e-3, res
+    assert np.isfinite(g.depth).mean() > 0.5  # the reference camera looks down on the castle: (almost) every pixel hits
+
+
+def test_full_size_bands_and_fusion(castle, monkeypatch):
+    ctx, desc, scene, _ = castle
+    noise5 = synth.stbn_unitvec3_cosine()
+    cam, sky = P.camera_for(EYE), P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    full = api.StandardPipeline(ctx, W, H)
+    full.set_noise(5, noise5)
+    full.render(scene, cam, sky, passes, frame_index=2, rand=77)
+    ref = P.read_hip_gbuffer(full)
+    banded = api.StandardPipeline(ctx, W, H)
+    banded.set_noise(5, noise5)
+    for r in range(8):  # the 8-GPU partition
+        banded.render(scene, cam, sky, passes, frame_index=2, rand=77, rows=sharding.band_rows(r, 8, H))
+    got = P.read_hip_gbuffer(banded)
+    for k in ref:
+        assert ref[k].tobytes() == got[k].tobytes(), f"bands: {k}"
+    monkeypatch.setenv("DUST_HIP_NO_FUSE", "1")
+    sep = api.StandardPipeline(ctx, W, H)
+    sep.set_noise(5, noise5)
+    sep.render(scene, cam, sky, passes, frame_index=2, rand=77)
+    got = P.read_hip_gbuffer(sep)
+    monkeypatch.delenv("DUST_HIP_NO_FUSE")
+    for k in ref:
+        assert ref[k].tobytes() == got[k].tobytes(), f"separate launches: {k}"
+
+
+def test_full_size_sharded_gi_equals_single_device(castle):
+    """Default hash capacity (32 Mi entries) and surfel pool (345 600): two ranks on row bands, collectives by hand."""
+    ctx, desc, scene, _ = castle
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def d2h(ptr, n):
+        out = np.empty(n, np.int32)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes, 2) == 0
+        return out
+
+    def h2d(ptr, arr):
+        arr = np.ascontiguousarray(arr, np.int32)
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, 1) == 0
+
+    n0, n5 = synth.stbn_scalar(), synth.stbn_unitvec3_cosine()
+    cam, sky = P.camera_for(EYE), P.sky_state()
+
+    def make():
+        p = api.StandardPipeline(ctx, W, H)
+        p.set_noise(0, n0)
+        p.set_noise(5, n5)
+        return p
+
+    world = 2
+    ref, ranks = make(), [make() for _ in range(world)]
+    per = sharding.gi_band_rows(world, H)
+    bands = [(min(H, r * per), min(H, (r + 1) * per)) for r in range(world)]
+    exs = [p.gi_exchange(world * per) for p in ranks]
+    pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER
+    for frame in (1, 2):
+        rnd = synth.frame_rand(3, frame)
+        ref.render(scene, cam, sky, pix | L.PASS_SURFEL | L.PASS_GI_ORDERED, frame, rnd)
+        for r, p in enumerate(ranks):
+            p.render(scene, cam, sky, pix | L.PASS_GI_SHARDED, frame, rnd, rows=bands[r])
+        ctx.sync()
+        owner = np.max([d2h(e.slot_owner, e.pool_size) for e in exs], axis=0)
+        touched = np.zeros(world * per * W, np.int32)
+        for r, e in enumerate(exs):
+            touched[r * per * W:(r + 1) * per * W] = d2h(e.touched, world * per * W)[r * per * W:(r + 1) * per * W]
+        for e in exs:
+            h2d(e.slot_owner, owner)
+            h2d(e.touched, touched)
+        for r, p in enumerate(ranks):
+            p.gi_export(*bands[r])
+        ctx.sync()
+        merged = np.sum([d2h(e.merged, e.pool_size * 4) for e in exs], axis=0, dtype=np.int64).astype(np.int32)
+        for r, (p, e) in enumerate(zip(ranks, exs)):
+            h2d(e.merged, merged)
+            p.gi_import(bands[r][0], bands[r][1], frame)
+            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
+        ctx.sync()
+    h_ref, s_ref = ref.read_gi()
+    ill_ref = ref.read_plane(L.PLANE_ILLUMINANCE)
+    assert int((h_ref[:, 0] != 0).sum()) > 10_000
+    for r, p in enumerate(ranks):
+        h, sp = p.read_gi()
+        assert np.array_equal(h, h_ref), f"rank {r}: hash differs"
+        assert np.array_equal(sp.view(np.uint32), s_ref.view(np.uint32)), f"rank {r}: surfel pool differs"
+        ill = p.read_plane(L.PLANE_ILLUMINANCE)
+        assert np.array_equal(ill[bands[r][0]:bands[r][1]], ill_ref[bands[r][0]:bands[r][1]])
