@@ -271,19 +271,26 @@ __device__ bool brick_intersect(V3 o, V3 d, V3 tc, uint32_t m1, uint32_t m2, flo
   V3 tm = mk(((float)px + fmaxf(st.x, 0.0f)) * tc.x - tb.x, ((float)py + fmaxf(st.y, 0.0f)) * tc.y - tb.y,
              ((float)pz + fmaxf(st.z, 0.0f)) * tc.z - tb.z);
   V3 td = mk((1.0f * tc.x) * st.x, (1.0f * tc.y) * st.y, (1.0f * tc.z) * st.z);
+  const int sx = (int)st.x, sy = (int)st.y, sz = (int)st.z;
   uint32_t hit = encode_index(px, py, pz);
   int iters = 0;
   while (grid_clear(m1, m2, hit)) {
     if (++iters > kDdaMaxIters) return false;
-    float cx = gstep(tm.x, tm.z) * gstep(tm.x, tm.y);
-    float cy = gstep(tm.y, tm.x) * gstep(tm.y, tm.z);
-    float cz = gstep(tm.z, tm.y) * gstep(tm.z, tm.x);
-    px = (int)(int8_t)(px + (int)(st.x * cx));
-    py = (int)(int8_t)(py + (int)(st.y * cy));
-    pz = (int)(int8_t)(pz + (int)(st.z * cz));
+    // hit.rint:103-117. The shader multiplies by comp = step(tMax.xyz, tMax.zxy) * step(tMax.xyz, tMax.yzx), a 0/1
+    // vector (ties and NaNs set more than one component: step(edge, x) is 1 unless x < edge); selecting on the same
+    // predicates gives the same position and the same tMax -- x * 1 is x, tMax + x * 0 is tMax (up to the sign of a
+    // zero tMax, and except for direction components in the denormal range, where x * 0 is NaN) -- in half the VALU work
+    const bool bx = !(tm.z < tm.x) & !(tm.y < tm.x);
+    const bool by = !(tm.x < tm.y) & !(tm.z < tm.y);
+    const bool bz = !(tm.y < tm.z) & !(tm.x < tm.z);
+    px += bx ? sx : 0;
+    py += by ? sy : 0;
+    pz += bz ? sz : 0;
     hd = fminf(fminf(tm.x, tm.y), tm.z);
     if (hd + 0.001f >= t1) return false;
-    tm.x += td.x * cx; tm.y += td.y * cy; tm.z += td.z * cz;
+    tm.x = bx ? tm.x + td.x : tm.x;
+    tm.y = by ? tm.y + td.y : tm.y;
+    tm.z = bz ? tm.z + td.z : tm.z;
     hit = encode_index(px, py, pz);
   }
   t_out = hd / 1.0f;
