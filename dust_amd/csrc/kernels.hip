@@ -432,13 +432,65 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
   best.found = true; best.t = t; best.inst = inst; best.block = key; best.voxel = vox;
 }
 
+// The cold part of the conservative walk (see trace_instance): the entry point of the cell at ijk may lie within delta
+// of further brick planes; decide exactly which, and test every brick around that edge / corner. A real call, not
+// inlined: the hot loop then carries neither this code's registers nor a second copy of the lookup and brick test
+// (inlined, the same code cost the fused kernel 15 %). State goes in and out by value so nothing of the caller's has
+// its address taken.
+struct NeighbourVisit {
+  Hit best;
+  MidCache mc;
+  uint32_t bricks_tested;
+};
+template <int RT, bool COUNT>
+__device__ __attribute__((noinline)) NeighbourVisit visit_neighbours(const DUST_CONST_AS DevModel* mp, uint32_t inst, V3 o, V3 d, V3 inv_d,
+                                                                    float tmin, float tmax, float t, int i0, int i1, int i2,
+                                                                    uint32_t stepped, Hit best, MidCache mc) {
+  ModelRef m = *mp;
+  NeighbourVisit out;
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  const int ijk[3] = {i0, i1, i2};
+  uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the brick's low / high plane on axis a
+  uint32_t unstepped_near = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int blo = (int)m.bmin[a], bhi = (int)m.bmax[a] - 1;  // voxel range that holds bricks (tight bounds, multiples of 4)
+    const float p = oo[a] + dd[a] * t;
+    const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
+    const int b0 = ijk[a] & ~3;
+    const float q = p - (float)b0;
+    // a plane only matters if bricks can exist on its far side
+    if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo) near_neg |= 1u << a; } else if (b0 + 4 <= bhi) near_pos |= 1u << a; }
+    else if (q <= delta) { if (b0 - 1 >= blo) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
+    else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+  }
+  const uint32_t nearm = near_neg | near_pos;
+  if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
+#pragma unroll 1
+    for (uint32_t sub = 1; sub < 8; ++sub) {  // one visit per non-empty subset of the near axes
+      if ((sub & ~nearm) != 0 || (stepped != 0 && sub == stepped)) continue;  // sub == stepped: the cell we came from
+      int c[3] = {ijk[0], ijk[1], ijk[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
+      uint32_t cl2, key;
+      const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
+      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+    }
+  }
+  out.best = best;
+  out.mc = mc;
+  out.bricks_tested = st.bricks_tested;
+  return out;
+}
+
 // Hierarchical traversal of one instance in object space. Visits, front to back, a SUPERSET of the
 // bricks whose intersection routine can report an accepted hit: exit planes are recomputed from
 // integer cell coordinates at every step (no accumulated error), and whenever the walk passes within
 // delta of a brick-grid edge or corner every brick around it is tested too (DESIGN.md "Conservative walk").
-// One loop iteration handles one cell: normally the cell the ray is in; when the entry point lies within
-// delta of other brick planes, the bricks across those planes are queued in `pending` (a 7-bit set of
-// axis subsets) and visited by the same code before the walk advances.
+// One loop iteration handles one cell; when its entry point lies within delta of other brick planes, the bricks across
+// those planes (one per non-empty subset of the near axes) are tested by visit_neighbours before the walk advances.
 template <int RT, bool COUNT>
 __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                                Hit& best, LaneStats& st) {
@@ -450,98 +502,58 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   float t = fmaxf(te, 0.0f);
   if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
   int ijk[3];
-  int blo[3], bhi[3];  // voxel range that holds bricks (tight bounds, multiples of 4)
+  // Near-plane screen (see the loop): |p/4 - rint(p/4)| <= near_tol flags an entry point that may lie within
+  // delta = 1e-6 (|o_a| + |p_a| + 16) of a brick plane. One tolerance for the whole visit: 3e-7 (20 % above delta / 4,
+  // which covers evaluating p at the step's exit time instead of the clamped t) times the largest |o_a| + |p_a| the
+  // walk can meet (p is linear in t, so the ends of [te, tx] bound it).
+  float reach = 0.0f;
+  bool screen = false;  // does the CURRENT cell's entry point need the exact near-plane test?
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    blo[a] = (int)m.bmin[a];
-    bhi[a] = (int)m.bmax[a] - 1;
     // the cell the ray is moving into: floor for d >= 0, ceil - 1 for d < 0 (differs only on a cell plane)
     const float p = oo[a] + dd[a] * t;
     ijk[a] = f2i_clamp(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p), 0, E - 1);
+    reach = fmaxf(reach, fabsf(oo[a]) + fmaxf(fabsf(p), fabsf(oo[a] + dd[a] * tx)));
+  }
+  const float near_tol = 3.0e-7f * (reach + 16.0f);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float r = (oo[a] + dd[a] * t) * 0.25f;
+    screen = screen | (fabsf(r - rintf(r)) <= near_tol);
   }
   uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
-  uint32_t pending = 0;   // bit (sub-1): neighbour subset `sub` still to visit
-  uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the brick's low / high plane on axis a
   uint32_t cl_main = 2;
   MidCache mc;
   mc.key = -1;
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   for (int guard = 0; guard < 200000; ++guard) {
     PROF_COUNT(P_N_STEPS, 1);
-    const bool is_main = pending == 0;
-    int c[3] = {ijk[0], ijk[1], ijk[2]};
-    if (is_main) {
+    {
       const float limit = best.found ? best.t : tmax;
       if (t * (1.0f - 2e-6f) > limit) return;
       if (any_hit && best.found) return;
-    } else {
-      const uint32_t sub = (uint32_t)__ffs((int)pending);  // 1..7
-      pending &= pending - 1u;
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-        if (sub & (1u << a)) {
-          c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
-        }
-      {
-        uint32_t cl2, key;
-        PROF_ENTER(P_FIND);
-        const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
-        const bool have = mask != 0;
-        PROF_LEAVE(P_FIND);
-        PROF_ENTER(P_BRICK);
-        if (have) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
-        PROF_LEAVE(P_BRICK);
-        if (pending != 0) continue;
-      }
     }
-    if (is_main) {
+    {
       uint32_t key;
       PROF_ENTER(P_FIND);
-      const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl_main, key, mc, st, true);
+      const uint64_t mask = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true);
       const bool have = mask != 0;
       PROF_LEAVE(P_FIND);
       PROF_ENTER(P_BRICK);
-      if (have) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      if (have) test_brick<RT, COUNT>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
       PROF_LEAVE(P_BRICK);
-      PROF_ENTER(P_SCREEN);
-      // Which further brick planes is the entry point within delta of? Cheap screen first: the distance of p to
-      // the nearest multiple of 4 on the axes that did not step (a superset of the exact test below), and exact
-      // ties on exit (more than one axis stepped). Almost every step ends here.
-      bool screen = __popc(stepped) > 1;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float p = oo[a] + dd[a] * t;
-        const float r = p * 0.25f;
-        const float f = fabsf(r - rintf(r));
-        if (!(stepped & (1u << a)) && f <= 2.6e-7f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f)) screen = true;
-      }
-      near_neg = 0; near_pos = 0;
-      bool queued = false;
-      if (screen) {
-        uint32_t unstepped_near = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float p = oo[a] + dd[a] * t;
-          const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
-          const float q = p - (float)(ijk[a] & ~3);
-          const int b0 = ijk[a] & ~3;
-          // a plane only matters if bricks can exist on its far side
-          if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo[a]) near_neg |= 1u << a; } else if (b0 + 4 <= bhi[a]) near_pos |= 1u << a; }
-          else if (q <= delta) { if (b0 - 1 >= blo[a]) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
-          else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi[a]) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
-        }
-        const uint32_t nearm = near_neg | near_pos;
-        if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
-          pending = 0;
-#pragma unroll
-          for (uint32_t sub = 1; sub < 8; ++sub)
-            if ((sub & ~nearm) == 0 && !(stepped != 0 && sub == stepped)) pending |= 1u << (sub - 1);  // sub == stepped: the cell we came from
-          queued = pending != 0;
-        }
-      }
-      PROF_LEAVE(P_SCREEN);
-      if (queued) continue;
     }
+    // Is the entry point within delta of further brick planes? `screen` (worked out when the walk stepped into this
+    // cell, from the entry point that step computed anyway) is a cheap superset of that: the distance of p to the
+    // nearest multiple of 4 on the axes that did not step, or an exact tie on exit. Almost every step skips the call.
+    PROF_ENTER(P_SCREEN);
+    if (__builtin_expect(screen, 0)) {
+      const NeighbourVisit nv = visit_neighbours<RT, COUNT>(&m, inst, o, d, inv_d, tmin, tmax, t, ijk[0], ijk[1], ijk[2], stepped, best, mc);
+      best = nv.best;
+      mc = nv.mc;
+      if (COUNT) st.bricks_tested += nv.bricks_tested;
+    }
+    PROF_LEAVE(P_SCREEN);
     // leave the cell of size 2^cl_main that contains ijk
     PROF_ENTER(P_ADVANCE);
     const int S = 1 << cl_main;
@@ -561,6 +573,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     if (!(tn < INFINITY)) { PROF_LEAVE(P_ADVANCE); return; }
     stepped = 0;
     bool outside = false;
+    screen = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (ta[a] == tn) {
@@ -568,9 +581,13 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
         ijk[a] = dd[a] > 0.0f ? cc[a] + S : cc[a] - 1;
         if (ijk[a] < 0 || ijk[a] >= E) outside = true;
       } else {
-        ijk[a] = f2i_clamp(floorf(oo[a] + dd[a] * tn), cc[a], cc[a] + S - 1);
+        const float p = oo[a] + dd[a] * tn;  // the next cell's entry point on an axis that does not cross a plane
+        ijk[a] = f2i_clamp(floorf(p), cc[a], cc[a] + S - 1);
+        const float r = p * 0.25f;
+        screen = screen | (fabsf(r - rintf(r)) <= near_tol);
       }
     }
+    screen = screen | (__popc(stepped) > 1);
     PROF_LEAVE(P_ADVANCE);
     if (outside) return;
     t = fmaxf(t, tn);
