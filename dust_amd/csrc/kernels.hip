@@ -49,7 +49,8 @@ __device__ __forceinline__ void prof_count(int idx, unsigned long long n) {
 #define PROF_COUNT(i, n)
 #endif
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
-       P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };  // the P_N_* buckets count events, not cycles
+       P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
+enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)  // the P_N_* buckets count events, not cycles
 
 namespace {
 
@@ -518,8 +519,13 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   const float near_tol = 3.0e-7f * (reach + 16.0f);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float r = (oo[a] + dd[a] * t) * 0.25f;
-    screen = screen | (fabsf(r - rintf(r)) <= near_tol);
+    // A walk that starts on the model's bounds (every visit from outside does: the bounds are brick planes) is "near a
+    // plane" there by construction, but no brick exists beyond it -- the exact test would say so too; do not pay a
+    // call to hear it.
+    const float p = oo[a] + dd[a] * t;
+    const float r = p * 0.25f;
+    const bool on_bounds = fabsf(p - m.bmin[a]) <= 4.0f * near_tol || fabsf(p - m.bmax[a]) <= 4.0f * near_tol;
+    screen = screen | ((fabsf(r - rintf(r)) <= near_tol) & !on_bounds);
   }
   uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
   uint32_t cl_main = 2;
@@ -548,6 +554,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     // nearest multiple of 4 on the axes that did not step, or an exact tie on exit. Almost every step skips the call.
     PROF_ENTER(P_SCREEN);
     if (__builtin_expect(screen, 0)) {
+      PROF_COUNT(P_N_NEIGHBOUR_CALLS, 1);
       const NeighbourVisit nv = visit_neighbours<RT, COUNT>(&m, inst, o, d, inv_d, tmin, tmax, t, ijk[0], ijk[1], ijk[2], stepped, best, mc);
       best = nv.best;
       mc = nv.mc;

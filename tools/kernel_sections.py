@@ -54,7 +54,8 @@ def report(title, b, ms):
         print(f"  {k:44s}{100.0 * x / tot:6.1f} %")
     nt = max(1, b[11])
     print(f"  per packet-trace (wave level): candidates {b[12] / nt:.1f}, candidate-loop iterations {b[13] / nt:.1f}, "
-          f"instance visits {b[14] / nt:.2f}, traversal loop trips {b[15] / nt:.1f} ({b[15] / max(1, b[14]):.1f} per visit)")
+          f"instance visits {b[14] / nt:.2f}, traversal loop trips {b[15] / nt:.1f} ({b[15] / max(1, b[14]):.1f} per visit), "
+          f"of which {100.0 * b[10] / max(1, b[15]):.1f} % call visit_neighbours")
 
 
 def main():
