@@ -23,6 +23,9 @@ hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32
 hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
 hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t);
+hipError_t launch_surfel_keys(const FrameArgs* dev, hipStream_t);
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, uint32_t key_bits, hipStream_t s);
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
@@ -119,6 +122,7 @@ struct DustHipScene {
   std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
   DeviceBuffer d_models, d_instances, d_root_table, d_boxes;
   std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
+  float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
   uint32_t n_lds_models = 0;
   bool committed = false;
 };
@@ -132,6 +136,8 @@ struct DustHipPipeline {
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
+  DeviceBuffer gi_sort_keys, gi_sort_vals, gi_sort_keys_out, gi_perm, gi_sort_tmp;  // position order of the surfel pool
+  size_t gi_sort_tmp_bytes = 0;
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
@@ -614,6 +620,9 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
         }
       }
     }
+    for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
+    for (const dust::DevInstance& d : di)
+      for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], d.wmin[a]); s->world_max[a] = std::max(s->world_max[a], d.wmax[a]); }
     // roots of the first models go to LDS, as many as the budget holds
     s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
     std::vector<dust::DevModel> dm(s->models.size());
@@ -738,6 +747,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.n_lds_models = s->n_lds_models;
   a.root_table = static_cast<const uint8_t*>(s->d_root_table.p);
   a.boxes = static_cast<const dust::DevBox*>(s->d_boxes.p);
+  for (int k = 0; k < 3; ++k) { a.world_min[k] = s->world_min[k]; a.world_max[k] = s->world_max[k]; }
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
   a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;
@@ -836,8 +846,22 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     b.tiles_y = 1;
     take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
+    if (!std::getenv("DUST_HIP_NO_SURFEL_SORT")) {  // phase 0: Morton keys + radix sort -> gi.perm
+      b.gi.sort_keys = static_cast<uint32_t*>(p->gi_sort_keys.p);
+      b.gi.sort_vals = static_cast<uint32_t*>(p->gi_sort_vals.p);
+      const dust::FrameArgs* dk = nullptr;
+      { DustStatus us = upload_args(p, b, st, &dk); if (us != DUST_OK) return us; }
+      if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
+      HIP_TRY(dust::launch_surfel_keys(dk, st));
+      HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+      size_t tmp_bytes = p->gi_sort_tmp_bytes;
+      HIP_TRY(dust::sort_pairs_u32(p->gi_sort_tmp.p, &tmp_bytes, b.gi.sort_keys, static_cast<uint32_t*>(p->gi_sort_keys_out.p),
+                                   b.gi.sort_vals, static_cast<uint32_t*>(p->gi_perm.p), p->gi_pool_size, 32, st));
+      b.gi.perm = static_cast<const uint32_t*>(p->gi_perm.p);
+    } else if (ctx->timing) {
+      HIP_TRY(hipEventRecord(p->ev[6], st));
+    }
     const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
     const dust::FrameArgs* d = nullptr;
     { DustStatus us = upload_args(p, b, st, &d); if (us != DUST_OK) return us; }
     HIP_TRY(dust::launch_surfel(b, d, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
@@ -905,6 +929,10 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_pixel_surfel.alloc(size_t(p->width) * p->height * 16));
   HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));
   HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
+  for (DeviceBuffer* b : {&p->gi_sort_keys, &p->gi_sort_vals, &p->gi_sort_keys_out, &p->gi_perm}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
+  p->gi_sort_tmp_bytes = 0;
+  HIP_TRY(dust::sort_pairs_u32(nullptr, &p->gi_sort_tmp_bytes, nullptr, nullptr, nullptr, nullptr, surfel_pool_size, 32, p->ctx->stream));
+  HIP_TRY(p->gi_sort_tmp.alloc(p->gi_sort_tmp_bytes));
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;
   p->gi_touched_rows = 0;  // the exchange buffers follow the pool size: dust_hip_pipeline_gi_exchange re-creates them

@@ -114,6 +114,9 @@ struct DevGI {
   DevSurfel* pixel_surfel;  // width*height: the surfel each pixel wants to enqueue
   DevHashRequest* requests; // pool_size
   DevSurfel* replacement;   // pool_size: direction == 0xFFFFFFFF means "keep"
+  const uint32_t* perm;     // surfel indices ordered by position (k_surfel_keys + radix sort), or null = pool order
+  uint32_t* sort_keys;      // pool_size keys / indices the sort consumes (k_surfel_keys fills them)
+  uint32_t* sort_vals;
   uint32_t* touched;        // multi-GPU: per pixel, 1 + index of the hash entry its final gather stamped (null otherwise)
   DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
 };
@@ -125,6 +128,7 @@ struct FrameArgs {
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
+  float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];
   DevGBuffer g;

@@ -1328,6 +1328,40 @@ __global__ void k_gi_import(const FrameArgs* __restrict__ ap) {
   }
 }
 
+// ==================================================================== surfel pass, phase 0: order the pool by position
+// Consecutive pool slots hold the hit points of unrelated final-gather rays, scattered over the whole scene: a packet of
+// 64 of them bounds nothing and walks a dozen instances per ray. Sorting the slots by a 30-bit Morton code of their
+// position (1024^3 cells over the scene's bounds; dead slots last) makes a packet's origins neighbours, so the packet culling works again.
+// Only the grouping into packets changes: every surfel still computes and writes exactly what it did, at its own slot.
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 1023u;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void k_surfel_keys(const FrameArgs* __restrict__ ap) {
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.gi.pool_size; i += gridDim.x * blockDim.x) {
+    const DevSurfel e = a.gi.pool[i];
+    uint32_t key = 0xFFFFFFFFu;  // dead slots sort last
+    if (e.direction < 6u) {
+      const float q[3] = {e.x, e.y, e.z};
+      uint32_t c[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float span = fmaxf(a.world_max[k] - a.world_min[k], 1.0f);
+        const float f = fminf(fmaxf((q[k] - a.world_min[k]) * (1024.0f / span), 0.0f), 1023.0f);  // NaN -> 0
+        c[k] = (uint32_t)f;
+      }
+      key = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+    }
+    a.gi.sort_keys[i] = key;
+    a.gi.sort_vals[i] = i;
+  }
+}
+
 // ==================================================================== surfel pass, phase 1: trace + read the hash
 // surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
 template <bool COUNT>
@@ -1340,7 +1374,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
   Packet p;
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   while (next_packet(a, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
-    const uint32_t i = (p.px >> 3) * 64u + (threadIdx.x & 63u);
+    const uint32_t slot = (p.px >> 3) * 64u + (threadIdx.x & 63u);
+    const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
     const bool in_range = i < a.gi.pool_size;
     DevSurfel e;
     e.x = e.y = e.z = 0.0f; e.direction = 0xFFFFFFFFu;
@@ -1623,6 +1658,10 @@ hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint
   if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, dev);
   else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, dev);
   if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, dev);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_keys(const FrameArgs* dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, dev);
   return hipGetLastError();
 }
 hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {

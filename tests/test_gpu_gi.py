@@ -84,3 +84,32 @@ def test_gi_racy_mode_is_statistically_close():
     assert len(fp_o & fp_r) >= 0.9 * len(fp_o)
     a, b = ill_ord[..., :3], ill_racy[..., :3]
     assert abs(a.mean() - b.mean()) <= 0.05 * abs(a.mean()) + 1e-6
+
+
+def test_surfel_position_sort_only_regroups(monkeypatch):
+    """The surfel pass traces the pool in position order (k_surfel_keys + radix sort); that changes which surfels share a
+    wavefront, never what a surfel computes: with the ordered apply the GI state must equal the pool-order run bit for bit."""
+    desc = P.small_scene(seed=9, n_models=3, n_instances=6, size=(28, 28, 28))
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    sky, cam = P.sky_state(), P.camera_for((80.0, 60.0, 90.0))
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    states = []
+    for no_sort in (False, True):
+        if no_sort:
+            monkeypatch.setenv("DUST_HIP_NO_SURFEL_SORT", "1")
+        else:
+            monkeypatch.delenv("DUST_HIP_NO_SURFEL_SORT", raising=False)
+        pipe = api.StandardPipeline(ctx, 128, 80)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(1 << 14, 4096)
+        for f in range(1, 5):
+            pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(2, f))
+        h, s = pipe.read_gi()
+        states.append((h, s.view(np.uint32).copy(), pipe.read_plane(L.PLANE_ILLUMINANCE)))
+    monkeypatch.delenv("DUST_HIP_NO_SURFEL_SORT", raising=False)
+    assert (states[0][0][:, 0] != 0).sum() > 50
+    for x, y in zip(states[0], states[1]):
+        assert np.array_equal(x, y)
