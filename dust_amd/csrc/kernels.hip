@@ -739,6 +739,14 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
   const V3 inv_d = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
   const bool zero_axis = __any(active && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));  // e.g. the default sun (x == 0)
+  // when the ray leaves the union of all instance boxes (a ray that hits nothing never "settles" on a hit: this is what
+  // lets a packet of sky-bound rays stop walking the candidate list)
+  float t_scene = INFINITY;
+  if (RT >= 2 && n > 8u) {  // the incoherent ray types; coherent packets have lists of one or two
+    float te_s, tx_s;
+    const bool in = slab_box(o, d, inv_d, a.world_min, a.world_max, te_s, tx_s);
+    t_scene = in ? tx_s * (1.0f + 1e-5f) + 1e-3f : -1.0f;
+  }
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     uint32_t ii;
     float lo[3], hi[3];
@@ -750,7 +758,8 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
       // the list is sorted by earliest possible entry: once every ray of the packet has a hit in front of this
       // candidate's earliest entry, no later candidate can matter either
       const float t_lo = __uint_as_float(c & 0xFFFF0000u);
-      const bool settled = !active || (best.found && (any_hit || best.t < t_lo * (1.0f - 1e-5f) - 1e-4f));
+      const bool settled = !active || (best.found && (any_hit || best.t < t_lo * (1.0f - 1e-5f) - 1e-4f)) ||
+                           t_scene < t_lo * (1.0f - 1e-5f) - 1e-4f;
       if (__all(settled)) break;
     }
     ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)ii);  // wave-uniform by construction: say so, so that the
