@@ -44,6 +44,11 @@ class VoxModelInfo(C.Structure):
                 ("n_materials", C.c_uint64), ("used", C.c_uint32)]
 
 
+class PngInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("layers", C.c_uint32), ("channels", C.c_uint32),
+                ("bytes_per_channel", C.c_uint32)]
+
+
 class VoxInstance(C.Structure):
     _fields_ = [("model", C.c_uint32), ("obj_to_world", C.c_float * 12)]
 
@@ -120,6 +125,7 @@ SYMBOLS = {
     "dust_vox_flatten_model": (C.c_int, [_P, C.c_size_t, _u32p, _P, C.POINTER(C.POINTER(Block)), _u32p,
                                          C.POINTER(_u8p), _u64p]),
     "dust_vox_free": (None, [_P]),
+    "dust_png_load_array": (C.c_int, [_P, C.c_size_t, C.POINTER(PngInfo), C.POINTER(_u8p)]),
     "dust_hip_context_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "dust_hip_context_destroy": (None, [_P]),
     "dust_hip_sync": (C.c_int, [_P]),

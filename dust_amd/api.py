@@ -374,3 +374,21 @@ class StandardPipeline:
         s = np.zeros(pool, SURFEL_DTYPE)
         L.check(self._lib.dust_hip_pipeline_read_gi(self._h, 1, _ptr(s), s.nbytes))
         return h, s
+
+
+def load_png_array(data: bytes):
+    """PNG / APNG -> array (layers, height, width, channels), uint8 (big-endian uint16 for 16-bit files): the reference's
+    PngLoader (rhyolite_bevy/src/loaders/png.rs:70-200). RGB comes back as RGBA with a zero fourth channel."""
+    lib = L.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    info = L.PngInfo()
+    out = C.POINTER(C.c_uint8)()
+    L.check(lib.dust_png_load_array(C.cast(buf, C.c_void_p), len(data), C.byref(info), C.byref(out)))
+    try:
+        n = info.layers * info.height * info.width * info.channels * info.bytes_per_channel
+        raw = np.ctypeslib.as_array(out, shape=(n,)).copy()
+    finally:
+        lib.dust_vox_free(out)
+    dt = np.uint8 if info.bytes_per_channel == 1 else np.dtype(">u2")
+    return raw.view(dt).reshape(info.layers, info.height, info.width, info.channels)
+

@@ -14,6 +14,7 @@
 
 #include "dust_dev.h"
 #include "vdb.hpp"
+#include "png.hpp"
 #include "vox.hpp"
 
 namespace dust {
@@ -387,6 +388,19 @@ DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** ou
   });
 }
 void dust_vox_scene_destroy(DustVoxScene* s) { delete s; }
+DustStatus dust_png_load_array(const uint8_t* bytes, size_t n_bytes, DustPngInfo* info, uint8_t** texels) {
+  if (!bytes || !info || !texels) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] {
+    const dust::png::ImageArray img = dust::png::load(bytes, n_bytes);
+    uint8_t* out = static_cast<uint8_t*>(std::malloc(img.texels.size() ? img.texels.size() : 1));
+    if (!out) throw std::bad_alloc();
+    std::memcpy(out, img.texels.data(), img.texels.size());
+    info->width = img.width; info->height = img.height; info->layers = img.layers;
+    info->channels = img.channels; info->bytes_per_channel = img.bytes_per_channel;
+    *texels = out;
+    return DUST_OK;
+  });
+}
 DustStatus dust_vox_scene_counts(const DustVoxScene* s, uint32_t* n_models, uint32_t* n_instances) {
   if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
   if (n_models) *n_models = uint32_t(s->scene.models.size());

@@ -378,3 +378,66 @@ def procedural_deep_blocks(seed=0xC5, occupancy=0.01, extent_log2=12, chunk=1 <<
     materials = rng.integers(0, 255, int(counts.sum()), dtype=np.uint8)
     blocks["avg_albedo"] = (hh & np.uint32(0xFFFFFFFC)) | np.uint32(3)
     return blocks, materials
+
+
+def write_apng(frames, filters=(0, 1, 2, 3, 4), interlace=0, frame_rect=None):
+    """Encode frames (layers, h, w[, channels]; uint8 or uint16) as a PNG (1 layer) or an APNG whose first frame is the
+    default image -- the layout of the reference's stbn/*.png textures. Scanline filter types cycle through `filters`.
+    frame_rect=(w, h, x, y) writes that (wrong on purpose) rectangle into the later frames' fcTL for the error tests."""
+    import struct
+    import zlib
+    a = np.asarray(frames)
+    if a.ndim == 3:
+        a = a[..., None]
+    layers, h, w, ch = a.shape
+    depth = 8 if a.dtype == np.uint8 else 16
+    color_type = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    bpp = ch * depth // 8
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    def encode(img):
+        rows = (img.astype(">u2") if depth == 16 else img).reshape(h, -1).view(np.uint8).astype(np.int32)
+        out = bytearray()
+        prev = np.zeros(rows.shape[1], np.int32)
+        for y in range(h):
+            f = filters[y % len(filters)]
+            cur = rows[y]
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+            ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            if f == 0:
+                pred = np.zeros_like(cur)
+            elif f == 1:
+                pred = left
+            elif f == 2:
+                pred = prev
+            elif f == 3:
+                pred = (left + prev) >> 1
+            else:
+                p = left + prev - ul
+                pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            out.append(f)
+            out += ((cur - pred) & 255).astype(np.uint8).tobytes()
+            prev = cur
+        return zlib.compress(bytes(out), 6)
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, interlace))
+    seq = 0
+    if layers > 1:
+        png += chunk(b"acTL", struct.pack(">II", layers, 0))
+    for i in range(layers):
+        if layers > 1:
+            fw, fh, fx, fy = (w, h, 0, 0) if (frame_rect is None or i == 0) else frame_rect
+            png += chunk(b"fcTL", struct.pack(">IIIIIHHBB", seq, fw, fh, fx, fy, 1, 30, 0, 0))
+            seq += 1
+        z = encode(a[i])
+        if i == 0:
+            half = len(z) // 2   # two IDAT chunks: the stream may be split anywhere
+            png += chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:])
+        else:
+            png += chunk(b"fdAT", struct.pack(">I", seq) + z)
+            seq += 1
+    return png + chunk(b"IEND", b"")
+

@@ -119,6 +119,19 @@ DustStatus dust_vox_flatten_model(const uint8_t* xyzi, size_t n_voxels, const ui
                                   uint8_t** materials, uint64_t* n_materials);
 void dust_vox_free(void*);
 
+/* ---- PNG / APNG -> sliced image array ----
+ * PngLoader::load (crates/rhyolite_bevy/src/loaders/png.rs:70-200), the loader behind the six spatiotemporal blue-noise
+ * textures (crates/render/src/noise.rs:16-29, 128 x 128 x 64-frame APNGs): every animation frame becomes one layer;
+ * grey and grey+alpha keep 1 / 2 channels, RGB is widened to RGBA with a zero fourth byte, 16-bit samples stay
+ * big-endian. DUST_ERR_UNSUPPORTED for indexed colour, sub-byte samples, interlacing and partial frames.
+ * The result feeds dust_hip_pipeline_set_noise directly (texture 0: 1 channel, texture 5: 4 channels). */
+typedef struct DustPngInfo {
+  uint32_t width, height, layers;
+  uint32_t channels;           /* 1, 2 or 4 */
+  uint32_t bytes_per_channel;  /* 1 or 2 */
+} DustPngInfo;
+DustStatus dust_png_load_array(const uint8_t* bytes, size_t n_bytes, DustPngInfo* info, uint8_t** texels /* dust_vox_free */);
+
 /* ===================================================================== device side
  * Replaces the Vulkan objects the render plugin owns (crates/render/src/lib.rs:58-134): device,
  * BLAS/TLAS stores, SBT, the four ray-tracing pipelines and their persistent buffers. */

@@ -135,6 +135,23 @@ struct VoxScene {
   std::array<uint8_t, 1024> palette{};
 };
 
+// PngLoader (rhyolite_bevy/src/loaders/png.rs:70-200): a PNG / APNG as a sliced image array, one layer per frame
+struct SlicedImageArray {
+  DustPngInfo info{};
+  std::vector<uint8_t> texels;  // layers x height x width x channels x bytes_per_channel
+};
+struct PngLoader {
+  static SlicedImageArray load(const uint8_t* bytes, size_t n) {
+    SlicedImageArray a;
+    uint8_t* p = nullptr;
+    check(dust_png_load_array(bytes, n, &a.info, &p));
+    const size_t total = size_t(a.info.layers) * a.info.height * a.info.width * a.info.channels * a.info.bytes_per_channel;
+    a.texels.assign(p, p + total);
+    dust_vox_free(p);
+    return a;
+  }
+};
+
 class VoxLoader {
  public:
   explicit VoxLoader(RenderContext& ctx) : ctx_(ctx) {}

@@ -55,6 +55,12 @@ static int cpu_tests() {
     DustVoxScene* s = nullptr;
     EXPECT(dust_vox_load(junk, sizeof(junk), &s) == DUST_ERR_PARSE);
   }
+  {  // PngLoader: a file that is not a PNG is a parse error, not a crash
+    bool threw = false;
+    const uint8_t junk[16] = {'N', 'O', 'P', 'E'};
+    try { (void)dust::PngLoader::load(junk, sizeof(junk)); } catch (const dust::Error& e) { threw = e.status == DUST_ERR_PARSE; }
+    EXPECT(threw);
+  }
   std::puts("cpu ok");
   return 0;
 }

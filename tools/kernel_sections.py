@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 if "--build" in sys.argv:
     import __graft_entry__ as G
     srcs = [os.path.join(G.CSRC, s) for s in G.HIP_SOURCES]
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + G.HIPCC_FLAGS + ["-DDUST_PROFILE", "-I", G.CSRC] + srcs + ["-o", PROF_LIB],
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + G.HIPCC_FLAGS + ["-DDUST_PROFILE", "-I", G.CSRC] + srcs + ["-lz", "-o", PROF_LIB],
                           cwd=G.CSRC)
     print("built", PROF_LIB)
     sys.exit(0)
