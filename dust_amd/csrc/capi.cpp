@@ -22,6 +22,7 @@ hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t 
 hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
+hipError_t launch_gather_order(const FrameArgs* dev, uint32_t n_tiles, hipStream_t);
 hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t);
 hipError_t launch_surfel_keys(const FrameArgs* dev, hipStream_t);
@@ -139,6 +140,7 @@ struct DustHipPipeline {
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
   DeviceBuffer gi_sort_keys, gi_sort_vals, gi_sort_keys_out, gi_perm, gi_sort_tmp;  // position order of the surfel pool
   size_t gi_sort_tmp_bytes = 0;
+  DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 32x32 tile grouped by ray octant
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
@@ -845,12 +847,27 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       a.gi.merged = static_cast<dust::DevSurfel*>(p->gi_merged.p);
       HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
     }
-    take_counters(p, 2, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
+    dust::FrameArgs g = a;
+    uint32_t ggrid = grid;
+    if (!std::getenv("DUST_HIP_NO_GATHER_ORDER")) {  // pre-pass: regroup the band's live pixels by ray-direction octant
+      const uint32_t otx = (p->width + 31) / 32, oty = (a.row_end - a.row_begin + 31) / 32;
+      g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
+      g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
+      g.gi.order_tiles_x = otx;
+      const dust::FrameArgs* dk = nullptr;
+      { DustStatus us = upload_args(p, g, st, &dk); if (us != DUST_OK) return us; }
+      HIP_TRY(dust::launch_gather_order(dk, otx * oty, st));
+      HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+      g.tiles_x = otx * oty * 16;  // 16 packets of 64 per tile, the empty ones skipped by the kernel
+      g.tiles_y = 1;
+      ggrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (g.tiles_x + 7) / 8));
+    }
+    take_counters(p, 2, g);
     const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_final_gather(a, d, grid, block, count, !sharded, st));
+    { DustStatus us = upload_args(p, g, st, &d); if (us != DUST_OK) return us; }
+    HIP_TRY(dust::launch_final_gather(g, d, ggrid, block, count, !sharded, st));
     HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
   }
@@ -941,6 +958,11 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_owner.alloc(size_t(surfel_pool_size) * 4));
   HIP_TRY(hipMemset(p->gi_owner.p, 0, size_t(surfel_pool_size) * 4));
   HIP_TRY(p->gi_pixel_surfel.alloc(size_t(p->width) * p->height * 16));
+  {
+    const size_t tiles = size_t((p->width + 31) / 32) * ((p->height + 31) / 32);
+    HIP_TRY(p->gi_order.alloc(tiles * 1024 * 4));
+    HIP_TRY(p->gi_order_count.alloc(tiles * 4));
+  }
   HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));
   HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys, &p->gi_sort_vals, &p->gi_sort_keys_out, &p->gi_perm}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));

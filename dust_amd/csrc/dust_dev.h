@@ -117,6 +117,9 @@ struct DevGI {
   const uint32_t* perm;     // surfel indices ordered by position (k_surfel_keys + radix sort), or null = pool order
   uint32_t* sort_keys;      // pool_size keys / indices the sort consumes (k_surfel_keys fills them)
   uint32_t* sort_vals;
+  uint32_t* order;          // final gather: per 32x32-pixel tile, its live pixels grouped by ray-direction octant (1024 slots per tile)
+  uint32_t* order_count;    // live pixels per tile; null order = plain 8x8 pixel packets
+  uint32_t order_tiles_x;   // 32x32 tiles per row
   uint32_t* touched;        // multi-GPU: per pixel, 1 + index of the hash entry its final gather stamped (null otherwise)
   DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
 };
@@ -144,7 +147,8 @@ struct FrameArgs {
   uint32_t accum_count;       // frames already in `accum`
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
-  uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling); 0 in production
+  uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in
+                              // index order instead of the packet's sorted candidate list); 0 in production
 };
 
 }  // namespace dust

@@ -48,6 +48,14 @@ __device__ __forceinline__ void prof_count(int idx, unsigned long long n) {
 #define PROF_LEAVE(i)
 #define PROF_COUNT(i, n)
 #endif
+// -DDUST_TRACE_DEBUG (never shipped): printf what the final gather does for ONE pixel, DUST_HIP_DEBUG = (pixel index + 1) << 12
+#ifdef DUST_TRACE_DEBUG
+__shared__ unsigned long long g_dbg_mask[16];  // per wave: lanes being traced verbosely
+#define DBG_LANE() ((g_dbg_mask[threadIdx.x >> 6] >> (threadIdx.x & 63u)) & 1ull)
+#define DBG_PRINT(...) do { if (DBG_LANE()) printf(__VA_ARGS__); } while (0)
+#else
+#define DBG_PRINT(...)
+#endif
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
        P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)  // the P_N_* buckets count events, not cycles
@@ -425,6 +433,7 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
   uint32_t vox;
   if (COUNT) st.bricks_tested += 1;
   if (!brick_intersect<RT>(ol, d, inv_d, (uint32_t)mask, (uint32_t)(mask >> 32), tmin, t, vox)) return;
+  DBG_PRINT("    brick inst %u key %u at %d,%d,%d: t=%.9g (best found=%d t=%.9g inst=%u blk=%u)\n", inst, key, bx, by, bz, t, (int)best.found, best.t, best.inst, best.block);
   const float cur = best.found ? best.t : tmax;
   if (!(t >= tmin && t <= cur)) return;
   if (best.found && t == best.t) {
@@ -438,17 +447,22 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
 // inlined: the hot loop then carries neither this code's registers nor a second copy of the lookup and brick test
 // (inlined, the same code cost the fused kernel 15 %). State goes in and out by value so nothing of the caller's has
 // its address taken.
-struct NeighbourVisit {
-  Hit best;
-  MidCache mc;
-  uint32_t bricks_tested;
-};
+// Everything crosses the call in registers: scalars in, one 8-word vector out
+// {t, inst, block, voxel, found, mc.key, mc.mid, bricks_tested}. (Structs by value go through the stack here, and a build
+// that passed Hit that way resolved equal-t ties between overlapping instances differently from the inlined code.)
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 template <int RT, bool COUNT>
-__device__ __attribute__((noinline)) NeighbourVisit visit_neighbours(const DUST_CONST_AS DevModel* mp, uint32_t inst, V3 o, V3 d, V3 inv_d,
-                                                                    float tmin, float tmax, float t, int i0, int i1, int i2,
-                                                                    uint32_t stepped, Hit best, MidCache mc) {
+__device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS DevModel* mp, uint32_t inst, float ox, float oy, float oz,
+                                                           float dx, float dy, float dz, float ix, float iy, float iz,
+                                                           float tmin, float tmax, float t, int i0, int i1, int i2, uint32_t stepped,
+                                                           float best_t, uint32_t best_inst, uint32_t best_block, uint32_t best_voxel,
+                                                           uint32_t best_found, int mc_key, uint32_t mc_mid) {
   ModelRef m = *mp;
-  NeighbourVisit out;
+  const V3 o = mk(ox, oy, oz), d = mk(dx, dy, dz), inv_d = mk(ix, iy, iz);
+  Hit best;
+  best.t = best_t; best.inst = best_inst; best.block = best_block; best.voxel = best_voxel; best.found = best_found != 0;
+  MidCache mc;
+  mc.key = mc_key; mc.mid = mc_mid;
   LaneStats st = {0, 0, 0, 0, 0, 0};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   const int ijk[3] = {i0, i1, i2};
@@ -480,9 +494,9 @@ __device__ __attribute__((noinline)) NeighbourVisit visit_neighbours(const DUST_
       if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
     }
   }
-  out.best = best;
-  out.mc = mc;
-  out.bricks_tested = st.bricks_tested;
+  u32x8 out;
+  out[0] = __float_as_uint(best.t); out[1] = best.inst; out[2] = best.block; out[3] = best.voxel; out[4] = best.found ? 1u : 0u;
+  out[5] = (uint32_t)mc.key; out[6] = mc.mid; out[7] = st.bricks_tested;
   return out;
 }
 
@@ -555,10 +569,12 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     PROF_ENTER(P_SCREEN);
     if (__builtin_expect(screen, 0)) {
       PROF_COUNT(P_N_NEIGHBOUR_CALLS, 1);
-      const NeighbourVisit nv = visit_neighbours<RT, COUNT>(&m, inst, o, d, inv_d, tmin, tmax, t, ijk[0], ijk[1], ijk[2], stepped, best, mc);
-      best = nv.best;
-      mc = nv.mc;
-      if (COUNT) st.bricks_tested += nv.bricks_tested;
+      const u32x8 nv = visit_neighbours<RT, COUNT>(&m, inst, o.x, o.y, o.z, d.x, d.y, d.z, inv_d.x, inv_d.y, inv_d.z, tmin, tmax, t,
+                                                   ijk[0], ijk[1], ijk[2], stepped, best.t, best.inst, best.block, best.voxel,
+                                                   best.found ? 1u : 0u, mc.key, mc.mid);
+      best.t = __uint_as_float(nv[0]); best.inst = nv[1]; best.block = nv[2]; best.voxel = nv[3]; best.found = nv[4] != 0;
+      mc.key = (int)nv[5]; mc.mid = nv[6];
+      if (COUNT) st.bricks_tested += nv[7];
     }
     PROF_LEAVE(P_SCREEN);
     // leave the cell of size 2^cl_main that contains ijk
@@ -733,7 +749,7 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // popcounts of ballots: uniform, but only we know
   PROF_COUNT(P_N_TRACES, 1);
   PROF_COUNT(P_N_CAND, ncand);
-  const bool all = ncand > kMaxCand;
+  const bool all = ncand > kMaxCand || (a.debug & 4u);  // debug bit 4: ignore the list, walk every instance in index order
   const uint32_t n = all ? a.n_instances : ncand;
   // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
   // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
@@ -865,6 +881,9 @@ __device__ __forceinline__ void prof_end() {
 }
 __device__ __forceinline__ void stage_roots(ArgsRef a) {
   prof_begin();
+#ifdef DUST_TRACE_DEBUG
+  if (threadIdx.x < 16) g_dbg_mask[threadIdx.x] = 0;
+#endif
   if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
@@ -1228,6 +1247,65 @@ __device__ void brick_surfel(ArgsRef a, const Hit& h, V3 o, V3 d, HashKey& key, 
 }  // namespace
 
 // ==================================================================== final gather
+// final_gather.rgen:14-44: is this pixel's gather ray live, and where does it start and point?
+__device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, bool valid, V3& inval, V3& loc, V3& ad) {
+  const size_t pix = valid ? (size_t)py * a.width + px : 0;
+  const float hitT = valid ? a.g.depth[pix] : INFINITY;
+  bool live = valid && !(hitT == INFINITY);
+  inval = mk(0, 0, 0); loc = mk(0, 0, 0); ad = mk(0, 0, 1);
+  if (live) {
+    float w;
+    inval = load_radiance(a.g.illuminance, pix, w);
+    if (w > 0.0f) live = false;  // resolved by the ambient occlusion pass
+  }
+  if (live) {
+    const V3 n = nrd_unpack_normal(a.g.normal[pix]);
+    const V3 d = camera_ray_dir(a.cam, px, py, a.width, a.height);
+    loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
+             (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+    const uint32_t nx = (px + 7u + a.rand) % 128u, ny = (py + 183u + a.rand) % 128u;
+    const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
+    const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
+                     (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+    ad = normalize3(rotate_by_normal(n, ns));
+  }
+  return live;
+}
+
+// Regrouping pre-pass. Gather rays leave neighbouring pixels in unrelated directions, so an 8x8 pixel packet bounds
+// nothing by direction and most of its lanes idle through every instance visit. One workgroup per 32x32 pixel tile
+// orders the tile's LIVE pixels by the octant their ray points into (a stable counting sort on ballots: deterministic);
+// k_final_gather then takes 64 consecutive entries as a packet: same neighbourhood, one octant, no dead lanes.
+// Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
+constexpr uint32_t kOrderTile = 32, kOrderSlots = kOrderTile * kOrderTile;
+__global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs* __restrict__ ap) {
+  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+  __shared__ uint32_t cnt[kOrderSlots / 64][8];
+  const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
+  const uint32_t px = tx * kOrderTile + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTile + (threadIdx.x / kOrderTile);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  V3 inval, loc, ad;
+  const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
+  const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) : 8u;
+  uint32_t below = 0;  // lanes of this wave with the same key and a lower lane id
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint64_t m = __ballot(key == k);
+    if (lane == 0) cnt[wave][k] = (uint32_t)__popcll(m);
+    if (key == k) below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  uint32_t rank = below, total = 0;
+  for (uint32_t k = 0; k < 8; ++k)
+    for (uint32_t w = 0; w < kOrderSlots / 64; ++w) {
+      const uint32_t c = cnt[w][k];
+      total += c;
+      if (k < key || (k == key && w < wave)) rank += c;
+    }
+  if (live) a.gi.order[(size_t)tile * kOrderSlots + rank] = py * a.width + px;
+  if (threadIdx.x == 0) a.gi.order_count[tile] = total;
+}
+
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __restrict__ ap) {
@@ -1238,26 +1316,26 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
   WorkCursor wc = cursor_begin();
   Packet p;
   while (next_packet(a, wc, p)) {
+    if (a.gi.order) {  // regrouped: packet id -> 64 entries of one tile's octant-ordered pixel list
+      const uint32_t id = p.px >> 3, tile = id / (kOrderSlots / 64u), idx = (id % (kOrderSlots / 64u)) * 64u + (threadIdx.x & 63u);
+      const uint32_t n = a.gi.order_count[tile];
+      if ((idx & ~63u) >= n) continue;  // this tile has fewer live pixels
+      p.valid = idx < n;
+      const uint32_t pixel = p.valid ? a.gi.order[(size_t)tile * kOrderSlots + idx] : 0u;
+      p.px = pixel % a.width;
+      p.py = pixel / a.width;
+    }
     const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
-    const float hitT = p.valid ? a.g.depth[pix] : INFINITY;
-    bool live = p.valid && !(hitT == INFINITY);
-    V3 inval = mk(0, 0, 0), loc = mk(0, 0, 0), ad = mk(0, 0, 1);
-    if (live) {
-      float w;
-      inval = load_radiance(a.g.illuminance, pix, w);
-      if (w > 0.0f) live = false;  // resolved by the ambient occlusion pass
+    V3 inval, loc, ad;
+    const bool live = gather_ray(a, p.px, p.py, p.valid, inval, loc, ad);
+#ifdef DUST_TRACE_DEBUG
+    {
+      const unsigned long long m = __ballot(p.valid && (uint32_t)pix + 1u == (a.debug >> 12));
+      if ((threadIdx.x & 63u) == 0) g_dbg_mask[threadIdx.x >> 6] = m;
+      __builtin_amdgcn_wave_barrier();
+      DBG_PRINT("FG pixel %u,%u live=%d o=%.9g,%.9g,%.9g d=%.9g,%.9g,%.9g\n", p.px, p.py, (int)live, loc.x, loc.y, loc.z, ad.x, ad.y, ad.z);
     }
-    if (live) {
-      const V3 n = nrd_unpack_normal(a.g.normal[pix]);
-      const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
-      loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
-               (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
-      const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
-      const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
-      const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
-                       (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
-      ad = normalize3(rotate_by_normal(n, ns));
-    }
+#endif
     Hit h;
     const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
     trace_ray<2, COUNT>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
@@ -1662,6 +1740,10 @@ hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t s) {
   hipLaunchKernelGGL(k_gi_import, dim3(1024), dim3(256), 0, s, dev);
   return hipGetLastError();
 }
+hipError_t launch_gather_order(const FrameArgs* dev, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderSlots), 0, s, dev);
+  return hipGetLastError();
+}
 hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
   const size_t lds = lds_bytes(host, block);
   if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, dev);
@@ -1689,6 +1771,9 @@ hipError_t configure_kernels(size_t max_lds) {
   hipError_t e;
 #ifdef DUST_PROFILE
   max_lds -= sizeof(g_prof);  // the profiling build's static buckets come out of the same 160 KB
+#endif
+#ifdef DUST_TRACE_DEBUG
+  max_lds -= 1024;
 #endif
   const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
                        (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>,
