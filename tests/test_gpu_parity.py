@@ -173,3 +173,26 @@ def test_api_errors(ctx, noise5):
         api.Model(ctx, b[::-1].copy(), m, desc.palette)
     with pytest.raises(L.DustError):  # singular transform
         api.Scene(ctx).add_instance(api.Model(ctx, b, m, desc.palette), np.zeros(12, np.float32))
+
+
+def test_candidate_list_and_index_order_agree(ctx, noise5, monkeypatch):
+    """The packet's sorted candidate list (culling, front-to-back order, early exit) against the plain walk over every
+    instance in index order (DUST_HIP_DEBUG bit 4): every plane identical on the castle, whose instances overlap."""
+    data, _ = synth.castle_scene(scale=0.15)
+    desc = P.SceneDesc.from_vox(data)
+    scene = P.hip_scene(ctx, desc)
+    s = 0.15
+    cam, sky = P.camera_for((122.0 * s, 300.61 * s, 54.45 * s)), P.sky_state()
+    outs = []
+    for dbg in (None, "4"):
+        if dbg:
+            monkeypatch.setenv("DUST_HIP_DEBUG", dbg)
+        else:
+            monkeypatch.delenv("DUST_HIP_DEBUG", raising=False)
+        pipe = api.StandardPipeline(ctx, 384, 216)
+        pipe.set_noise(5, noise5)
+        pipe.render(scene, cam, sky, L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION, frame_index=3, rand=99)
+        outs.append(P.read_hip_gbuffer(pipe))
+    monkeypatch.delenv("DUST_HIP_DEBUG", raising=False)
+    for k in outs[0]:
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
