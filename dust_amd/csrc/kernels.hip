@@ -533,13 +533,13 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   const float near_tol = 3.0e-7f * (reach + 16.0f);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    // A walk that starts on the model's bounds (every visit from outside does: the bounds are brick planes) is "near a
-    // plane" there by construction, but no brick exists beyond it -- the exact test would say so too; do not pay a
-    // call to hear it.
-    const float p = oo[a] + dd[a] * t;
-    const float r = p * 0.25f;
-    const bool on_bounds = fabsf(p - m.bmin[a]) <= 4.0f * near_tol || fabsf(p - m.bmax[a]) <= 4.0f * near_tol;
-    screen = screen | ((fabsf(r - rintf(r)) <= near_tol) & !on_bounds);
+    // The first cell gets the exact test's own shape with the looser tolerance, because it can tell what the cheap
+    // distance-to-a-multiple-of-4 cannot: a walk that starts on the model's bounds (every visit from outside does:
+    // the bounds are brick planes) is "near a plane" there by construction, but no brick exists beyond it, and that
+    // is not worth a call. (A plane only matters if bricks can exist on its far side.)
+    const int b0 = ijk[a] & ~3, blo = (int)m.bmin[a], bhi = (int)m.bmax[a] - 1;
+    const float q = (oo[a] + dd[a] * t) - (float)b0;
+    screen = screen | ((q <= 4.0f * near_tol) & (b0 - 1 >= blo)) | ((q >= 4.0f - 4.0f * near_tol) & (b0 + 4 <= bhi));
   }
   uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
   uint32_t cl_main = 2;

@@ -147,14 +147,23 @@ def compare_gbuffers(g, hip, check_ao=False):
     # radiance planes go through exp/pow/acos: compare as floats
     den_o, den_h = half_to_float(g.denoised), half_to_float(hip["denoised"])
     miss = ~hit
+    def rel_l2(a, b):
+        """relative L2 over the finite samples; where fp16 overflowed (looking into the sun) both sides must hold the
+        same non-finite half"""
+        fin = np.isfinite(a) & np.isfinite(b)
+        if not np.array_equal(np.isfinite(a), np.isfinite(b)) or not np.array_equal(np.sign(a[~fin]), np.sign(b[~fin])):
+            return float("inf")
+        a, b = a[fin].astype(np.float64), b[fin].astype(np.float64)
+        return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))
+
     if miss.any():
         a, b = den_o[miss][:, :3], den_h[miss][:, :3]
-        res["denoised_rel_l2"] = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))
+        res["denoised_rel_l2"] = rel_l2(a, b)
         res["denoised_hitdist"] = int(np.count_nonzero(g.denoised[miss][:, 3] != hip["denoised"][miss][:, 3]))
     ill_o, ill_h = half_to_float(g.illuminance), half_to_float(hip["illuminance"])
     if hit.any():
         a, b = ill_o[hit][:, :3], ill_h[hit][:, :3]
-        res["illuminance_rel_l2"] = float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))
+        res["illuminance_rel_l2"] = rel_l2(a, b)
         res["illuminance_hitdist"] = int(np.count_nonzero(g.illuminance[hit][:, 3] != hip["illuminance"][hit][:, 3]))
     return res
 

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (GPU box; minutes, not part of pytest).
+Many small random scenes -- overlapping instances on aligned and half-voxel-shifted lattices, axis rotations and mirrors,
+cameras inside and outside, axis-parallel views -- through all five passes for a few frames each; integer planes, hit
+distances and GI state must match the oracle bit for bit, radiance within 1e-3.
+usage: stress_parity.py [n_scenes] [first_seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import parity_util as P  # noqa: E402
+from dust_amd import _lib as L, api, synth  # noqa: E402
+
+def run(n_scenes, seed0, big=False, verbose=True):
+    """Returns the seeds whose frames did not match."""
+    ctx = api.Context(device=0)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    failed = []
+    for k in range(n_scenes):
+        seed = seed0 + k
+        rng = np.random.default_rng(seed)
+        desc = P.small_scene(seed=seed, n_models=int(rng.integers(1, 6 if big else 4)), n_instances=int(rng.integers(1, 25 if big else 9)),
+                             size=tuple(int(v) for v in rng.integers(12, 110 if big else 40, 3)))
+        if k % 3 == 0:   # stack instances on top of each other: equal-t ties between instances
+            desc.instances = [(m, t.copy()) for m, t in desc.instances]
+            for j in range(1, len(desc.instances)):
+                desc.instances[j][1][3::4] = desc.instances[0][1][3::4] + rng.integers(-2, 3, 3) * 4.0
+        scene, oscene = P.hip_scene(ctx, desc), P.oracle_scene(desc)
+        eye = rng.uniform(-90, 90, 3)
+        if k % 5 == 0:
+            eye = np.round(eye / 4.0) * 4.0   # on the lattice
+        if k % 7 == 0:
+            eye[int(rng.integers(0, 3))] = 0.0
+        cam = P.camera_for(tuple(float(v) for v in eye), target=tuple(float(v) for v in rng.uniform(-10, 10, 3)) if k % 4 else (0.0, 0.0, 0.0))
+        w, h = int(rng.integers(40, 140)), int(rng.integers(24, 90))
+        cap, pool = int(rng.choice([61, 509, 4093, 1 << 14])), int(rng.choice([97, 777, 2048]))
+        pipe = api.StandardPipeline(ctx, w, h)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(cap, pool)
+        gi = O.GI(cap, pool)
+        f = 0
+        try:
+            for f in range(1, 4):
+                rnd = synth.frame_rand(seed, f)
+                pipe.render(scene, cam, sky, passes | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
+                g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f)
+                res = P.compare_gbuffers(g, P.read_hip_gbuffer(pipe))
+                P.assert_parity(res)
+                assert res.get("illuminance_rel_l2", 0.0) <= 1e-3 and res.get("denoised_rel_l2", 0.0) <= 1e-3, res
+                oh, op = gi.hash(), gi.pool()
+                hh, hp = pipe.read_gi()
+                assert np.array_equal(oh["fingerprint"], hh[:, 0]), "hash fingerprints"
+                assert np.array_equal(oh["sample_count"], hh[:, 2] >> 16), "hash sample counts"
+                assert np.array_equal(oh["last_accessed_frame"], hh[:, 2] & 0xFFFF), "hash LRU stamps"
+                assert np.array_equal(op["direction"], hp["direction"]), "surfel pool"
+        except AssertionError as e:
+            failed.append(seed)
+            if verbose:
+                print(f"seed {seed}: MISMATCH frame {f} ({w}x{h}, {len(desc.instances)} instances, eye {eye}): {str(e)[:300]}", flush=True)
+    return failed
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    bad = run(n, first, big=os.environ.get("STRESS_BIG") == "1")
+    print(f"{n} scenes, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
