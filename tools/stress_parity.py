@@ -38,6 +38,8 @@ def run(n_scenes, seed0, big=False, verbose=True):
             eye = np.round(eye / 4.0) * 4.0   # on the lattice
         if k % 7 == 0:
             eye[int(rng.integers(0, 3))] = 0.0
+        if abs(eye[0]) + abs(eye[2]) < 1e-3:
+            eye[0] = 1.0   # straight up/down the y axis has no look-at frame (NaN camera): not a traversal case
         cam = P.camera_for(tuple(float(v) for v in eye), target=tuple(float(v) for v in rng.uniform(-10, 10, 3)) if k % 4 else (0.0, 0.0, 0.0))
         w, h = int(rng.integers(40, 140)), int(rng.integers(24, 90))
         cap, pool = int(rng.choice([61, 509, 4093, 1 << 14])), int(rng.choice([97, 777, 2048]))
