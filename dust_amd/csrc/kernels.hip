@@ -1280,7 +1280,9 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 constexpr uint32_t kOrderTile = 32, kOrderSlots = kOrderTile * kOrderTile;
 __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs* __restrict__ ap) {
   ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
-  __shared__ uint32_t cnt[kOrderSlots / 64][8];
+  constexpr uint32_t kWaves = kOrderSlots / 64;
+  __shared__ uint32_t cnt[8 * kWaves];   // [octant][wave] counts, then their exclusive prefix in that (octant-major) order
+  __shared__ uint32_t half_total[2];
   const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
   const uint32_t px = tx * kOrderTile + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTile + (threadIdx.x / kOrderTile);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1291,19 +1293,27 @@ __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs* _
 #pragma unroll
   for (uint32_t k = 0; k < 8; ++k) {
     const uint64_t m = __ballot(key == k);
-    if (lane == 0) cnt[wave][k] = (uint32_t)__popcll(m);
+    if (lane == 0) cnt[k * kWaves + wave] = (uint32_t)__popcll(m);
     if (key == k) below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  uint32_t rank = below, total = 0;
-  for (uint32_t k = 0; k < 8; ++k)
-    for (uint32_t w = 0; w < kOrderSlots / 64; ++w) {
-      const uint32_t c = cnt[w][k];
-      total += c;
-      if (k < key || (k == key && w < wave)) rank += c;
+  // exclusive scan of the 128 counters by the first two waves (each scans its 64, the second adds the first's total)
+  uint32_t v = 0, inc = 0;
+  if (threadIdx.x < 8 * kWaves) {
+    v = cnt[threadIdx.x];
+    inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d);
+      if (lane >= d) inc += up;
     }
-  if (live) a.gi.order[(size_t)tile * kOrderSlots + rank] = py * a.width + px;
-  if (threadIdx.x == 0) a.gi.order_count[tile] = total;
+    if (lane == 63) half_total[wave] = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * kWaves) cnt[threadIdx.x] = inc - v + (wave == 1 ? half_total[0] : 0u);
+  __syncthreads();
+  if (live) a.gi.order[(size_t)tile * kOrderSlots + cnt[key * kWaves + wave] + below] = py * a.width + px;
+  if (threadIdx.x == 0) a.gi.order_count[tile] = half_total[0] + half_total[1];
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
