@@ -151,7 +151,9 @@ def compare_gbuffers(g, hip, check_ao=False):
         """relative L2 over the finite samples; where fp16 overflowed (looking into the sun) both sides must hold the
         same non-finite half"""
         fin = np.isfinite(a) & np.isfinite(b)
-        if not np.array_equal(np.isfinite(a), np.isfinite(b)) or not np.array_equal(np.sign(a[~fin]), np.sign(b[~fin])):
+        inf_a, inf_b = np.isinf(a), np.isinf(b)
+        if (not np.array_equal(np.isnan(a), np.isnan(b)) or not np.array_equal(inf_a, inf_b)
+                or not np.array_equal(np.sign(a[inf_a]), np.sign(b[inf_b]))):   # NaNs (acos of 1 + ulp in the sky model) carry no sign
             return float("inf")
         a, b = a[fin].astype(np.float64), b[fin].astype(np.float64)
         return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((a ** 2).sum())))

@@ -32,6 +32,19 @@ def run(n_scenes, seed0, big=False, verbose=True):
             desc.instances = [(m, t.copy()) for m, t in desc.instances]
             for j in range(1, len(desc.instances)):
                 desc.instances[j][1][3::4] = desc.instances[0][1][3::4] + rng.integers(-2, 3, 3) * 4.0
+        if k % 2 == 1 and os.environ.get("STRESS_AFFINE", "1") == "1":   # arbitrary rotations, non-uniform scales, fractional offsets
+            desc.instances = [(m, t.copy()) for m, t in desc.instances]
+            for j in range(len(desc.instances)):
+                q = rng.normal(size=4)
+                q /= np.linalg.norm(q)
+                qw, qx, qy, qz = q
+                R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                              [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                              [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+                A = (R * rng.uniform(0.5, 2.0, 3)[None, :]).astype(np.float32)
+                t = desc.instances[j][1].reshape(3, 4)
+                t[:, :3] = A
+                t[:, 3] = rng.uniform(-50, 50, 3).astype(np.float32)
         scene, oscene = P.hip_scene(ctx, desc), P.oracle_scene(desc)
         eye = rng.uniform(-90, 90, 3)
         if k % 5 == 0:
