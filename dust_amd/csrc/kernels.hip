@@ -988,6 +988,20 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
 }
 
+// What a sun-lit point receives per unit cos(theta): the same for every ray of a frame (nee.rmiss:11-22 evaluates it per
+// ray), so each wave works it out once and carries it as scalars.
+struct SunTerm { V3 sd, srk; };
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ SunTerm sun_term(ArgsRef a) {
+  SunTerm s;
+  const V3 sd = normalize3(mk(a.sky[48], a.sky[49], a.sky[50]));
+  const V3 sr = sun_radiance(a.sky, normalize3(sd));
+  const float kk = 1.0f - cosf(a.sky[55]);
+  s.sd = mk(uniform_f(sd.x), uniform_f(sd.y), uniform_f(sd.z));
+  s.srk = mk(uniform_f(sr.x * kk), uniform_f(sr.y * kk), uniform_f(sr.z * kk));
+  return s;
+}
+
 // ==================================================================== sun shadow + ambient occlusion
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
@@ -1026,6 +1040,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
     __builtin_amdgcn_wave_barrier();
     if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22
+      // (evaluated per packet on purpose: carried across the fused kernel's loop as in k_surfel_trace it measured 2.5 % slower)
       const V3 sr = sun_radiance(a.sky, normalize3(sd));
       const float kk = 1.0f - cosf(a.sky[55]);
       const float dn = dot3(n, sd);
@@ -1467,6 +1482,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
+  const SunTerm sunt = sun_term(a);
   WorkCursor wc = cursor_begin();
   Packet p;
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
@@ -1494,7 +1510,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
     }
     V3 payload = mk(0, 0, 0);
     const bool sun_live = live && dot3(sun, n) > 0.0f;
-    const V3 sd = normalize3(sun);
+    const V3 sd = sunt.sd;
     Hit h;
     const Range3 orgs = wave_range(live, org);
 #pragma unroll 1
@@ -1507,10 +1523,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
       if (COUNT) add_stats(k == 0 ? st_sun : st_cos, cur);
       __builtin_amdgcn_wave_barrier();
       if (k == 0 && sun_live && !h.found) {  // surfel/nee.rmiss:15-27
-        const V3 sr = sun_radiance(a.sky, normalize3(sd));
-        const float kk = 1.0f - cosf(a.sky[55]);
         const float dn = dot3(n, sd);
-        payload = mk((sr.x * kk) * dn, (sr.y * kk) * dn, (sr.z * kk) * dn);
+        payload = mk(sunt.srk.x * dn, sunt.srk.y * dn, sunt.srk.z * dn);
       }
     }
     if (live) {
