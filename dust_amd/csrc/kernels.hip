@@ -7,8 +7,10 @@
 //     per-XCD-region atomic counters (block b runs on XCD b%8, so a region stays in one L2);
 //   * the root node (4096-bit child mask + rank prefix) of every model is staged in LDS once per
 //     workgroup; mid nodes and brick masks come from HBM/L2 (16 B and 8 B loads);
-//   * the packet's rays are bounded once (wave reductions) and tested against all instance boxes
-//     64 at a time (__ballot compaction into an LDS candidate list);
+//   * the packet's rays are bounded once (DPP wave reductions) and tested against all instance boxes
+//     64 at a time (__ballot compaction into a per-wave LDS candidate list, rank-sorted front to back);
+//   * incoherent rays are regrouped before they are traced: gather rays by direction octant inside
+//     32x32 pixel tiles (k_gather_order), surfels by position (k_surfel_keys + a radix sort);
 //   * per ray, a hierarchical DDA over 16^3 / 4^3 cells finds candidate bricks front to back; the
 //     brick test itself is the reference's intersection shader arithmetic, bit for bit
 //     (primary/hit.rint:43-131, final_gather/ambient_occlusion.rint:46-134, rough.rint:42-59).
