@@ -79,8 +79,7 @@ def main():
 
     from dust_amd import _lib as L
     from dust_amd import api, sharding, synth
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import parity_util as P  # scene description helpers + sky fixture (shared with the tests)
+    from dust_amd import scenes as P  # scene description helpers + sky fixture; the oracle is only imported in the cpu_baseline leg
 
     W, H = args.width, args.height
     Hband = H
@@ -251,8 +250,10 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O  # the checker, used here only as the reported CPU baseline (never in the timed GPU path)
-        oscene = P.oracle_scene(desc)
+        import parity_util
+        oscene = parity_util.oracle_scene(desc)
         cores = os.cpu_count() or 1
         n_rows = args.cpu_rows or max(cores, min(Hband, 8 * cores))
         y0 = (Hband - n_rows) // 2

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from PIL import Image
 
-import parity_util as P
+from dust_amd import scenes as P
 from dust_amd import _lib as L, api, synth
 
 out = sys.argv[1] if len(sys.argv) > 1 else "castle.png"

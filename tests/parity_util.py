@@ -10,30 +10,9 @@ import oracle_lib as O
 from dust_amd import _lib as L
 from dust_amd import api, synth
 
+from dust_amd.scenes import SceneDesc, camera_for, hip_scene, sky_state  # noqa: F401  (oracle-free, shared with bench.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def sky_state(name="default"):
-    with open(os.path.join(ROOT, "tests", "golden", "sky_states.json")) as f:
-        return np.asarray(json.load(f)[name]["state"], np.float32)
-
-
-class SceneDesc:
-    """Flattened scene: models [(blocks, materials)], one palette, instances [(model, obj_to_world[12])]."""
-
-    def __init__(self, models, palette, instances):
-        self.models, self.palette, self.instances = models, palette, instances
-
-    @staticmethod
-    def from_vox(data: bytes):
-        vs = api.VoxScene(data)
-        used = sorted({m for m, _ in vs.instances})
-        remap = {m: i for i, m in enumerate(used)}
-        models = [vs.model_data(m) for m in used]
-        return SceneDesc(models, vs.palette, [(remap[m], t) for m, t in vs.instances])
-
-    def n_bricks(self):
-        return sum(len(b) for b, _ in self.models)
 
 
 def random_model(rng, size=(48, 40, 56), fill=0.08, blobs=6):
@@ -79,21 +58,6 @@ def oracle_scene(desc: SceneDesc):
         s.add_instance(mid, t)
     s.commit()
     return s
-
-
-def hip_scene(ctx, desc: SceneDesc):
-    models = [api.Model(ctx, b, m, desc.palette) for b, m in desc.models]
-    s = api.Scene(ctx)
-    for mid, t in desc.instances:
-        s.add_instance(models[mid], t)
-    s.commit()
-    return s
-
-
-def camera_for(desc_or_eye, target=(0.0, 0.0, 0.0), proj=None):
-    proj = proj or api.PinholeProjection()
-    eye = desc_or_eye
-    return api.make_camera(eye, api.look_at_rotation(eye, target), proj)
 
 
 def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.ORC_MODE_HIER, rows=None, stats=None,

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-import parity_util as P  # noqa: E402
+from dust_amd import scenes as P  # noqa: E402
 from dust_amd import _lib as L, api, synth  # noqa: E402
 
 occ = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01

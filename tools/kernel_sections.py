@@ -26,7 +26,7 @@ if "--build" in sys.argv:
     sys.exit(0)
 
 os.environ["DUST_HIP_LIB"] = PROF_LIB
-import parity_util as P  # noqa: E402
+from dust_amd import scenes as P  # noqa: E402
 from dust_amd import _lib as L, api, synth  # noqa: E402
 
 NAMES = ["total", "grab", "cull", "trace_ray", "instance", "find_brick", "brick_test", "screen", "advance", "stage_roots"]

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import parity_util as P
+from dust_amd import scenes as P
 from dust_amd import _lib as L, api, synth
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
