@@ -47,3 +47,14 @@ def test_product_does_not_reference_the_oracle():
                 if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                     text = open(os.path.join(dp, f)).read()
                     assert "oracle_lib" not in text and "liboracle" not in text and "orc_" not in text, os.path.join(dp, f)
+
+
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    leg = text.index("if not args.no_cpu_baseline:")
+    head = text[:leg]
+    assert "import oracle_lib" not in head and "parity_util" not in head
+    assert "import oracle_lib" in text[leg:]
+    for tool in ("tools/kernel_sections.py", "tools/ray_stats.py", "tools/gi_timing.py", "tools/deep_tree_timing.py", "examples/render_castle.py"):
+        t = open(os.path.join(ROOT, tool)).read()
+        assert "oracle_lib" not in t and "parity_util" not in t, tool
