@@ -36,7 +36,10 @@ if __name__ == "__main__":
                  "means per launch of the timed (non-counting) kernel instantiations. FETCH_SIZE/WRITE_SIZE are KiB. "
                  "MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies half of a wide coalesced read stream, so it is doubled "
                  "as prescribed; these kernels' 8/16-byte gathers are an uncalibrated width, so the read side is an upper bound. "
-                 "WRITE_SIZE exceeds the G-buffer bytes because the 8x8-pixel packets write 32-byte row segments of the "
+                 "Calibration on a kernel with known traffic in the same run: k_accumulate streams 28 B/px in and 24 B/px out "
+                 "(58.1 MB / 49.8 MB at 1080p) and reports FETCH_SIZE 29.0 MB (x2 = 58.1) and WRITE_SIZE 49.8 MB -- the doubling "
+                 "rule holds for its 16-byte reads and WRITE_SIZE is exact for full-line stores. The traversal kernels' "
+                 "WRITE_SIZE exceeds their G-buffer bytes because the 8x8-pixel packets write 32-byte row segments of the "
                  "4-byte planes, which the counter tallies as 64-byte requests.",
          "fetch_size_kib": {}, "write_size_kib": {}, "hbm_bytes_per_launch": {}, "tcc_hit": {}, "tcc_miss": {}}
     for k, v in c.items():
