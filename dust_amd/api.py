@@ -278,6 +278,15 @@ class Scene:
         self._models.append(model)
         return idx.value
 
+    def set_transform(self, instance, obj_to_world, prev=None):
+        """New transform for an instance (castle.rs:287-291 moves the teapot every frame); prev = last frame's
+        object-to-world mat4, column-major (standard.rs:845-878), which the motion vectors are measured against."""
+        m = np.ascontiguousarray(obj_to_world, np.float32).reshape(12)
+        p = None if prev is None else np.ascontiguousarray(prev, np.float32).reshape(16)
+        L.check(self._lib.dust_hip_scene_set_transform(
+            self._h, instance, m.ctypes.data_as(C.POINTER(C.c_float)),
+            None if p is None else p.ctypes.data_as(C.POINTER(C.c_float))))
+
     def commit(self):
         L.check(self._lib.dust_hip_scene_commit(self._h))
 

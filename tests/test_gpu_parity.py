@@ -196,3 +196,46 @@ def test_candidate_list_and_index_order_agree(ctx, noise5, monkeypatch):
     monkeypatch.delenv("DUST_HIP_DEBUG", raising=False)
     for k in outs[0]:
         assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def test_moving_instance_motion_vectors(ctx, noise5):
+    """teapot_move_system (examples/castle.rs:287-291): an instance moves between frames; the motion plane is measured
+    against the previous frame's object-to-world matrix (standard.rs:845-878), bit for bit like the oracle's."""
+    desc = P.small_scene(seed=21, n_models=2, n_instances=3, size=(32, 32, 32))
+    sky, cam = P.sky_state(), P.camera_for((70.0, 55.0, 80.0))
+    models = [api.Model(ctx, b, m, desc.palette) for b, m in desc.models]
+    scene = api.Scene(ctx)
+    ids = [scene.add_instance(models[mid], t) for mid, t in desc.instances]
+    scene.commit()
+    w, h = 160, 100
+    pipe = api.StandardPipeline(ctx, w, h)
+    pipe.set_noise(5, noise5)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+
+    def mat4_cols(t12):  # 3x4 row-major -> column-major mat4
+        m4 = np.eye(4, dtype=np.float32)
+        m4[:3, :] = np.asarray(t12, np.float32).reshape(3, 4)
+        return m4.T.reshape(16).copy()
+
+    cur = [np.asarray(t, np.float32).reshape(12).copy() for _, t in desc.instances]
+    for frame in range(1, 4):
+        prev = [mat4_cols(t) for t in cur]
+        cur[0] = cur[0].copy()
+        cur[0][7] += 2.5                       # the first instance rises 2.5 units per frame
+        cur[1] = cur[1].copy()
+        cur[1][3] -= 0.75                      # the second slides along x
+        for j in (0, 1):
+            scene.set_transform(ids[j], cur[j], prev[j])
+        scene.commit()
+        os_ = O.Scene()
+        for b, m in desc.models:
+            os_.add_model(b, m, desc.palette)
+        for j, (mid, _) in enumerate(desc.instances):
+            os_.add_instance(mid, cur[j], prev[j] if j < 2 else None)
+        os_.commit()
+        pipe.render(scene, cam, sky, passes, frame_index=frame, rand=frame * 13)
+        g = P.render_oracle(os_, cam, sky, w, h, passes, noise5[frame % len(noise5)], frame * 13)
+        hip = P.read_hip_gbuffer(pipe)
+        P.assert_parity(P.compare_gbuffers(g, hip))
+        hit = np.isfinite(g.depth)
+        assert (P.half_to_float(hip["motion"])[hit][:, :3] != 0).any()   # something actually moved
