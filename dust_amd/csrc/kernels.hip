@@ -527,9 +527,11 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   bool screen = false;  // does the CURRENT cell's entry point need the exact near-plane test?
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    // the cell the ray is moving into: floor for d >= 0, ceil - 1 for d < 0 (differs only on a cell plane)
+    // the cell the ray is moving into: floor for d >= 0, ceil - 1 for d < 0 (differs only on a cell plane), kept inside
+    // the tight bounds: the start point is the origin inside them or the entry point on them, and an entry point that
+    // rounding left a hair outside would otherwise start the walk one (empty) cell early, next to the plane, every time
     const float p = oo[a] + dd[a] * t;
-    ijk[a] = f2i_clamp(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p), 0, E - 1);
+    ijk[a] = f2i_clamp(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p), (int)m.bmin[a], (int)m.bmax[a] - 1);
     reach = fmaxf(reach, fabsf(oo[a]) + fmaxf(fabsf(p), fabsf(oo[a] + dd[a] * tx)));
   }
   const float near_tol = 3.0e-7f * (reach + 16.0f);
