@@ -29,7 +29,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // .so). PROF_ENTER/PROF_LEAVE add -/+ s_memtime to a per-wave LDS bucket (fire-and-forget ds_add by the first
 // active lane), so a bucket ends up holding the wave's inclusive cycles in that section.
 #ifdef DUST_PROFILE
-constexpr int kProfBuckets = 16;
+constexpr int kProfBuckets = 24;
 __shared__ unsigned long long g_prof[16][kProfBuckets];
 __device__ unsigned long long g_prof_out[kProfBuckets];
 __device__ __forceinline__ void prof_mark(int idx, bool leave) {
@@ -45,7 +45,9 @@ __device__ __forceinline__ void prof_count(int idx, unsigned long long n) {
 #define PROF_ENTER(i) prof_mark(i, false)
 #define PROF_LEAVE(i) prof_mark(i, true)
 #define PROF_COUNT(i, n) prof_count(i, n)
+#define PROF_COUNT_LANES(i, pred) prof_count(i, (unsigned long long)__popcll(__ballot(pred)))
 #else
+#define PROF_COUNT_LANES(i, pred)
 #define PROF_ENTER(i)
 #define PROF_LEAVE(i)
 #define PROF_COUNT(i, n)
@@ -60,7 +62,8 @@ __shared__ unsigned long long g_dbg_mask[16];  // per wave: lanes being traced v
 #endif
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
        P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
-enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)  // the P_N_* buckets count events, not cycles
+enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
+enum { P_L_TRIPS = 16, P_L_BRICK, P_L_EMPTY4, P_L_EMPTY16 };  // lane-level trip outcomes  // the P_N_* buckets count events, not cycles
 
 namespace {
 
@@ -563,6 +566,10 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       const uint64_t mask = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true);
       const bool have = mask != 0;
       PROF_LEAVE(P_FIND);
+      PROF_COUNT_LANES(P_L_TRIPS, true);
+      PROF_COUNT_LANES(P_L_BRICK, have);
+      PROF_COUNT_LANES(P_L_EMPTY4, !have && cl_main == 2);
+      PROF_COUNT_LANES(P_L_EMPTY16, !have && cl_main > 2);
       PROF_ENTER(P_BRICK);
       if (have) test_brick<RT, COUNT>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
       PROF_LEAVE(P_BRICK);

@@ -33,8 +33,8 @@ NAMES = ["total", "grab", "cull", "trace_ray", "instance", "find_brick", "brick_
 
 
 def read(lib):
-    buf = (ctypes.c_ulonglong * 16)()
-    assert lib.dust_hip_profile_read(buf, 16) == 0
+    buf = (ctypes.c_ulonglong * 24)()
+    assert lib.dust_hip_profile_read(buf, 24) == 0
     return [int(x) for x in buf]
 
 
@@ -56,6 +56,9 @@ def report(title, b, ms):
     print(f"  per packet-trace (wave level): candidates {b[12] / nt:.1f}, candidate-loop iterations {b[13] / nt:.1f}, "
           f"instance visits {b[14] / nt:.2f}, traversal loop trips {b[15] / nt:.1f} ({b[15] / max(1, b[14]):.1f} per visit), "
           f"of which {100.0 * b[10] / max(1, b[15]):.1f} % call visit_neighbours")
+    lt = max(1, b[16])
+    print(f"  lane-level trips: {b[16] / nt / 64:.2f} per ray-slot; {100.0 * b[17] / lt:.0f} % test a brick, {100.0 * b[18] / lt:.0f} % cross an empty "
+          f"4-cell, {100.0 * b[19] / lt:.0f} % an empty 16-cell (or larger)")
 
 
 def main():
