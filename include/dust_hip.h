@@ -162,6 +162,9 @@ DustStatus dust_hip_model_create(DustHipContext*, const DustHipBlock* blocks, ui
                                  const uint8_t* materials, uint64_t n_materials, const uint8_t* palette_rgba255x4,
                                  uint32_t tree_extent_log2, DustHipModel** out);
 void dust_hip_model_destroy(DustHipModel*);
+/* Lifetimes: a model must outlive every scene that instances it, a scene every frame in flight that renders it
+ * (dust_hip_sync before destroying), a context everything created from it. Calls on one context are not thread-safe
+ * against each other; dust_hip_last_error() is per thread. */
 
 /* TLASStore (render/src/accel_struct/tlas.rs:28-180) + the prev-frame transform vec (standard.rs:845-878) */
 DustStatus dust_hip_scene_create(DustHipContext*, DustHipScene** out);
