@@ -774,6 +774,57 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
     const bool in = slab_box(o, d, inv_d, a.world_min, a.world_max, te_s, tx_s);
     t_scene = in ? tx_s * (1.0f + 1e-5f) + 1e-3f : -1.0f;
   }
+  if (RT >= 2 && !all && !(a.debug & 8u)) {
+    // Incoherent packets (gather and surfel rays). The rays of such a packet spread over several instances, and a
+    // wave-uniform walk (below) leaves most lanes idle in each visit. Here the list is taken 32 candidates at a time:
+    // a uniform scan (scalar box loads, one slab test per ray and candidate) leaves every lane with the bit mask of the
+    // boxes ITS ray meets, then each lane pops its own bits front to back and the wave traverses up to 64 different
+    // instances at once -- instance and model records come through vector loads there.
+    for (uint32_t base = 0; base < n; base += 32u) {
+      const uint32_t cnt = n - base < 32u ? n - base : 32u;
+      {
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[base]);
+        const float t_lo = __uint_as_float(c0 & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
+        const bool settled = !active || (best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo;
+        if (__all(settled)) break;  // sorted by earliest entry: no later candidate matters either
+      }
+      uint32_t mask = 0;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        PROF_COUNT(P_N_CAND_ITER, 1);
+        const uint32_t ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[base + k]) & 0xFFFFu;
+        const DUST_CONST_AS DevBox& bx = a.boxes[ii];
+        float lo[3], hi[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { lo[q] = bx.lo[q]; hi[q] = bx.hi[q]; }
+        float te, tx;
+        const bool box = zero_axis ? slab_box(o, d, inv_d, lo, hi, te, tx) : slab_box_nonzero(o, inv_d, lo, hi, te, tx);
+        mask |= box ? 1u << k : 0u;
+      }
+      if (!active) mask = 0;
+      while (__any(mask != 0)) {
+        uint32_t mine = 0xFFFFFFFFu;
+        if (mask != 0) {
+          const uint32_t c = cand[base + (uint32_t)__builtin_ctz(mask)];
+          mask &= mask - 1u;
+          const float t_lo = __uint_as_float(c & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
+          if ((best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo) mask = 0;
+          else mine = c & 0xFFFFu;
+        }
+        PROF_COUNT(P_N_VISITS, 1);
+        if (mine != 0xFFFFFFFFu) {
+          if (COUNT) st.instances_tested += 1;
+          InstanceRef in = a.instances[mine];
+          ModelRef m = a.models[in.model];
+          PROF_ENTER(P_INSTANCE);
+          trace_instance<RT, COUNT>(m, mine, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
+          PROF_LEAVE(P_INSTANCE);
+        }
+      }
+    }
+    if (COUNT && best.found) st.hits += 1;
+    PROF_LEAVE(P_TRACE_RAY);
+    return;
+  }
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
     uint32_t ii;
     float lo[3], hi[3];
