@@ -36,6 +36,37 @@ hipError_t configure_kernels(size_t max_lds);
 }  // namespace dust
 
 namespace {
+// sky.glsl:81-113 (sun disc radiance, limb darkening) at the sun's own direction, times the solid-angle factor of
+// nee.rmiss:11-22, in single precision like the shader. The kernels read the result as a launch constant.
+void sun_constants(const float* s, float* dir, float* term) {
+  const float len = std::sqrt((s[48] * s[48] + s[49] * s[49]) + s[50] * s[50]);
+  const float d[3] = {s[48] / len, s[49] / len, s[50] / len};
+  for (int k = 0; k < 3; ++k) { dir[k] = d[k]; term[k] = 0.0f; }
+  const float len2 = std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);  // the shader normalises the direction again
+  const float e[3] = {d[0] / len2, d[1] / len2, d[2] / len2};
+  const float cos_gamma = (e[0] * s[48] + e[1] * s[49]) + e[2] * s[50];
+  if (!(cos_gamma >= 0.0f) || e[1] < 0.0f) return;
+  const float sol_rad_sin = std::sin(s[55]);
+  const float ar2 = 1.0f / (sol_rad_sin * sol_rad_sin);
+  const float singamma = 1.0f - cos_gamma * cos_gamma;
+  const float sc2 = 1.0f - (ar2 * singamma) * singamma;
+  if (!(sc2 > 0.0f)) return;
+  const float sc = std::sqrt(sc2);
+  float dark[3] = {s[10] + s[11] * sc, s[26] + s[27] * sc, s[42] + s[43] * sc};
+  float cur = sc;
+  for (int i = 0; i < 4; ++i) {
+    cur *= sc;
+    dark[0] += s[12 + i] * cur; dark[1] += s[28 + i] * cur; dark[2] += s[44 + i] * cur;
+  }
+  const float v[3] = {s[52] * dark[0], s[53] * dark[1], s[54] * dark[2]};
+  const float kk = 1.0f - std::cos(s[55]);
+  term[0] = ((1.6410228f * v[0] + -0.32480323f * v[1]) + -0.23642465f * v[2]) * kk;   // color.glsl:24-31
+  term[1] = ((-0.66366285f * v[0] + 1.6153315f * v[1]) + 0.016756356f * v[2]) * kk;
+  term[2] = ((0.011721907f * v[0] + -0.0082844375f * v[1]) + 0.9883947f * v[2]) * kk;
+}
+}  // namespace
+
+namespace {
 
 thread_local std::string g_last_error;
 
@@ -768,6 +799,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
   a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;
   std::memcpy(a.sky, sky->state, sizeof(a.sky));
+  sun_constants(a.sky, a.sun_dir, a.sun_term);
   a.g.illuminance = static_cast<uint16_t*>(p->planes[DUST_PLANE_ILLUMINANCE].p);
   a.g.denoised = static_cast<uint16_t*>(p->planes[DUST_PLANE_DENOISED].p);
   a.g.albedo = static_cast<uint32_t*>(p->planes[DUST_PLANE_ALBEDO].p);

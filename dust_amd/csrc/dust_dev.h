@@ -134,6 +134,9 @@ struct FrameArgs {
   float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];
+  float sun_dir[3];           // normalize(sky[48..50]): the sun shadow rays' direction
+  float sun_term[3];          // sun_radiance(sun_dir) * (1 - cos(solar radius)): what a lit point receives per unit cos(theta)
+                              // (nee.rmiss:11-22 evaluates it per ray; it is a constant of the frame, worked out once on the host)
   DevGBuffer g;
   uint32_t width, height;
   uint32_t row_begin, row_end;
@@ -148,7 +151,8 @@ struct FrameArgs {
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in
-                              // index order instead of the packet's sorted candidate list); 0 in production
+                              // index order instead of the packet's sorted candidate list, 8: gather / surfel rays take the
+                              // wave-uniform candidate walk of the coherent ray types); 0 in production
 };
 
 }  // namespace dust

@@ -1050,20 +1050,6 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
 }
 
-// What a sun-lit point receives per unit cos(theta): the same for every ray of a frame (nee.rmiss:11-22 evaluates it per
-// ray), so each wave works it out once and carries it as scalars.
-struct SunTerm { V3 sd, srk; };
-__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ SunTerm sun_term(ArgsRef a) {
-  SunTerm s;
-  const V3 sd = normalize3(mk(a.sky[48], a.sky[49], a.sky[50]));
-  const V3 sr = sun_radiance(a.sky, normalize3(sd));
-  const float kk = 1.0f - cosf(a.sky[55]);
-  s.sd = mk(uniform_f(sd.x), uniform_f(sd.y), uniform_f(sd.z));
-  s.srk = mk(uniform_f(sr.x * kk), uniform_f(sr.y * kk), uniform_f(sr.z * kk));
-  return s;
-}
-
 // ==================================================================== sun shadow + ambient occlusion
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
@@ -1088,7 +1074,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   // two rays per pixel through the same code: k = 0 the sun shadow ray (any-hit, ambient_occlusion.rgen:33-50),
   // k = 1 the ambient occlusion ray (closest hit within 8 units, ambient_occlusion.rgen:52-65)
   const bool sun_live = live && dot3(sun, n) > 0.0f;
-  const V3 sd = normalize3(sun);
+  const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);  // normalize(sun)
   const Range3 org = wave_range(live, loc);  // both rays leave from the same points (sun_live is a subset of live)
   Hit h;
 #pragma unroll 1
@@ -1101,12 +1087,9 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
     trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
     __builtin_amdgcn_wave_barrier();
-    if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22
-      // (evaluated per packet on purpose: carried across the fused kernel's loop as in k_surfel_trace it measured 2.5 % slower)
-      const V3 sr = sun_radiance(a.sky, normalize3(sd));
-      const float kk = 1.0f - cosf(a.sky[55]);
+    if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22; sun_term = sun radiance x (1 - cos(solar radius))
       const float dn = dot3(n, sd);
-      payload.x += (sr.x * kk) * dn; payload.y += (sr.y * kk) * dn; payload.z += (sr.z * kk) * dn;
+      payload.x += a.sun_term[0] * dn; payload.y += a.sun_term[1] * dn; payload.z += a.sun_term[2] * dn;
     }
   }
   if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
@@ -1544,7 +1527,6 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
-  const SunTerm sunt = sun_term(a);
   WorkCursor wc = cursor_begin();
   Packet p;
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
@@ -1572,7 +1554,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
     }
     V3 payload = mk(0, 0, 0);
     const bool sun_live = live && dot3(sun, n) > 0.0f;
-    const V3 sd = sunt.sd;
+    const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
     Hit h;
     const Range3 orgs = wave_range(live, org);
 #pragma unroll 1
@@ -1586,7 +1568,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
       __builtin_amdgcn_wave_barrier();
       if (k == 0 && sun_live && !h.found) {  // surfel/nee.rmiss:15-27
         const float dn = dot3(n, sd);
-        payload = mk(sunt.srk.x * dn, sunt.srk.y * dn, sunt.srk.z * dn);
+        payload = mk(a.sun_term[0] * dn, a.sun_term[1] * dn, a.sun_term[2] * dn);
       }
     }
     if (live) {

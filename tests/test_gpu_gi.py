@@ -147,10 +147,11 @@ def _castle_gi_states(monkeypatch, settings, frames=3):
 
 def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     """Closest hit with the lower (instance, block) on equal t is a property of the ray, not of the order instances are
-    visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4) nor of which rays share a wavefront
+    visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4; every lane on its own instance vs the whole
+    wave on one, bit 8) nor of which rays share a wavefront
     (octant-ordered gather packets, position-ordered surfels). Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
-    _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
+    _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"}])
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:
