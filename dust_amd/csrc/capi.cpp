@@ -809,6 +809,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.g.voxel_id = static_cast<uint32_t*>(p->planes[DUST_PLANE_VOXEL_ID].p);
   a.g.accum = static_cast<float*>(p->planes[DUST_PLANE_ACCUM].p);
   a.width = p->width; a.height = p->height;
+  a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
   a.row_begin = fp->row_begin;
   a.row_end = fp->row_end ? fp->row_end : p->height;
   if (a.row_begin >= a.row_end || a.row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
@@ -1037,6 +1038,7 @@ static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uin
   HIP_TRY(hipSetDevice(p->ctx->device));
   dust::FrameArgs a{};
   a.width = p->width; a.height = p->height;
+  a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
   a.row_begin = row_begin; a.row_end = row_end;
   a.frame_index = frame_index;
   a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);

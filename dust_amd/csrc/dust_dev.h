@@ -139,6 +139,7 @@ struct FrameArgs {
                               // (nee.rmiss:11-22 evaluates it per ray; it is a constant of the frame, worked out once on the host)
   DevGBuffer g;
   uint32_t width, height;
+  float inv_width, inv_height, aspect;  // RN(1 / width), RN(1 / height), RN(width / height): camera.glsl's divisions, done once
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
   DUST_RW(uint32_t) work_counters;    // 8 per-band tile counters, kCounterStride apart, zero at launch

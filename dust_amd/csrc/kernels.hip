@@ -81,10 +81,32 @@ __device__ __forceinline__ float gsign(float x) { return (float)((x > 0.0f) - (x
 __device__ __forceinline__ float gstep(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 __device__ __forceinline__ float gclamp(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ V3 normalize3(V3 v) {
-  float l = sqrtf(dot3(v, v));
-  return mk(v.x / l, v.y / l, v.z / l);
+// a / b, correctly rounded, given y = RN(1 / b) (an IEEE division done once per instance and axis): Markstein's
+// sequence q0 = RN(a y), r = a - b q0 (exact in an FMA), q = RN(q0 + r y) yields RN(a / b) whenever nothing under- or
+// overflows. b == 0 (y infinite) takes q0 = a * (+-inf), which is what a / (+-0) is, NaN for a == 0 included.
+// Four instructions against the ten of the hardware division sequence, bit for bit the same quotient; direction
+// components in the denormal range (1 / b overflowing) are the one input class where it would differ.
+__device__ __forceinline__ float div_by(float a, float b, float y, bool y_inf) {
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-b, q0, a);
+  const float q = __builtin_fmaf(r, y, q0);
+  return y_inf ? q0 : q;
 }
+// The same sequence wherever the shaders divide: by a constant (y folds at compile time), or several numerators by one
+// divisor (one IEEE reciprocal instead of a division each). y zero, infinite or NaN (a divisor that is infinite, zero
+// or NaN) takes a * y, which is a / b in those cases too.
+__device__ __forceinline__ float div_const(float a, float c) {  // c: a literal
+  const float y = 1.0f / c;
+  const float q0 = a * y;
+  return __builtin_fmaf(__builtin_fmaf(-c, q0, a), y, q0);
+}
+__device__ __forceinline__ bool recip_special(float y) { return __builtin_amdgcn_classf(y, 0x267); }  // NaN, +-inf, +-0
+__device__ __forceinline__ V3 div3(V3 v, float b) {  // v / b
+  const float y = 1.0f / b;
+  const bool sp = recip_special(y);
+  return mk(div_by(v.x, b, y, sp), div_by(v.y, b, y, sp), div_by(v.z, b, y, sp));
+}
+__device__ __forceinline__ V3 normalize3(V3 v) { return div3(v, sqrtf(dot3(v, v))); }
 __device__ __forceinline__ int f2i_clamp(float f, int lo, int hi) {  // clamp(int(floor-ed f)) with NaN -> lo side of 0
   float c = fminf(fmaxf(f, (float)lo), (float)hi);                   // fmaxf(NaN, lo) == lo
   return (int)c;
@@ -131,7 +153,11 @@ __device__ __forceinline__ V3 cubed_normalize(V3 d) {  // normal.glsl:39-43
 __device__ __forceinline__ V3 rotate_by_normal(V3 n, V3 t) {  // normal.glsl:31-37
   float qx = -n.y, qy = n.x, qz = 0.0f, qw = 1.0f + n.z;
   float l = sqrtf(((qx * qx + qy * qy) + qz * qz) + qw * qw);
-  qx /= l; qy /= l; qz /= l; qw /= l;
+  {
+    const float y = 1.0f / l;
+    const bool sp = recip_special(y);
+    qx = div_by(qx, l, y, sp); qy = div_by(qy, l, y, sp); qz = div_by(qz, l, y, sp); qw = div_by(qw, l, y, sp);
+  }
   if (n.z < -0.99999f) { qx = -1.0f; qy = 0.0f; qz = 0.0f; qw = 0.0f; }
   V3 q = mk(qx, qy, qz);
   float two_dot = 2.0f * dot3(q, t);
@@ -143,14 +169,14 @@ __device__ __forceinline__ V3 rotate_by_normal(V3 n, V3 t) {  // normal.glsl:31-
 }
 __device__ __forceinline__ uint32_t nrd_pack_normal(V3 v, float roughness, float material_id) {  // nrd.glsl:2-10,25-52
   float s = (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z);
-  v.x /= s; v.y /= s; v.z /= s;
+  v = div3(v, s);
   float wx = (1.0f - fabsf(v.y)) * (gstep(0.0f, v.x) * 2.0f - 1.0f);
   float wy = (1.0f - fabsf(v.x)) * (gstep(0.0f, v.y) * 2.0f - 1.0f);
   float ex = v.z >= 0.0f ? v.x : wx, ey = v.z >= 0.0f ? v.y : wy;
-  return pack_rgb10a2(ex * 0.5f + 0.5f, ey * 0.5f + 0.5f, roughness, gclamp(material_id / 3.0f, 0.0f, 1.0f));
+  return pack_rgb10a2(ex * 0.5f + 0.5f, ey * 0.5f + 0.5f, roughness, gclamp(div_const(material_id, 3.0f), 0.0f, 1.0f));
 }
 __device__ __forceinline__ V3 nrd_unpack_normal(uint32_t p) {  // nrd.glsl:54-94 on an A2B10G10R10 texel
-  float p0 = (float)(p & 1023u) / 1023.0f, p1 = (float)((p >> 10) & 1023u) / 1023.0f;
+  float p0 = div_const((float)(p & 1023u), 1023.0f), p1 = div_const((float)((p >> 10) & 1023u), 1023.0f);
   float px = p0 * 2.0f - 1.0f, py = p1 * 2.0f - 1.0f;
   V3 n = mk(px, py, (1.0f - fabsf(px)) - fabsf(py));
   float t = gclamp(-n.z, 0.0f, 1.0f);
@@ -236,17 +262,6 @@ __device__ __forceinline__ bool grid_clear(uint32_t m1, uint32_t m2, uint32_t hi
 }
 __device__ __forceinline__ uint32_t encode_index(int px, int py, int pz) {  // hit.rint:30-32 on u8vec3
   return (((uint32_t)px << 4) | ((uint32_t)py << 2) | ((uint32_t)pz & 0xFFu)) & 0xFFu;
-}
-// a / b, correctly rounded, given y = RN(1 / b) (an IEEE division done once per instance and axis): Markstein's
-// sequence q0 = RN(a y), r = a - b q0 (exact in an FMA), q = RN(q0 + r y) yields RN(a / b) whenever nothing under- or
-// overflows. b == 0 (y infinite) takes q0 = a * (+-inf), which is what a / (+-0) is, NaN for a == 0 included.
-// Four instructions against the ten of the hardware division sequence, bit for bit the same quotient; direction
-// components in the denormal range (1 / b overflowing) are the one input class where it would differ.
-__device__ __forceinline__ float div_by(float a, float b, float y, bool y_inf) {
-  const float q0 = a * y;
-  const float r = __builtin_fmaf(-b, q0, a);
-  const float q = __builtin_fmaf(r, y, q0);
-  return y_inf ? q0 : q;
 }
 __device__ __forceinline__ void intersect_aabb04(V3 o, V3 d, V3 rd, float& t_min, float& t_max) {  // hit.rint:20-28, rd = 1 / d
   const bool ix = fabsf(rd.x) == INFINITY, iy = fabsf(rd.y) == INFINITY, iz = fabsf(rd.z) == INFINITY;
@@ -974,12 +989,14 @@ __device__ __forceinline__ void flush_stats(ArgsRef a, int slot, const LaneStats
   atomicAdd((unsigned long long*)&a.stats[slot].hits, (unsigned long long)st.hits);
 }
 
-__device__ __forceinline__ V3 camera_ray_dir(const DUST_CONST_AS DevCamera& c, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
-  // camera.glsl:4-16
-  float nx = ((float)px + 0.5f) / (float)w, ny = ((float)py + 0.5f) / (float)h;
+__device__ __forceinline__ V3 camera_ray_dir(ArgsRef a, uint32_t px, uint32_t py) {
+  // camera.glsl:4-16. The divisions by the frame size go through the reciprocals the host put in the launch descriptor
+  // (div_by: same quotients), and width / height is a launch constant.
+  const DUST_CONST_AS DevCamera& c = a.cam;
+  float nx = div_by((float)px + 0.5f, (float)a.width, a.inv_width, false), ny = div_by((float)py + 0.5f, (float)a.height, a.inv_height, false);
   float cx = 2.0f * nx - 1.0f, cy = 2.0f * ny - 1.0f;
   cy *= -1.0f;
-  cx *= (float)w / (float)h;
+  cx *= a.aspect;
   cx *= c.tan_half_fov; cy *= c.tan_half_fov;
   const float cz = -1.0f;
   return mk((c.col0[0] * cx + c.col1[0] * cy) + c.col2[0] * cz, (c.col0[1] * cx + c.col1[1] * cy) + c.col2[1] * cz,
@@ -997,7 +1014,7 @@ template <bool COUNT>
 __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
-  const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+  const V3 d = camera_ray_dir(a, p.px, p.py);
   const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
   Hit h;
   h.found = false;
@@ -1010,7 +1027,7 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   if (!h.found) {
     const V3 dir = normalize3(d);
     const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
-    store_radiance(a.g.denoised, pix, mk((s0.x + s1.x) / 3.14f, (s0.y + s1.y) / 3.14f, (s0.z + s1.z) / 3.14f), 100000.0f);
+    store_radiance(a.g.denoised, pix, mk(div_const(s0.x + s1.x, 3.14f), div_const(s0.y + s1.y, 3.14f), div_const(s0.z + s1.z, 3.14f)), 100000.0f);
     a.g.albedo[pix] = 0xFFFFFFFFu;
     a.g.depth[pix] = INFINITY;
     store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
@@ -1033,8 +1050,8 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
   const uint32_t pal = m.materials[b.material_ptr + voff];
   const uint32_t col = m.palette[pal];
-  a.g.albedo[pix] = pack_rgb10a2((float)(col & 255u) / 255.0f, (float)((col >> 8) & 255u) / 255.0f,
-                                 (float)((col >> 16) & 255u) / 255.0f, 1.0f);
+  a.g.albedo[pix] = pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
+                                 div_const((float)((col >> 16) & 255u), 255.0f), 1.0f);
   a.g.depth[pix] = h.t;
   hitT = h.t;
   normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
@@ -1047,7 +1064,8 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
   const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
   const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
-  store_half4(a.g.motion, pix, hx / hw - hpw.x, hy / hw - hpw.y, hz / hw - hpw.z, 0.0f);
+  const V3 hp = div3(mk(hx, hy, hz), hw);
+  store_half4(a.g.motion, pix, hp.x - hpw.x, hp.y - hpw.y, hp.z - hpw.z, 0.0f);
 }
 
 // ==================================================================== sun shadow + ambient occlusion
@@ -1062,13 +1080,13 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   V3 n = mk(0, 0, 1), loc = mk(0, 0, 0), ad = mk(0, 0, 1);
   if (live) {
     n = nrd_unpack_normal(normal_packed);
-    const V3 d = camera_ray_dir(a.cam, p.px, p.py, a.width, a.height);
+    const V3 d = camera_ray_dir(a, p.px, p.py);
     loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
              (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
     const uint32_t nx = (p.px + 7u + a.rand) % 128u, ny = (p.py + 183u + a.rand) % 128u;
     const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
-    V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
-               (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+    V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+               div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
     ad = normalize3(rotate_by_normal(n, ns));
   }
   // two rays per pixel through the same code: k = 0 the sun shadow ray (any-hit, ambient_occlusion.rgen:33-50),
@@ -1271,8 +1289,8 @@ __device__ __forceinline__ float srgb_to_linear(float c) {  // color.glsl:1-5
   return c < 0.04045f ? c / 12.92f : powf(fabsf(c + 0.055f) / 1.055f, 2.4f);
 }
 __device__ V3 modulate_by_avg_albedo(V3 r, uint32_t packed) {  // final_gather.rchit:68-80, surfel.rchit:60-71
-  const V3 alb = mk(srgb_to_linear((float)((packed >> 22) & 1023u) / 1023.0f), srgb_to_linear((float)((packed >> 12) & 1023u) / 1023.0f),
-                    srgb_to_linear((float)((packed >> 2) & 1023u) / 1023.0f));
+  const V3 alb = mk(srgb_to_linear(div_const((float)((packed >> 22) & 1023u), 1023.0f)), srgb_to_linear(div_const((float)((packed >> 12) & 1023u), 1023.0f)),
+                    srgb_to_linear(div_const((float)((packed >> 2) & 1023u), 1023.0f)));
   const V3 s = mk((1.7312546f * r.x + -0.6040432f * r.y) + -0.08010775f * r.z, (-0.131619f * r.x + 1.1348418f * r.y) + -0.008679431f * r.z,
                   (-0.024568284f * r.x + -0.12575036f * r.y) + 1.0656371f * r.z);  // ACEScg -> sRGB, color.glsl:16-23
   const V3 m = mk(s.x * alb.x, s.y * alb.y, s.z * alb.z);
@@ -1320,13 +1338,13 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
   }
   if (live) {
     const V3 n = nrd_unpack_normal(a.g.normal[pix]);
-    const V3 d = camera_ray_dir(a.cam, px, py, a.width, a.height);
+    const V3 d = camera_ray_dir(a, px, py);
     loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
              (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
     const uint32_t nx = (px + 7u + a.rand) % 128u, ny = (py + 183u + a.rand) % 128u;
     const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
-    const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
-                     (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+    const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                     div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
     ad = normalize3(rotate_by_normal(n, ns));
   }
   return live;
@@ -1426,7 +1444,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
     hash_get(a.gi, key, a.frame_index, rad, count, entry);
     if (a.gi.touched) a.gi.touched[p.px + p.py * a.width] = entry;  // multi-GPU: the other ranks repeat this stamp
     const float prob = 1.0f / (float)(count + 2u);
-    const float noise = (float)a.noise0[((p.py + 21u + a.rand) % 128u) * 128u + ((p.px + 34u + a.rand) % 128u)] / 255.0f;
+    const float noise = div_const((float)a.noise0[((p.py + 21u + a.rand) % 128u) * 128u + ((p.px + 34u + a.rand) % 128u)], 255.0f);
     if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
       const uint32_t index = p.px + p.py * a.width;
       a.gi.pixel_surfel[index] = sf;
@@ -1548,8 +1566,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
     V3 cd = mk(0, 0, 1);
     if (live) {
       const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
-      const V3 ns = mk((float)(tex & 255u) / 255.0f * 2.0f - 1.0f, (float)((tex >> 8) & 255u) / 255.0f * 2.0f - 1.0f,
-                       (float)((tex >> 16) & 255u) / 255.0f * 2.0f - 1.0f);
+      const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                       div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
       cd = normalize3(rotate_by_normal(n, ns));
     }
     V3 payload = mk(0, 0, 0);
@@ -1587,7 +1605,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
         uint32_t count = 0;
         uint32_t entry;
         const bool found = hash_get(a.gi, key, a.frame_index, rad, count, entry);
-        const float rnd0 = (float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)] / 255.0f;
+        const float rnd0 = div_const((float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)], 255.0f);
         if (found) {
           rad = modulate_by_avg_albedo(rad, alb);
           rq.vx = rad.x + payload.x; rq.vy = rad.y + payload.y; rq.vz = rad.z + payload.z;

@@ -47,6 +47,25 @@ int main(int argc, char** argv) {
       volatile float y = 1.0f / zero[j], want = num[i] / zero[j];
       if (!same(div_by(num[i], zero[j], y), want)) { printf("%g / %g wrong\n", num[i], zero[j]); ++bad; }
     }
+  /* The shaders' other divisions take the same sequence (div_const, camera_ray_dir in kernels.hip); their numerators come
+   * from small sets, checked here one by one: bytes / 255, 10-bit fields / 1023, material ids / 3, and the pixel centres
+   * (px + 0.5) / size for every frame size up to 8192. */
+  {
+    static const float cs[] = {255.0f, 1023.0f, 3.0f};
+    static const int lim[] = {256, 1024, 256};
+    for (int c = 0; c < 3; ++c)
+      for (int x = 0; x < lim[c]; ++x) {
+        volatile float y = 1.0f / cs[c], want = (float)x / cs[c];
+        if (!same(div_by((float)x, cs[c], y), want)) { printf("%d / %g wrong\n", x, cs[c]); ++bad; }
+      }
+    for (int w = 1; w <= 8192; ++w) {
+      volatile float y = 1.0f / (float)w;
+      for (int px = 0; px < w; ++px) {
+        volatile float want = ((float)px + 0.5f) / (float)w;
+        if (!same(div_by((float)px + 0.5f, (float)w, y), want)) { if (bad < 5) printf("(%d + 0.5) / %d wrong\n", px, w); ++bad; }
+      }
+    }
+  }
   printf("samples %lld bad %lld\n", n, bad);
   return bad == 0 ? 0 : 1;
 }
