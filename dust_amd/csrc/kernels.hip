@@ -709,8 +709,8 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
     const float d1 = dir.lo[k], d2 = dir.hi[k];
     z1[k] = d1 == 0.0f; up1[k] = d1 > 0.0f; lo1[k] = d1 < 0.0f;
     z2[k] = d2 == 0.0f; lo2[k] = d2 > 0.0f; up2[k] = d2 < 0.0f;
-    r1[k] = z1[k] ? 0.0f : 1.0f / d1;
-    r2[k] = z2[k] ? 0.0f : 1.0f / d2;
+    r1[k] = z1[k] ? 0.0f : __builtin_amdgcn_rcpf(d1);  // 1 ulp: the interval ends carry 1e-5 of slack, and the stored
+    r2[k] = z2[k] ? 0.0f : __builtin_amdgcn_rcpf(d2);  // entry time is rounded down by 2^-7
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n_inst = a.n_instances;
