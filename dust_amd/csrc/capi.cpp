@@ -153,7 +153,7 @@ struct DustHipScene {
   DustHipContext* ctx = nullptr;
   std::vector<HostInstance> instances;
   std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
-  DeviceBuffer d_models, d_instances, d_root_table, d_boxes;
+  DeviceBuffer d_models, d_instances, d_root_table, d_boxes, d_visits;
   std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
   uint32_t n_lds_models = 0;
@@ -691,6 +691,13 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       boxes[i].pad0 = boxes[i].pad1 = 0.0f;
     }
     HIP_TRY(s->d_boxes.upload(boxes.data(), boxes.size() * sizeof(dust::DevBox)));
+    std::vector<dust::DevVisit> visits(di.size() + 1);
+    for (size_t i = 0; i < di.size(); ++i) {
+      std::memcpy(visits[i].w2o, di[i].w2o, sizeof(visits[i].w2o));
+      visits[i].m = dm[di[i].model];
+      visits[i].pad[0] = visits[i].pad[1] = 0;
+    }
+    HIP_TRY(s->d_visits.upload(visits.data(), visits.size() * sizeof(dust::DevVisit)));
     s->committed = true;
     return DUST_OK;
   });
@@ -794,6 +801,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.n_lds_models = s->n_lds_models;
   a.root_table = static_cast<const uint8_t*>(s->d_root_table.p);
   a.boxes = static_cast<const dust::DevBox*>(s->d_boxes.p);
+  a.visits = static_cast<const dust::DevVisit*>(s->d_visits.p);
   for (int k = 0; k < 3; ++k) { a.world_min[k] = s->world_min[k]; a.world_max[k] = s->world_max[k]; }
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);

@@ -71,6 +71,12 @@ struct DevInstance {
   uint32_t pad;
 };
 
+struct DevVisit {  // what a ray needs to enter an instance, in one record (the per-lane visits of the incoherent ray types
+  float w2o[12];   // gather it: instance -> model would be two dependent loads)
+  DevModel m;
+  uint32_t pad[2];
+};
+
 struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, pad, hi.xyz, pad}
   float lo[3], pad0;
   float hi[3], pad1;
@@ -131,6 +137,7 @@ struct FrameArgs {
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
+  DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}
   float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];

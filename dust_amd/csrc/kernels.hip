@@ -828,10 +828,9 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
         PROF_COUNT(P_N_VISITS, 1);
         if (mine != 0xFFFFFFFFu) {
           if (COUNT) st.instances_tested += 1;
-          InstanceRef in = a.instances[mine];
-          ModelRef m = a.models[in.model];
+          const DUST_CONST_AS DevVisit& v = a.visits[mine];
           PROF_ENTER(P_INSTANCE);
-          trace_instance<RT, COUNT>(m, mine, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
+          trace_instance<RT, COUNT>(v.m, mine, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin, tmax, any_hit, best, st);
           PROF_LEAVE(P_INSTANCE);
         }
       }
