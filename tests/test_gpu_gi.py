@@ -159,6 +159,32 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
             assert np.array_equal(x, y)
 
 
+def test_gi_does_not_depend_on_which_roots_fit_in_lds():
+    """Root nodes staged in LDS or read from memory is a per-model property; with per-lane instance visits the lanes of
+    one wavefront mix both. Same planes and GI state when only the first 20 of the castle's roots are staged."""
+    data, _ = synth.castle_scene(scale=0.15)
+    desc = P.SceneDesc.from_vox(data)
+    s = 0.15
+    sky, cam = P.sky_state(), P.camera_for((122.0 * s, 300.61 * s, 54.45 * s))
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    out = []
+    for lds in (0, 20 * 640):
+        ctx = api.Context(device=0, lds_root_bytes=lds)
+        scene = P.hip_scene(ctx, desc)
+        pipe = api.StandardPipeline(ctx, 192, 104)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(1 << 14, 776)
+        for f in (1, 2):
+            pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(7, f))
+        h, sp = pipe.read_gi()
+        out.append([h, sp.view(np.uint32).copy()] + [pipe.read_plane(pl) for pl in (L.PLANE_ILLUMINANCE, L.PLANE_DEPTH, L.PLANE_VOXEL_ID)])
+    assert len(desc.models) > 20
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_castle_gi_matches_oracle(monkeypatch):
     desc, cam, sky, n0, n5, st = _castle_gi_states(monkeypatch, [{}], frames=2)
     oscene = P.oracle_scene(desc)
