@@ -18,18 +18,18 @@
 #include "vox.hpp"
 
 namespace dust {
-hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
-hipError_t launch_gather_order(const FrameArgs* dev, uint32_t n_tiles, hipStream_t);
-hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t);
-hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t);
-hipError_t launch_surfel_keys(const FrameArgs* dev, hipStream_t);
+hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
+hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
+hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
+hipError_t launch_gi_import(const FrameArgs& a, hipStream_t);
+hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t);
 hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                           uint32_t* vals_out, uint32_t n, uint32_t key_bits, hipStream_t s);
-hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
-hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t);
+hipError_t launch_surfel(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
+hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
@@ -179,13 +179,6 @@ struct DustHipPipeline {
   uint32_t accum_count = 0;
   hipEvent_t ev[8] = {};
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
-  // launch descriptors: a ring of pinned host slots mirrored in device memory, one slot per kernel launch
-  static constexpr int kArgSlots = 32;
-  dust::FrameArgs* host_args = nullptr;  // hipHostMalloc
-  DeviceBuffer dev_args;
-  hipEvent_t slot_done[kArgSlots] = {};
-  bool slot_used[kArgSlots] = {};
-  int next_slot = 0;
   bool stats_valid = false;
   bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
   dust::DevStats host_stats[8] = {};
@@ -722,9 +715,6 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     HIP_TRY(p->exposure.alloc(257 * 4));
     HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_args), sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots, hipHostMallocDefault));
-    HIP_TRY(p->dev_args.alloc(sizeof(dust::FrameArgs) * DustHipPipeline::kArgSlots));
-    for (auto& e : p->slot_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     *out = p.release();
     return DUST_OK;
   });
@@ -732,8 +722,6 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
 void dust_hip_pipeline_destroy(DustHipPipeline* p) {
   if (!p) return;
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
-  for (auto& e : p->slot_done) if (e) (void)hipEventDestroy(e);
-  if (p->host_args) (void)hipHostFree(p->host_args);
   delete p;
 }
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
@@ -748,17 +736,6 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, con
 
 extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size);
 // copies one launch descriptor into the next ring slot (pinned host -> device, on the launch stream)
-static DustStatus upload_args(DustHipPipeline* p, const dust::FrameArgs& a, hipStream_t st, const dust::FrameArgs** dev) {
-  const int slot = p->next_slot;
-  if (p->slot_used[slot]) HIP_TRY(hipEventSynchronize(p->slot_done[slot]));  // the launch that last read this slot is done
-  p->host_args[slot] = a;
-  dust::FrameArgs* d = static_cast<dust::FrameArgs*>(p->dev_args.p) + slot;
-  HIP_TRY(hipMemcpyAsync(d, &p->host_args[slot], sizeof(dust::FrameArgs), hipMemcpyHostToDevice, st));
-  p->slot_used[slot] = true;
-  p->next_slot = (slot + 1) % DustHipPipeline::kArgSlots;
-  *dev = d;
-  return DUST_OK;
-}
 
 // Work counters without a memset per launch: every pass kind owns two sets; a launch pulls tiles from one and its
 // first workgroup zeroes the other, which is the set the next launch of that kind (stream-ordered behind it) will use.
@@ -856,30 +833,21 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     take_counters(p, 0, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_primary_ao(a, d, grid, block, count, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_primary_ao(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     take_counters(p, 0, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_primary(a, d, grid, block, count, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_primary(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
     take_counters(p, 1, a);
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_ambient_occlusion(a, d, grid, block, count, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
@@ -897,19 +865,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
-      const dust::FrameArgs* dk = nullptr;
-      { DustStatus us = upload_args(p, g, st, &dk); if (us != DUST_OK) return us; }
-      HIP_TRY(dust::launch_gather_order(dk, otx * oty, st));
-      HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+      HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
       g.tiles_x = otx * oty * 16;  // 16 packets of 64 per tile, the empty ones skipped by the kernel
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (g.tiles_x + 7) / 8));
     }
     take_counters(p, 2, g);
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, g, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_final_gather(g, d, ggrid, block, count, !sharded, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
@@ -921,11 +883,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (!std::getenv("DUST_HIP_NO_SURFEL_SORT")) {  // phase 0: Morton keys + radix sort -> gi.perm
       b.gi.sort_keys = static_cast<uint32_t*>(p->gi_sort_keys.p);
       b.gi.sort_vals = static_cast<uint32_t*>(p->gi_sort_vals.p);
-      const dust::FrameArgs* dk = nullptr;
-      { DustStatus us = upload_args(p, b, st, &dk); if (us != DUST_OK) return us; }
       if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
-      HIP_TRY(dust::launch_surfel_keys(dk, st));
-      HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+      HIP_TRY(dust::launch_surfel_keys(b, st));
       size_t tmp_bytes = p->gi_sort_tmp_bytes;
       HIP_TRY(dust::sort_pairs_u32(p->gi_sort_tmp.p, &tmp_bytes, b.gi.sort_keys, static_cast<uint32_t*>(p->gi_sort_keys_out.p),
                                    b.gi.sort_vals, static_cast<uint32_t*>(p->gi_perm.p), p->gi_pool_size, 32, st));
@@ -934,17 +893,11 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(hipEventRecord(p->ev[6], st));
     }
     const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, b, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_surfel(b, d, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_surfel(b, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
-    const dust::FrameArgs* d = nullptr;
-    { DustStatus us = upload_args(p, a, st, &d); if (us != DUST_OK) return us; }
-    HIP_TRY(dust::launch_accumulate(d, st));
-    HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], st));
+    HIP_TRY(dust::launch_accumulate(a, st));
     p->accum_count += 1;
   }
   if (count) {
@@ -1057,10 +1010,7 @@ static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uin
   a.gi.pixel_surfel = static_cast<dust::DevSurfel*>(p->gi_pixel_surfel.p);
   a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
   a.gi.merged = static_cast<dust::DevSurfel*>(p->gi_merged.p);
-  const dust::FrameArgs* d = nullptr;
-  { DustStatus us = upload_args(p, a, p->ctx->stream, &d); if (us != DUST_OK) return us; }
-  HIP_TRY(import ? dust::launch_gi_import(d, p->ctx->stream) : dust::launch_gi_export(d, p->ctx->stream));
-  HIP_TRY(hipEventRecord(p->slot_done[(p->next_slot + DustHipPipeline::kArgSlots - 1) % DustHipPipeline::kArgSlots], p->ctx->stream));
+  HIP_TRY(import ? dust::launch_gi_import(a, p->ctx->stream) : dust::launch_gi_export(a, p->ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_gi_export(DustHipPipeline* p, uint32_t row_begin, uint32_t row_end) {

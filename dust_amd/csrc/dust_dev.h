@@ -15,8 +15,8 @@
 
 #include "../../include/dust_hip.h"
 
-// Address spaces. The kernels take their launch descriptor by device pointer, so every pointer inside it would be a
-// generic ("flat") pointer to the compiler: flat_load for everything, no scalar loads (it cannot prove the scene is
+// Address spaces. The kernels read their launch descriptor from the kernel-argument segment; every pointer inside it
+// would be a generic ("flat") pointer to the compiler: flat_load for everything, no scalar loads (it cannot prove the scene is
 // not written by the G-buffer stores). In the device pass the read-only scene pointers are therefore declared in the
 // constant address space (uniform index -> s_load into SGPRs, divergent index -> global_load off a scalar base) and
 // the written planes in the global one (global_store). Same 64-bit representation: the host (and every translation

@@ -71,6 +71,12 @@ namespace {
 typedef const DUST_CONST_AS FrameArgs& ArgsRef;
 typedef const DUST_CONST_AS DevModel& ModelRef;
 typedef const DUST_CONST_AS DevInstance& InstanceRef;
+// The launch descriptor travels by value in the kernel-argument segment (about 800 of the 4096 bytes it may hold) and is
+// read in place through the segment's own constant-address-space pointer: uniform fields are s_loads, nothing is copied,
+// and the host side needs no staging buffer, copy or event per launch. Every kernel's only parameter is the descriptor.
+__device__ __forceinline__ const DUST_CONST_AS FrameArgs& launch_args() {
+  return *(const DUST_CONST_AS FrameArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1113,8 +1119,8 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
+  ArgsRef a = launch_args();
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
@@ -1130,8 +1136,8 @@ __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs* __restrict_
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
+  ArgsRef a = launch_args();
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
@@ -1159,8 +1165,8 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs* _
 // in registers (as the quantised values the separate pass would load back). One launch, one LDS staging and one
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
 template <bool COUNT>
-__global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs) {
+  ArgsRef a = launch_args();
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
@@ -1355,8 +1361,8 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 // k_final_gather then takes 64 consecutive entries as a packet: same neighbourhood, one octant, no dead lanes.
 // Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
 constexpr uint32_t kOrderTile = 32, kOrderSlots = kOrderTile * kOrderTile;
-__global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
+  ArgsRef a = launch_args();
   constexpr uint32_t kWaves = kOrderSlots / 64;
   __shared__ uint32_t cnt[8 * kWaves];   // [octant][wave] counts, then their exclusive prefix in that (octant-major) order
   __shared__ uint32_t half_total[2];
@@ -1395,8 +1401,8 @@ __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs* _
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
 template <bool COUNT>
-__global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
+  ArgsRef a = launch_args();
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st = {0, 0, 0, 0, 0, 0};
@@ -1457,8 +1463,8 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs* __rest
 }
 
 // the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
-__global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_surfel_commit(const FrameArgs) {
+  ArgsRef a = launch_args();
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
     const uint32_t o = a.gi.slot_owner[s];
     if (o != 0u) {
@@ -1471,8 +1477,8 @@ __global__ void k_surfel_commit(const FrameArgs* __restrict__ ap) {
 // ==================================================================== multi-GPU exchange of the final gather's side effects
 // (dust_hip.h, dust_hip_pipeline_gi_exchange). slot_owner holds the all-reduced (MAX) owners when these run.
 // export: this rank's share of the winning surfels -- the slots whose winning pixel lies in rows [row_begin, row_end)
-__global__ void k_gi_export(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_gi_export(const FrameArgs) {
+  ArgsRef a = launch_args();
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
     const uint32_t o = a.gi.slot_owner[s];
     DevSurfel v;
@@ -1485,8 +1491,8 @@ __global__ void k_gi_export(const FrameArgs* __restrict__ ap) {
   }
 }
 // import: repeat the last_accessed_frame stamps of the other bands' final gather, commit the merged winners
-__global__ void k_gi_import(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_gi_import(const FrameArgs) {
+  ArgsRef a = launch_args();
   const uint32_t n_px = a.width * a.height;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += gridDim.x * blockDim.x) {
     const uint32_t row = i / a.width;
@@ -1515,8 +1521,8 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every 
   v = (v | (v << 2)) & 0x09249249u;
   return v;
 }
-__global__ void k_surfel_keys(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_surfel_keys(const FrameArgs) {
+  ArgsRef a = launch_args();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.gi.pool_size; i += gridDim.x * blockDim.x) {
     const DevSurfel e = a.gi.pool[i];
     uint32_t key = 0xFFFFFFFFu;  // dead slots sort last
@@ -1539,8 +1545,8 @@ __global__ void k_surfel_keys(const FrameArgs* __restrict__ ap) {
 // ==================================================================== surfel pass, phase 1: trace + read the hash
 // surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
 template <bool COUNT>
-__global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
+  ArgsRef a = launch_args();
   stage_roots(a);
   uint32_t* cand = wave_cand_list(a);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
@@ -1626,8 +1632,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs* __rest
 
 // ==================================================================== surfel pass, phase 2: apply in surfel order
 // Deterministic mode: one wavefront scans the requests 64 at a time and lane 0 applies them in index order.
-__global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs) {
+  ArgsRef a = launch_args();
   const uint32_t lane = threadIdx.x;
   for (uint32_t base = 0; base < a.gi.pool_size; base += 64u) {
     const uint32_t i = base + lane;
@@ -1652,8 +1658,8 @@ __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs* __
 }
 // Throughput mode: every surfel applies its own insert concurrently, as the reference's shaders do (racy by design,
 // spatial_hash.glsl:147-195 only claims the fingerprint atomically); results are statistically, not bitwise, repeatable.
-__global__ void k_surfel_apply_racy(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_surfel_apply_racy(const FrameArgs) {
+  ArgsRef a = launch_args();
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
     const DevHashRequest rq = a.gi.requests[j];
     if (rq.dir_flags & 0x100u) {
@@ -1667,8 +1673,8 @@ __global__ void k_surfel_apply_racy(const FrameArgs* __restrict__ ap) {
 }
 
 // ==================================================================== N-frame mean (stands in for NRD)
-__global__ void k_accumulate(const FrameArgs* __restrict__ ap) {
-  ArgsRef a = *(const DUST_CONST_AS FrameArgs*)ap;
+__global__ void k_accumulate(const FrameArgs) {
+  ArgsRef a = launch_args();
   const uint32_t rows = a.row_end - a.row_begin;
   const size_t n = (size_t)rows * a.width;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1794,62 +1800,62 @@ hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t
 }
 
 // ==================================================================== launchers (called from capi.cpp)
-// `host` describes the launch (LDS size); `dev` is the same struct already copied to device memory.
+// `a` is the launch descriptor, passed to the kernels by value.
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
   return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 8u;
 }
 
-hipError_t launch_primary(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(host, block);
-  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, dev);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, dev);
+hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, a);
   return hipGetLastError();
 }
-hipError_t launch_primary_ao(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(host, block);
-  if (count) hipLaunchKernelGGL(k_primary_ao<true>, dim3(grid), dim3(block), lds, s, dev);
-  else hipLaunchKernelGGL(k_primary_ao<false>, dim3(grid), dim3(block), lds, s, dev);
+hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_primary_ao<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_primary_ao<false>, dim3(grid), dim3(block), lds, s, a);
   return hipGetLastError();
 }
-hipError_t launch_ambient_occlusion(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(host, block);
-  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, dev);
-  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, dev);
+hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, a);
   return hipGetLastError();
 }
-hipError_t launch_gi_export(const FrameArgs* dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_gi_export, dim3(512), dim3(256), 0, s, dev);
+hipError_t launch_gi_export(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_export, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_gi_import(const FrameArgs* dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_gi_import, dim3(1024), dim3(256), 0, s, dev);
+hipError_t launch_gi_import(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_import, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_gather_order(const FrameArgs* dev, uint32_t n_tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderSlots), 0, s, dev);
+hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderSlots), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_final_gather(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
-  const size_t lds = lds_bytes(host, block);
-  if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, dev);
-  else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, dev);
-  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, dev);
+hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, a);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_surfel_keys(const FrameArgs* dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, dev);
+hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_surfel(const FrameArgs& host, const FrameArgs* dev, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {
-  const size_t lds = lds_bytes(host, block);
-  if (count) hipLaunchKernelGGL(k_surfel_trace<true>, dim3(grid), dim3(block), lds, s, dev);
-  else hipLaunchKernelGGL(k_surfel_trace<false>, dim3(grid), dim3(block), lds, s, dev);
-  if (ordered) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, dev);
-  else hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, dev);
+hipError_t launch_surfel(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {
+  const size_t lds = lds_bytes(a, block);
+  if (count) hipLaunchKernelGGL(k_surfel_trace<true>, dim3(grid), dim3(block), lds, s, a);
+  else hipLaunchKernelGGL(k_surfel_trace<false>, dim3(grid), dim3(block), lds, s, a);
+  if (ordered) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_accumulate(const FrameArgs* dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, dev);
+hipError_t launch_accumulate(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t configure_kernels(size_t max_lds) {
