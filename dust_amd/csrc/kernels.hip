@@ -77,6 +77,14 @@ typedef const DUST_CONST_AS DevInstance& InstanceRef;
 __device__ __forceinline__ const DUST_CONST_AS FrameArgs& launch_args() {
   return *(const DUST_CONST_AS FrameArgs*)__builtin_amdgcn_kernarg_segment_ptr();
 }
+// The same descriptor through a pointer the optimiser has lost track of: fields read through the result are loaded
+// again (one s_load each, at the point of use) instead of being carried in SGPRs -- or spilled to VGPR lanes -- across
+// whatever came before.
+__device__ __forceinline__ const DUST_CONST_AS FrameArgs& reload_args(const DUST_CONST_AS FrameArgs& a) {
+  const DUST_CONST_AS FrameArgs* q = &a;
+  asm volatile("" : "+s"(q));
+  return *q;
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -772,7 +780,7 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
 
 // any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
 template <int RT, bool COUNT>
-__device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
+__device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                           const uint32_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
   PROF_ENTER(P_TRACE_RAY);
   best.found = false;
@@ -781,8 +789,8 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // popcounts of ballots: uniform, but only we know
   PROF_COUNT(P_N_TRACES, 1);
   PROF_COUNT(P_N_CAND, ncand);
-  const bool all = ncand > kMaxCand || (a.debug & 4u);  // debug bit 4: ignore the list, walk every instance in index order
-  const uint32_t n = all ? a.n_instances : ncand;
+  const bool all = ncand > kMaxCand || (a_in.debug & 4u);  // debug bit 4: ignore the list, walk every instance in index order
+  const uint32_t n = all ? a_in.n_instances : ncand;
   // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
   // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
   const V3 inv_d = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
@@ -792,10 +800,10 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
   float t_scene = INFINITY;
   if (RT >= 2 && n > 8u) {  // the incoherent ray types; coherent packets have lists of one or two
     float te_s, tx_s;
-    const bool in = slab_box(o, d, inv_d, a.world_min, a.world_max, te_s, tx_s);
+    const bool in = slab_box(o, d, inv_d, a_in.world_min, a_in.world_max, te_s, tx_s);
     t_scene = in ? tx_s * (1.0f + 1e-5f) + 1e-3f : -1.0f;
   }
-  if (RT >= 2 && !all && !(a.debug & 8u)) {
+  if (RT >= 2 && !all && !(a_in.debug & 8u)) {
     // Incoherent packets (gather and surfel rays). The rays of such a packet spread over several instances, and a
     // wave-uniform walk (below) leaves most lanes idle in each visit. Here the list is taken 32 candidates at a time:
     // a uniform scan (scalar box loads, one slab test per ray and candidate) leaves every lane with the bit mask of the
@@ -803,6 +811,7 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
     // instances at once -- instance and model records come through vector loads there.
     for (uint32_t base = 0; base < n; base += 32u) {
       const uint32_t cnt = n - base < 32u ? n - base : 32u;
+      ArgsRef a = reload_args(a_in);
       {
         const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[base]);
         const float t_lo = __uint_as_float(c0 & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
@@ -846,6 +855,7 @@ __device__ void trace_ray(ArgsRef a, bool active, V3 o, V3 d, float tmin, float 
     return;
   }
   for (uint32_t ci = 0; ci < n; ++ci) {  // wave-uniform loop
+    ArgsRef a = reload_args(a_in);  // per candidate: the table pointers are loaded again rather than carried through the visit
     uint32_t ii;
     float lo[3], hi[3];
     if (all) {  // more instances than the list holds: walk every instance box in index order
@@ -1016,6 +1026,9 @@ __device__ __forceinline__ V3 camera_ray_dir(ArgsRef a, uint32_t px, uint32_t py
 // store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
 // occlusion pass overwrites the texel of every hit pixel anyway.
 template <bool COUNT>
+__device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
+                                              float& hitT, uint32_t& normal_packed);
+template <bool COUNT>
 __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
@@ -1025,6 +1038,11 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   h.found = false;
   if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
+  return primary_shade<COUNT>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
+}
+template <bool COUNT>
+__device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
+                                              float& hitT, uint32_t& normal_packed) {
   hitT = INFINITY;
   normal_packed = 0;
   if (!p.valid) return;
@@ -1120,30 +1138,32 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
 
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
-  ArgsRef a = launch_args();
-  stage_roots(a);
-  uint32_t* cand = wave_cand_list(a);
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
   LaneStats st = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
   Packet p;
-  while (next_packet(a, wc, p)) {
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     float hitT;
     uint32_t npk;
     primary_packet<COUNT>(a, p, cand, st, true, hitT, npk);
   }
   prof_end();
-  flush_stats<COUNT>(a, 0, st);
+  flush_stats<COUNT>(a0, 0, st);
 }
 
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
-  ArgsRef a = launch_args();
-  stage_roots(a);
-  uint32_t* cand = wave_cand_list(a);
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
   Packet p;
-  while (next_packet(a, wc, p)) {
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
     const float hitT = p.valid ? a.g.depth[pix] : INFINITY;
     uint32_t npk = 0;
@@ -1156,8 +1176,8 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
     ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, payload);
   }
   prof_end();
-  flush_stats<COUNT>(a, 0, st_sun);
-  flush_stats<COUNT>(a, 1, st_ao);
+  flush_stats<COUNT>(a0, 0, st_sun);
+  flush_stats<COUNT>(a0, 1, st_ao);
 }
 
 // Fused primary + ambient occlusion passes: a pixel's AO pass reads only that pixel's own primary outputs, so the
@@ -1166,22 +1186,22 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs) {
-  ArgsRef a = launch_args();
-  stage_roots(a);
-  uint32_t* cand = wave_cand_list(a);
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
   Packet p;
-  while (next_packet(a, wc, p)) {
+  while (next_packet(a0, wc, p)) {
     float hitT;
     uint32_t npk;
-    primary_packet<COUNT>(a, p, cand, st, false, hitT, npk);
-    ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
+    primary_packet<COUNT>(reload_args(a0), p, cand, st, false, hitT, npk);
+    ao_packet<COUNT>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
   }
   prof_end();
-  flush_stats<COUNT>(a, 0, st);
-  flush_stats<COUNT>(a, 1, st_sun);
-  flush_stats<COUNT>(a, 2, st_ao);
+  flush_stats<COUNT>(a0, 0, st);
+  flush_stats<COUNT>(a0, 1, st_sun);
+  flush_stats<COUNT>(a0, 2, st_ao);
 }
 
 // ==================================================================== spatial hash (headers/spatial_hash.glsl)
@@ -1402,13 +1422,14 @@ __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
-  ArgsRef a = launch_args();
-  stage_roots(a);
-  uint32_t* cand = wave_cand_list(a);
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
   LaneStats st = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
   Packet p;
-  while (next_packet(a, wc, p)) {
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     if (a.gi.order) {  // regrouped: packet id -> 64 entries of one tile's octant-ordered pixel list
       const uint32_t id = p.px >> 3, tile = id / (kOrderSlots / 64u), idx = (id % (kOrderSlots / 64u)) * 64u + (threadIdx.x & 63u);
       const uint32_t n = a.gi.order_count[tile];
@@ -1459,7 +1480,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
     store_radiance(a.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
   }
   prof_end();
-  flush_stats<COUNT>(a, 0, st);
+  flush_stats<COUNT>(a0, 0, st);
 }
 
 // the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
@@ -1546,14 +1567,15 @@ __global__ void k_surfel_keys(const FrameArgs) {
 // surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
 template <bool COUNT>
 __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
-  ArgsRef a = launch_args();
-  stage_roots(a);
-  uint32_t* cand = wave_cand_list(a);
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
   LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
   Packet p;
-  const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
-  while (next_packet(a, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
+  const V3 sun = mk(a0.sky[48], a0.sky[49], a0.sky[50]);
+  while (next_packet(a0, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     const uint32_t slot = (p.px >> 3) * 64u + (threadIdx.x & 63u);
     const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
     const bool in_range = i < a.gi.pool_size;
@@ -1626,8 +1648,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
     }
   }
   prof_end();
-  flush_stats<COUNT>(a, 0, st_sun);
-  flush_stats<COUNT>(a, 1, st_cos);
+  flush_stats<COUNT>(a0, 0, st_sun);
+  flush_stats<COUNT>(a0, 1, st_cos);
 }
 
 // ==================================================================== surfel pass, phase 2: apply in surfel order
