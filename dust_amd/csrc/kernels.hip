@@ -1120,20 +1120,21 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   Hit h;
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
+    ArgsRef b = reload_args(a);
     const bool act = k == 0 ? sun_live : live;
     const V3 dir = k == 0 ? sd : ad;
     const float tmax = k == 0 ? 10000.0f : 8.0f;
-    const uint32_t ncand = cull_instances(a, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
+    const uint32_t ncand = cull_instances(b, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
     LaneStats cur = {0, 0, 0, 0, 0, 0};
-    trace_ray<1, COUNT>(a, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
+    trace_ray<1, COUNT>(b, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
     __builtin_amdgcn_wave_barrier();
     if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22; sun_term = sun radiance x (1 - cos(solar radius))
       const float dn = dot3(n, sd);
-      payload.x += a.sun_term[0] * dn; payload.y += a.sun_term[1] * dn; payload.z += a.sun_term[2] * dn;
+      payload.x += b.sun_term[0] * dn; payload.y += b.sun_term[1] * dn; payload.z += b.sun_term[2] * dn;
     }
   }
-  if (live) store_radiance(a.g.illuminance, pix, payload, h.found ? h.t : 0.0f);
+  if (live) store_radiance(reload_args(a).g.illuminance, pix, payload, h.found ? h.t : 0.0f);
 }
 
 template <bool COUNT>
@@ -1454,30 +1455,31 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
     const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
     trace_ray<2, COUNT>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
     __builtin_amdgcn_wave_barrier();
+    ArgsRef ar = reload_args(a0);
     if (!live) continue;
     if (!h.found) {
-      const V3 sk = sky_radiance(a.sky, normalize3(ad));
-      store_radiance(a.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
+      const V3 sk = sky_radiance(ar.sky, normalize3(ad));
+      store_radiance(ar.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
       continue;
     }
     HashKey key;
     DevSurfel sf;
     uint32_t alb;
-    brick_surfel(a, h, loc, ad, key, sf, alb);
+    brick_surfel(ar, h, loc, ad, key, sf, alb);
     V3 rad;
     uint32_t count;
     uint32_t entry;
-    hash_get(a.gi, key, a.frame_index, rad, count, entry);
-    if (a.gi.touched) a.gi.touched[p.px + p.py * a.width] = entry;  // multi-GPU: the other ranks repeat this stamp
+    hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+    if (ar.gi.touched) ar.gi.touched[p.px + p.py * ar.width] = entry;  // multi-GPU: the other ranks repeat this stamp
     const float prob = 1.0f / (float)(count + 2u);
-    const float noise = div_const((float)a.noise0[((p.py + 21u + a.rand) % 128u) * 128u + ((p.px + 34u + a.rand) % 128u)], 255.0f);
+    const float noise = div_const((float)ar.noise0[((p.py + 21u + ar.rand) % 128u) * 128u + ((p.px + 34u + ar.rand) % 128u)], 255.0f);
     if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
-      const uint32_t index = p.px + p.py * a.width;
-      a.gi.pixel_surfel[index] = sf;
-      atomicMax(&a.gi.slot_owner[index % a.gi.pool_size], index + 1u);
+      const uint32_t index = p.px + p.py * ar.width;
+      ar.gi.pixel_surfel[index] = sf;
+      atomicMax(&ar.gi.slot_owner[index % ar.gi.pool_size], index + 1u);
     }
     rad = modulate_by_avg_albedo(rad, alb);
-    store_radiance(a.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
+    store_radiance(ar.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
   }
   prof_end();
   flush_stats<COUNT>(a0, 0, st);
@@ -1604,35 +1606,37 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
     const Range3 orgs = wave_range(live, org);
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
+      ArgsRef b = reload_args(a0);
       const bool act = k == 0 ? sun_live : live;
       const V3 dir = k == 0 ? sd : cd;
-      const uint32_t ncand = cull_instances(a, __any(act), orgs, k == 0 ? point_range(sd) : wave_range(live, cd), 10000.0f, cand);
+      const uint32_t ncand = cull_instances(b, __any(act), orgs, k == 0 ? point_range(sd) : wave_range(live, cd), 10000.0f, cand);
       LaneStats cur = {0, 0, 0, 0, 0, 0};
-      trace_ray<3, COUNT>(a, act, org, dir, 0.1f, 10000.0f, k == 0, cand, ncand, h, cur);
+      trace_ray<3, COUNT>(b, act, org, dir, 0.1f, 10000.0f, k == 0, cand, ncand, h, cur);
       if (COUNT) add_stats(k == 0 ? st_sun : st_cos, cur);
       __builtin_amdgcn_wave_barrier();
       if (k == 0 && sun_live && !h.found) {  // surfel/nee.rmiss:15-27
         const float dn = dot3(n, sd);
-        payload = mk(a.sun_term[0] * dn, a.sun_term[1] * dn, a.sun_term[2] * dn);
+        payload = mk(b.sun_term[0] * dn, b.sun_term[1] * dn, b.sun_term[2] * dn);
       }
     }
+    ArgsRef ar = reload_args(a0);
     if (live) {
       rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
       rq.dir_flags = e.direction & 0xFFu;
       if (!h.found) {  // surfel.rmiss:14-26
-        const V3 sk = sky_radiance(a.sky, normalize3(cd));
+        const V3 sk = sky_radiance(ar.sky, normalize3(cd));
         rq.vx = sk.x + payload.x; rq.vy = sk.y + payload.y; rq.vz = sk.z + payload.z;
         rq.dir_flags |= 0x100u;
       } else {         // surfel.rchit:35-102
         HashKey key;
         DevSurfel sf;
         uint32_t alb;
-        brick_surfel(a, h, org, cd, key, sf, alb);
+        brick_surfel(ar, h, org, cd, key, sf, alb);
         V3 rad;
         uint32_t count = 0;
         uint32_t entry;
-        const bool found = hash_get(a.gi, key, a.frame_index, rad, count, entry);
-        const float rnd0 = div_const((float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)], 255.0f);
+        const bool found = hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+        const float rnd0 = div_const((float)ar.noise0[((ny0 + 40u + ar.rand) % 128u) * 128u + ((nx0 + 114u + ar.rand) % 128u)], 255.0f);
         if (found) {
           rad = modulate_by_avg_albedo(rad, alb);
           rq.vx = rad.x + payload.x; rq.vy = rad.y + payload.y; rq.vz = rad.z + payload.z;
@@ -1643,8 +1647,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
       }
     }
     if (in_range) {
-      a.gi.requests[i] = rq;
-      a.gi.replacement[i] = repl;
+      ar.gi.requests[i] = rq;
+      ar.gi.replacement[i] = repl;
     }
   }
   prof_end();
