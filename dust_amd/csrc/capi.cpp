@@ -811,7 +811,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (const char* env = std::getenv("DUST_HIP_BLOCK")) block = uint32_t(std::strtoul(env, nullptr, 10));
   uint32_t bpc = 2;
   if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
-  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8;
+  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8 + 16;
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
   const uint32_t grid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (total_tiles + 7) / 8));
