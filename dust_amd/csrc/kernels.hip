@@ -888,10 +888,9 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
     PROF_COUNT(P_N_VISITS, 1);
     if (go) {
       if (COUNT) st.instances_tested += 1;
-      InstanceRef in = a.instances[ii];
-      ModelRef m = a.models[in.model];
+      const DUST_CONST_AS DevVisit& v = a.visits[ii];  // transform + model in one record: one scalar-load level, not two
       PROF_ENTER(P_INSTANCE);
-      trace_instance<RT, COUNT>(m, ii, xform_point(in.w2o, o), xform_dir(in.w2o, d), tmin, tmax, any_hit, best, st);
+      trace_instance<RT, COUNT>(v.m, ii, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin, tmax, any_hit, best, st);
       PROF_LEAVE(P_INSTANCE);
     }
   }
