@@ -686,6 +686,8 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     HIP_TRY(s->d_boxes.upload(boxes.data(), boxes.size() * sizeof(dust::DevBox)));
     std::vector<dust::DevVisit> visits(di.size() + 1);
     for (size_t i = 0; i < di.size(); ++i) {
+      for (int a = 0; a < 3; ++a) { visits[i].lo[a] = di[i].wmin[a]; visits[i].hi[a] = di[i].wmax[a]; }
+      visits[i].pad0 = visits[i].pad1 = 0.0f;
       std::memcpy(visits[i].w2o, di[i].w2o, sizeof(visits[i].w2o));
       visits[i].m = dm[di[i].model];
       visits[i].pad[0] = visits[i].pad[1] = 0;

@@ -71,8 +71,10 @@ struct DevInstance {
   uint32_t pad;
 };
 
-struct DevVisit {  // what a ray needs to enter an instance, in one record (the per-lane visits of the incoherent ray types
-  float w2o[12];   // gather it: instance -> model would be two dependent loads)
+struct DevVisit {  // what a ray needs to test and enter an instance, in one record: box, transform and model arrive together
+  float lo[3], pad0;   // world bounds, as in DevBox
+  float hi[3], pad1;
+  float w2o[12];
   DevModel m;
   uint32_t pad[2];
 };

@@ -871,11 +871,14 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
       if (__all(settled)) break;
     }
     ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)ii);  // wave-uniform by construction: say so, so that the
-    {                                                         // box, instance and model records come through scalar loads
-      const DUST_CONST_AS DevBox& bx = a.boxes[ii];
+    // box, transform and model come through scalar loads of ONE record, all issued here: the object-space ray is worked
+    // out before the box test decides whether any lane needs it (18 operations, pinned below so that they are not sunk
+    // behind the branch again), which puts the three loads in flight together instead of one round trip after another
+    const DUST_CONST_AS DevVisit& v = a.visits[ii];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { lo[k] = bx.lo[k]; hi[k] = bx.hi[k]; }
-    }
+    for (int k = 0; k < 3; ++k) { lo[k] = v.lo[k]; hi[k] = v.hi[k]; }
+    const V3 oo = xform_point(v.w2o, o), od = xform_dir(v.w2o, d);
+    const float b0 = v.m.bmin[0], b1 = v.m.bmin[1], b2 = v.m.bmin[2], b3 = v.m.bmax[0], b4 = v.m.bmax[1], b5 = v.m.bmax[2];
     bool go = active && !(any_hit && best.found);
     float te, tx;
     bool box;
@@ -883,14 +886,14 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
     else box = slab_box_nonzero(o, inv_d, lo, hi, te, tx);
     const float limit = best.found ? best.t : tmax;
     go = go & box & !(te * (1.0f - 2e-6f) > limit);
+    asm volatile("" ::"v"(oo.x), "v"(oo.y), "v"(oo.z), "v"(od.x), "v"(od.y), "v"(od.z), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5));
     PROF_COUNT(P_N_CAND_ITER, 1);
     if (!__any(go)) continue;
     PROF_COUNT(P_N_VISITS, 1);
     if (go) {
       if (COUNT) st.instances_tested += 1;
-      const DUST_CONST_AS DevVisit& v = a.visits[ii];  // transform + model in one record: one scalar-load level, not two
       PROF_ENTER(P_INSTANCE);
-      trace_instance<RT, COUNT>(v.m, ii, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin, tmax, any_hit, best, st);
+      trace_instance<RT, COUNT>(v.m, ii, oo, od, tmin, tmax, any_hit, best, st);
       PROF_LEAVE(P_INSTANCE);
     }
   }
