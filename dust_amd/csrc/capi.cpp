@@ -168,7 +168,7 @@ struct DustHipPipeline {
   uint32_t counter_parity[4] = {0, 0, 0, 0};  // per pass kind: which of its two counter sets the next launch uses
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
-  DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement;
+  DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
   DeviceBuffer gi_sort_keys, gi_sort_vals, gi_sort_keys_out, gi_perm, gi_sort_tmp;  // position order of the surfel pool
   size_t gi_sort_tmp_bytes = 0;
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 32x32 tile grouped by ray octant
@@ -827,6 +827,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.gi.pixel_surfel = static_cast<dust::DevSurfel*>(p->gi_pixel_surfel.p);
   a.gi.requests = static_cast<dust::DevHashRequest*>(p->gi_requests.p);
   a.gi.replacement = static_cast<dust::DevSurfel*>(p->gi_replacement.p);
+  a.gi.sun_payload = static_cast<float*>(p->gi_sun_payload.p);
   if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 8 * sizeof(dust::DevStats), st));
   // primary + AO in one launch unless told otherwise (DUST_HIP_NO_FUSE=1 keeps the reference's one-launch-per-pass shape)
   const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !std::getenv("DUST_HIP_NO_FUSE");
@@ -877,8 +878,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
-    dust::FrameArgs b = a;  // 64 consecutive surfels per wavefront: one row of "tiles"
-    b.tiles_x = (p->gi_pool_size + 63) / 64;
+    dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
+    b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
     b.tiles_y = 1;
     take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
@@ -961,6 +962,7 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   }
   HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));
   HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
+  HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys, &p->gi_sort_vals, &p->gi_sort_keys_out, &p->gi_perm}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
   p->gi_sort_tmp_bytes = 0;
   HIP_TRY(dust::sort_pairs_u32(nullptr, &p->gi_sort_tmp_bytes, nullptr, nullptr, nullptr, nullptr, surfel_pool_size, 32, p->ctx->stream));

@@ -122,6 +122,7 @@ struct DevGI {
   DevSurfel* pixel_surfel;  // width*height: the surfel each pixel wants to enqueue
   DevHashRequest* requests; // pool_size
   DevSurfel* replacement;   // pool_size: direction == 0xFFFFFFFF means "keep"
+  float* sun_payload;       // pool_size x 4: what the surfel's sun ray adds to the value of its request (zero when shadowed)
   const uint32_t* perm;     // surfel indices ordered by position (k_surfel_keys + radix sort), or null = pool order
   uint32_t* sort_keys;      // pool_size keys / indices the sort consumes (k_surfel_keys fills them)
   uint32_t* sort_vals;

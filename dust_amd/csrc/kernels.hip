@@ -1618,56 +1618,68 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
   WorkCursor wc = cursor_begin();
   Packet p;
   const V3 sun = mk(a0.sky[48], a0.sky[49], a0.sky[50]);
-  while (next_packet(a0, wc, p)) {  // tiles_x = ceil(pool_size / 64), tiles_y = 1: 64 consecutive surfels per wave
+  // Work items: 64 consecutive surfels x one ray kind. The closest-hit cosine rays of every group come first (the long
+  // items), then the any-hit sun rays: with both rays of a group in one item the pool is only 1.3 items per resident wave and
+  // the kernel lasts as long as the waves that drew two. What a lit surfel receives from the sun goes through its own array
+  // and is added when the request is applied (surfel.rmiss:14-26 / surfel.rchit:35-102 add it to the same value there).
+  while (next_packet(a0, wc, p)) {  // tiles_x = 2 * ceil(pool_size / 64), tiles_y = 1
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
-    const uint32_t slot = (p.px >> 3) * 64u + (threadIdx.x & 63u);
+    const uint32_t groups = (a.gi.pool_size + 63u) / 64u;
+    const uint32_t item = p.px >> 3;
+    const bool sun_item = item >= groups;
+    const uint32_t slot = (sun_item ? item - groups : item) * 64u + (threadIdx.x & 63u);
     const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
     const bool in_range = i < a.gi.pool_size;
     DevSurfel e;
     e.x = e.y = e.z = 0.0f; e.direction = 0xFFFFFFFFu;
     if (in_range) e = a.gi.pool[i];
     const bool live = in_range && e.direction < 6u;
+    const V3 n = faceid2normal(live ? e.direction : 0u);
+    const V3 org = mk(e.x + 2.01f * n.x, e.y + 2.01f * n.y, e.z + 2.01f * n.z);
+    const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+    const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
+    V3 dir = sd;
+    bool act = live && dot3(sun, n) > 0.0f;
+    if (!sun_item) {
+      act = live;
+      dir = mk(0, 0, 1);
+      if (live) {
+        const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
+        const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                         div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
+        dir = normalize3(rotate_by_normal(n, ns));
+      }
+    }
+    Hit h;
+    {
+      const Range3 orgs = wave_range(live, org);
+      const uint32_t ncand = cull_instances(a, __any(act), orgs, sun_item ? point_range(sd) : wave_range(live, dir), 10000.0f, cand);
+      LaneStats cur = {0, 0, 0, 0, 0, 0};
+      trace_ray<3, COUNT>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
+      if (COUNT) add_stats(sun_item ? st_sun : st_cos, cur);
+      __builtin_amdgcn_wave_barrier();
+    }
+    ArgsRef ar = reload_args(a0);
+    if (sun_item) {  // surfel/nee.rmiss:15-27
+      f32x4 pay = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (act && !h.found) {
+        const float dn = dot3(n, sd);
+        pay.x = ar.sun_term[0] * dn; pay.y = ar.sun_term[1] * dn; pay.z = ar.sun_term[2] * dn;
+      }
+      if (in_range) reinterpret_cast<f32x4*>(ar.gi.sun_payload)[i] = pay;
+      continue;
+    }
+    const V3 cd = dir;
     DevHashRequest rq;
     rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
     DevSurfel repl;
     repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
-    const V3 n = faceid2normal(live ? e.direction : 0u);
-    const V3 org = mk(e.x + 2.01f * n.x, e.y + 2.01f * n.y, e.z + 2.01f * n.z);
-    const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
-    V3 cd = mk(0, 0, 1);
-    if (live) {
-      const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
-      const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
-                       div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
-      cd = normalize3(rotate_by_normal(n, ns));
-    }
-    V3 payload = mk(0, 0, 0);
-    const bool sun_live = live && dot3(sun, n) > 0.0f;
-    const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
-    Hit h;
-    const Range3 orgs = wave_range(live, org);
-#pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-      ArgsRef b = reload_args(a0);
-      const bool act = k == 0 ? sun_live : live;
-      const V3 dir = k == 0 ? sd : cd;
-      const uint32_t ncand = cull_instances(b, __any(act), orgs, k == 0 ? point_range(sd) : wave_range(live, cd), 10000.0f, cand);
-      LaneStats cur = {0, 0, 0, 0, 0, 0};
-      trace_ray<3, COUNT>(b, act, org, dir, 0.1f, 10000.0f, k == 0, cand, ncand, h, cur);
-      if (COUNT) add_stats(k == 0 ? st_sun : st_cos, cur);
-      __builtin_amdgcn_wave_barrier();
-      if (k == 0 && sun_live && !h.found) {  // surfel/nee.rmiss:15-27
-        const float dn = dot3(n, sd);
-        payload = mk(b.sun_term[0] * dn, b.sun_term[1] * dn, b.sun_term[2] * dn);
-      }
-    }
-    ArgsRef ar = reload_args(a0);
     if (live) {
       rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
       rq.dir_flags = e.direction & 0xFFu;
       if (!h.found) {  // surfel.rmiss:14-26
         const V3 sk = sky_radiance(ar.sky, normalize3(cd));
-        rq.vx = sk.x + payload.x; rq.vy = sk.y + payload.y; rq.vz = sk.z + payload.z;
+        rq.vx = sk.x; rq.vy = sk.y; rq.vz = sk.z;
         rq.dir_flags |= 0x100u;
       } else {         // surfel.rchit:35-102
         HashKey key;
@@ -1681,7 +1693,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
         const float rnd0 = div_const((float)ar.noise0[((ny0 + 40u + ar.rand) % 128u) * 128u + ((nx0 + 114u + ar.rand) % 128u)], 255.0f);
         if (found) {
           rad = modulate_by_avg_albedo(rad, alb);
-          rq.vx = rad.x + payload.x; rq.vy = rad.y + payload.y; rq.vz = rad.z + payload.z;
+          rq.vx = rad.x; rq.vy = rad.y; rq.vz = rad.z;
           rq.dir_flags |= 0x100u;
         } else if (rnd0 > 1.0f / (float)(count + 2u)) {
           repl = sf;
@@ -1716,7 +1728,8 @@ __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs) {
         if (rq.dir_flags & 0x100u) {
           HashKey k;
           k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
-          hash_insert(a.gi, k, mk(rq.vx, rq.vy, rq.vz), a.frame_index);
+          const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
+          hash_insert(a.gi, k, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
         }
         const DevSurfel r = a.gi.replacement[j];
         if (r.direction != 0xFFFFFFFFu) a.gi.pool[j % a.gi.pool_size] = r;
@@ -1733,7 +1746,8 @@ __global__ void k_surfel_apply_racy(const FrameArgs) {
     if (rq.dir_flags & 0x100u) {
       HashKey k;
       k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
-      hash_insert(a.gi, k, mk(rq.vx, rq.vy, rq.vz), a.frame_index);
+      const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];
+      hash_insert(a.gi, k, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
     }
     const DevSurfel r = a.gi.replacement[j];
     if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
