@@ -659,47 +659,40 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
 }
 
 // ------------------------------------------------------------------ packet-level instance culling
-// Wave-wide min/max on the VALU cross-lane paths: four DPP steps leave each 16-lane row holding its own result,
-// v_readlane picks the four rows up. No LDS round trips (the ds_bpermute butterfly this replaces made six).
-// Call with all 64 lanes executing.
-template <bool MAX>
-__device__ __forceinline__ float wave_reduce(float v) {
-  auto op = [](float x, float y) { return MAX ? fmaxf(x, y) : fminf(x, y); };
-  auto dpp = [](float x, int ctrl_is) {
-    const int xi = __float_as_int(x);
-    int r;
-    switch (ctrl_is) {
-      case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
-      case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
-      case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
-      default: r = __builtin_amdgcn_update_dpp(xi, xi, 0x140, 0xF, 0xF, false); break; // row_mirror
-    }
-    return __int_as_float(r);
-  };
-  v = op(v, dpp(v, 0));
-  v = op(v, dpp(v, 1));
-  v = op(v, dpp(v, 2));
-  v = op(v, dpp(v, 3));
-  const int vi = __float_as_int(v);
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
-  return op(op(r0, r1), op(r2, r3));
-}
-__device__ __forceinline__ float wave_min(float v) { return wave_reduce<false>(v); }
-__device__ __forceinline__ float wave_max(float v) { return wave_reduce<true>(v); }
-
-// per-axis interval of a per-lane vector over the wave's active rays
-struct Range3 { float lo[3], hi[3]; };
+struct Range3 { float lo[3], hi[3]; };  // per-axis interval of a per-lane vector over the wave's active rays
+// Wave-wide min/max of a per-lane vector on the VALU cross-lane paths (no LDS round trips): v_min/v_max_f32 with a DPP
+// source, four steps inside each 16-lane row (quad swaps, half mirror, mirror), then row_bcast:15 and row_bcast:31 carry
+// the row results up so that lane 63 holds the wave's; one v_readlane each picks them up. Three chains run interleaved:
+// a DPP read needs two wait states after the VALU write of its source, and the two instructions in between provide
+// them. 7 instructions per reduction; written through __builtin_amdgcn_update_dpp + fminf the compiler spent a move, a
+// canonicalisation and a nop on every step (24). Call with all 64 lanes executing.
+#define DUST_DPP_STEP(op, ctrl)  op " %0, %0, %0 " ctrl "\n" op " %1, %1, %1 " ctrl "\n" op " %2, %2, %2 " ctrl "\n"
+#define DUST_DPP_REDUCE(op, x, y, z)                                         \
+  asm("s_nop 1\n"                                                           \
+      DUST_DPP_STEP(op, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")   \
+      DUST_DPP_STEP(op, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")   \
+      DUST_DPP_STEP(op, "row_half_mirror row_mask:0xf bank_mask:0xf")       \
+      DUST_DPP_STEP(op, "row_mirror row_mask:0xf bank_mask:0xf")            \
+      DUST_DPP_STEP(op, "row_bcast:15 row_mask:0xa bank_mask:0xf")          \
+      DUST_DPP_STEP(op, "row_bcast:31 row_mask:0xc bank_mask:0xf")          \
+      : "+v"(x), "+v"(y), "+v"(z))
 __device__ __forceinline__ Range3 wave_range(bool active, V3 v) {
-  const float vv[3] = {v.x, v.y, v.z};
+  auto top = [](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); };
   Range3 r;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    r.lo[k] = wave_min(active ? vv[k] : INFINITY);
-    r.hi[k] = wave_max(active ? vv[k] : -INFINITY);
+  {
+    float l0 = active ? v.x : INFINITY, l1 = active ? v.y : INFINITY, l2 = active ? v.z : INFINITY;
+    DUST_DPP_REDUCE("v_min_f32_dpp", l0, l1, l2);
+    r.lo[0] = top(l0); r.lo[1] = top(l1); r.lo[2] = top(l2);
+  }
+  {
+    float h0 = active ? v.x : -INFINITY, h1 = active ? v.y : -INFINITY, h2 = active ? v.z : -INFINITY;
+    DUST_DPP_REDUCE("v_max_f32_dpp", h0, h1, h2);
+    r.hi[0] = top(h0); r.hi[1] = top(h1); r.hi[2] = top(h2);
   }
   return r;
 }
+#undef DUST_DPP_REDUCE
+#undef DUST_DPP_STEP
 __device__ __forceinline__ Range3 point_range(V3 v) {  // every ray shares v (the camera position, the sun direction)
   Range3 r;
   r.lo[0] = r.hi[0] = v.x; r.lo[1] = r.hi[1] = v.y; r.lo[2] = r.hi[2] = v.z;
