@@ -323,13 +323,14 @@ __device__ bool brick_intersect(V3 o, V3 d, V3 tc, uint32_t m1, uint32_t m2, flo
     // vector (ties and NaNs set more than one component: step(edge, x) is 1 unless x < edge); selecting on the same
     // predicates gives the same position and the same tMax -- x * 1 is x, tMax + x * 0 is tMax (up to the sign of a
     // zero tMax, and except for direction components in the denormal range, where x * 0 is NaN) -- in half the VALU work
-    const bool bx = !(tm.z < tm.x) & !(tm.y < tm.x);
-    const bool by = !(tm.x < tm.y) & !(tm.z < tm.y);
-    const bool bz = !(tm.y < tm.z) & !(tm.x < tm.z);
+    // step(tMax.xyz, tMax.zxy) * step(tMax.xyz, tMax.yzx) component by component is "not (the smallest of the three,
+    // NaNs ignored, is below this one)": one v_min3 (needed for the hit distance anyway) and three compares
+    // (tests/cpp/division_identity_test.c walks every combination of NaN, infinities, zeros and finite values)
+    hd = fminf(fminf(tm.x, tm.y), tm.z);
+    const bool bx = !(hd < tm.x), by = !(hd < tm.y), bz = !(hd < tm.z);
     px += bx ? sx : 0;
     py += by ? sy : 0;
     pz += bz ? sz : 0;
-    hd = fminf(fminf(tm.x, tm.y), tm.z);
     if (hd + 0.001f >= t1) return false;
     tm.x = bx ? tm.x + td.x : tm.x;
     tm.y = by ? tm.y + td.y : tm.y;

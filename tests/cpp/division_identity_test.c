@@ -66,6 +66,20 @@ int main(int argc, char** argv) {
       }
     }
   }
+  /* The brick DDA's axis predicates (kernels.hip, brick_intersect): step(tMax.xyz, tMax.zxy) * step(tMax.xyz, tMax.yzx),
+   * i.e. !(z < x) & !(y < x) per component, against the form the kernel evaluates, !(min3(x, y, z) < x) with a NaN-ignoring
+   * minimum: every combination of NaN, infinities, signed zeros and finite values. */
+  {
+    static const float v[] = {NAN, -INFINITY, -1.0f, -0.0f, 0.0f, 1.0f, 2.0f, INFINITY};
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j)
+        for (int k = 0; k < 8; ++k) {
+          const float x = v[i], y = v[j], z = v[k];
+          const int bx = !(z < x) & !(y < x), by = !(x < y) & !(z < y), bz = !(y < z) & !(x < z);
+          const float hd = fminf(fminf(x, y), z);
+          if (bx != !(hd < x) || by != !(hd < y) || bz != !(hd < z)) { printf("axis predicates differ at %g %g %g\n", x, y, z); ++bad; }
+        }
+  }
   printf("samples %lld bad %lld\n", n, bad);
   return bad == 0 ? 0 : 1;
 }
