@@ -155,7 +155,7 @@ __device__ __forceinline__ void store_half4(DUST_RW(uint16_t) plane, size_t pix,
   u32x2 v;
   v.x = (uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16);
   v.y = (uint32_t)f2h(c) | ((uint32_t)f2h(d) << 16);
-  *(DUST_GLOBAL_AS u32x2*)(plane + pix * 4) = v;
+  __builtin_nontemporal_store(v, (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));  // written once, read by a later pass: do not displace the scene in L2
 }
 
 // ------------------------------------------------------------------ headers/normal.glsl, nrd.glsl
@@ -1087,8 +1087,8 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
     const V3 dir = normalize3(d);
     const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
     store_radiance(a.g.denoised, pix, mk(div_const(s0.x + s1.x, 3.14f), div_const(s0.y + s1.y, 3.14f), div_const(s0.z + s1.z, 3.14f)), 100000.0f);
-    a.g.albedo[pix] = 0xFFFFFFFFu;
-    a.g.depth[pix] = INFINITY;
+    __builtin_nontemporal_store(0xFFFFFFFFu, &a.g.albedo[pix]);
+    __builtin_nontemporal_store(INFINITY, &a.g.depth[pix]);
     store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
@@ -1109,13 +1109,13 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
   const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
   const uint32_t pal = m.materials[b.material_ptr + voff];
   const uint32_t col = m.palette[pal];
-  a.g.albedo[pix] = pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
-                                 div_const((float)((col >> 16) & 255u), 255.0f), 1.0f);
-  a.g.depth[pix] = h.t;
+  __builtin_nontemporal_store(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
+                                           div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
+  __builtin_nontemporal_store(h.t, &a.g.depth[pix]);
   hitT = h.t;
   normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
-  a.g.normal[pix] = normal_packed;
-  a.g.voxel_id[pix] = (h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16);
+  __builtin_nontemporal_store(normal_packed, &a.g.normal[pix]);
+  __builtin_nontemporal_store((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
   const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
   const V3 hpm = xform_point(in.w2o, hpw);
   DUST_RO(float) P = in.prev;
