@@ -339,6 +339,10 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_pipeline_plane_device_ptr(self._h, plane, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def bind_plane(self, plane, device_ptr, nbytes):
+        """Redirect a plane to caller-owned device memory (device_ptr = 0 / None: back to the pipeline's own storage)."""
+        L.check(self._lib.dust_hip_pipeline_bind_plane(self._h, plane, C.c_void_p(device_ptr or None), nbytes))
+
     def clear(self):
         L.check(self._lib.dust_hip_pipeline_clear(self._h))
 

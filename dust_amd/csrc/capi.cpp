@@ -164,6 +164,8 @@ struct DustHipPipeline {
   DustHipContext* ctx = nullptr;
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
+  void* bound[DUST_PLANE_COUNT] = {};  // caller-owned storage a plane was redirected to (dust_hip_pipeline_bind_plane), or null
+  void* plane(int i) const { return bound[i] ? bound[i] : planes[i].p; }
   DeviceBuffer noise0, noise5, counters, stats;
   uint32_t counter_parity[4] = {0, 0, 0, 0};  // per pass kind: which of its two counter sets the next launch uses
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
@@ -716,7 +718,8 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
     HIP_TRY(p->exposure.alloc(257 * 4));
     HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
-    for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    // timing only (nothing waits on them for visibility): without the system-scope fence a record does not flush L2 between passes
+    for (auto& e : p->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     *out = p.release();
     return DUST_OK;
   });
@@ -787,14 +790,14 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.cam.tan_half_fov = cam->tan_half_fov; a.cam.far_ = cam->far_; a.cam.near_ = cam->near_;
   std::memcpy(a.sky, sky->state, sizeof(a.sky));
   sun_constants(a.sky, a.sun_dir, a.sun_term);
-  a.g.illuminance = static_cast<uint16_t*>(p->planes[DUST_PLANE_ILLUMINANCE].p);
-  a.g.denoised = static_cast<uint16_t*>(p->planes[DUST_PLANE_DENOISED].p);
-  a.g.albedo = static_cast<uint32_t*>(p->planes[DUST_PLANE_ALBEDO].p);
-  a.g.normal = static_cast<uint32_t*>(p->planes[DUST_PLANE_NORMAL].p);
-  a.g.depth = static_cast<float*>(p->planes[DUST_PLANE_DEPTH].p);
-  a.g.motion = static_cast<uint16_t*>(p->planes[DUST_PLANE_MOTION].p);
-  a.g.voxel_id = static_cast<uint32_t*>(p->planes[DUST_PLANE_VOXEL_ID].p);
-  a.g.accum = static_cast<float*>(p->planes[DUST_PLANE_ACCUM].p);
+  a.g.illuminance = static_cast<uint16_t*>(p->plane(DUST_PLANE_ILLUMINANCE));
+  a.g.denoised = static_cast<uint16_t*>(p->plane(DUST_PLANE_DENOISED));
+  a.g.albedo = static_cast<uint32_t*>(p->plane(DUST_PLANE_ALBEDO));
+  a.g.normal = static_cast<uint32_t*>(p->plane(DUST_PLANE_NORMAL));
+  a.g.depth = static_cast<float*>(p->plane(DUST_PLANE_DEPTH));
+  a.g.motion = static_cast<uint16_t*>(p->plane(DUST_PLANE_MOTION));
+  a.g.voxel_id = static_cast<uint32_t*>(p->plane(DUST_PLANE_VOXEL_ID));
+  a.g.accum = static_cast<float*>(p->plane(DUST_PLANE_ACCUM));
   a.width = p->width; a.height = p->height;
   a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
   a.row_begin = fp->row_begin;
@@ -931,8 +934,15 @@ DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustH
 }
 DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline* p, DustHipPlane plane, void** ptr, size_t* bytes) {
   if (!p || int(plane) < 0 || plane >= DUST_PLANE_COUNT) return fail(DUST_ERR_INVALID_ARGUMENT, "bad plane");
-  if (ptr) *ptr = p->planes[plane].p;
+  if (ptr) *ptr = p->plane(plane);
   if (bytes) *bytes = p->planes[plane].bytes;
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_bind_plane(DustHipPipeline* p, DustHipPlane plane, void* device_ptr, size_t bytes) {
+  if (!p || int(plane) < 0 || plane >= DUST_PLANE_COUNT) return fail(DUST_ERR_INVALID_ARGUMENT, "bad plane");
+  if (device_ptr && bytes < p->planes[plane].bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "bound storage is smaller than the plane");
+  if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u)) return fail(DUST_ERR_INVALID_ARGUMENT, "bound storage must be 16-byte aligned");
+  p->bound[plane] = device_ptr;  // launches enqueued from now on use it; the caller orders its own use of the memory on the stream
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, void* dst, size_t dst_bytes) {
@@ -940,7 +950,7 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, 
   if (dst_bytes < p->planes[plane].bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  HIP_TRY(hipMemcpy(dst, p->planes[plane].p, p->planes[plane].bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dst, p->plane(plane), p->planes[plane].bytes, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size) {
@@ -1038,9 +1048,9 @@ DustStatus dust_hip_tone_map(DustHipPipeline* p, const DustHipToneMapParams* tp)
   if (!(tp->max_log_luminance > tp->min_log_luminance)) return fail(DUST_ERR_INVALID_ARGUMENT, "empty luminance range");
   HIP_TRY(hipSetDevice(p->ctx->device));
   uint32_t* hist = static_cast<uint32_t*>(p->exposure.p);
-  HIP_TRY(dust::launch_tone_map(static_cast<const uint16_t*>(p->planes[DUST_PLANE_DENOISED].p),
-                                static_cast<const uint32_t*>(p->planes[DUST_PLANE_ALBEDO].p),
-                                static_cast<uint16_t*>(p->planes[DUST_PLANE_OUTPUT].p), p->width * p->height, hist,
+  HIP_TRY(dust::launch_tone_map(static_cast<const uint16_t*>(p->plane(DUST_PLANE_DENOISED)),
+                                static_cast<const uint32_t*>(p->plane(DUST_PLANE_ALBEDO)),
+                                static_cast<uint16_t*>(p->plane(DUST_PLANE_OUTPUT)), p->width * p->height, hist,
                                 reinterpret_cast<float*>(hist + 256), tp->min_log_luminance,
                                 tp->max_log_luminance - tp->min_log_luminance, tp->time_coefficient, tp->color_space_conversion,
                                 tp->transfer_function, p->ctx->stream));
@@ -1058,7 +1068,7 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->planes[i].p, 0, p->planes[i].bytes, p->ctx->stream));
+  for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->plane(i), 0, p->planes[i].bytes, p->ctx->stream));
   p->accum_count = 0;
   return DUST_OK;
 }

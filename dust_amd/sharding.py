@@ -70,6 +70,24 @@ class AsyncGather:
         self.k += 1
         return b
 
+    def wait_slot(self, b):
+        """Before slot b's source is rendered into again: the gather that last read it has completed."""
+        b %= len(self.works)
+        if self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+
+    def submit_view(self, view):
+        """Gather `view` (this rank's finished frame or band, still in its render target) to rank dst without a staging
+        copy. The caller alternates between len(self.bufs) targets and calls wait_slot(k) before rendering into one again."""
+        b = self.k % len(self.bufs)
+        self.wait_slot(b)
+        self.bufs[b] = view
+        if self.active:
+            self.works[b] = self.dist.gather(view, self.out[b] if self.out is not None else None, dst=self.dst, async_op=True)
+        self.k += 1
+        return b
+
     def finish(self):
         for i, w in enumerate(self.works):
             if w is not None:

@@ -247,6 +247,12 @@ DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const Du
  * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
 DustStatus dust_hip_pipeline_plane_device_ptr(DustHipPipeline*, DustHipPlane, void** ptr, size_t* bytes);
+/* Render target binding (the reference binds its G-buffer images per frame, standard.rs:974-1050): redirects one plane to
+ * caller-owned device memory of at least the plane's size (16-byte aligned), or back to the pipeline's own storage with a
+ * null pointer. Frames enqueued afterwards read and write the plane there -- e.g. alternate two illuminance buffers so that
+ * frame k can be sent to another GPU while frame k+1 renders, without a copy. The memory must stay valid until those frames
+ * have completed; ordering against the caller's own use is the caller's (same stream, or events). */
+DustStatus dust_hip_pipeline_bind_plane(DustHipPipeline*, DustHipPlane, void* device_ptr, size_t bytes);
 /* synchronous device-to-host copy of one plane */
 DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* dst, size_t dst_bytes);
 /* Persistent GI buffers (standard.rs:334-358): (re)allocates and resets the spatial hash (SpatialHashCapacity,

@@ -267,6 +267,7 @@ class StandardPipeline {
     check(s);
     return true;
   }
+  void bind_plane(DustHipPlane plane, void* device_ptr, size_t bytes) { check(dust_hip_pipeline_bind_plane(h_, plane, device_ptr, bytes)); }
   template <class T>
   std::vector<T> read_plane(DustHipPlane plane) {
     size_t bytes = 0;

@@ -239,3 +239,43 @@ def test_moving_instance_motion_vectors(ctx, noise5):
         P.assert_parity(P.compare_gbuffers(g, hip))
         hit = np.isfinite(g.depth)
         assert (P.half_to_float(hip["motion"])[hit][:, :3] != 0).any()   # something actually moved
+
+
+def test_bound_plane_equals_own_storage():
+    """dust_hip_pipeline_bind_plane: a frame rendered into caller-owned storage (here: a second pipeline's depth-sized
+    scratch is not needed -- a raw hipMalloc through torch) carries the same bits as the pipeline's own plane, the other
+    planes are untouched by the redirection, and unbinding restores the pipeline's storage."""
+    import torch
+    desc = P.small_scene(seed=21, n_models=3, n_instances=6, size=(40, 36, 28))
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    sky, cam = P.sky_state(), P.camera_for((60.0, 40.0, 55.0))
+    n5 = synth.stbn_unitvec3_cosine(layers=2)
+    W, H = 120, 72
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+
+    def frame(bind):
+        pipe = api.StandardPipeline(ctx, W, H)
+        pipe.set_noise(5, n5)
+        target = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+        if bind:
+            pipe.bind_plane(L.PLANE_ILLUMINANCE, target.data_ptr(), target.numel() * 2)
+        pipe.render(scene, cam, sky, passes, frame_index=1, rand=synth.frame_rand(3, 1))
+        ctx.sync()
+        ill = pipe.read_plane(L.PLANE_ILLUMINANCE)
+        out = (ill, pipe.read_plane(L.PLANE_DEPTH), target.cpu().numpy().view(np.uint16).copy())
+        if bind:
+            pipe.bind_plane(L.PLANE_ILLUMINANCE, 0, 0)
+            assert not pipe.read_plane(L.PLANE_ILLUMINANCE).any()   # the pipeline's own (never written) storage is back
+        return out
+
+    own_ill, own_depth, untouched = frame(False)
+    b_ill, b_depth, b_target = frame(True)
+    assert own_ill.view(np.uint16).any() and not untouched.any()
+    assert np.array_equal(own_ill.view(np.uint16), b_ill.view(np.uint16))
+    assert np.array_equal(own_ill.view(np.uint16), b_target.reshape(own_ill.view(np.uint16).shape))
+    assert np.array_equal(own_depth.view(np.uint32), b_depth.view(np.uint32))
+    import pytest
+    pipe = api.StandardPipeline(ctx, W, H)
+    with pytest.raises(L.DustError):
+        pipe.bind_plane(L.PLANE_ILLUMINANCE, torch.zeros(16, device="cuda").data_ptr(), 64)   # too small
