@@ -107,6 +107,18 @@ WORKER = textwrap.dedent('''
     ag.finish()
     if rank == 0:
         assert [int(x[0]) for x in ag.last()] == [400 + r for r in range(world)]
+    # --- the same without staging copies: two render targets used in turn, gathered straight from a row view of them
+    targets = [torch.zeros((6, 4), dtype=torch.int32) for _ in range(2)]
+    av = sharding.AsyncGather(dist, targets[0][2:4])
+    for k in range(5):
+        av.wait_slot(k % 2)                      # the gather that last read this target is done
+        targets[k % 2].fill_(1000 * k + rank)    # "render" frame k into it
+        av.submit_view(targets[k % 2][2:4])
+    av.finish()
+    if rank == 0:
+        got = av.last()
+        assert [tuple(x.shape) for x in got] == [(2, 4)] * world
+        assert [int(x[0, 0]) for x in got] == [4000 + r for r in range(world)]
         print("distributed ok")
     dist.barrier()
     dist.destroy_process_group()
