@@ -1289,9 +1289,9 @@ __device__ uint32_t logluv_encode(V3 rgb) {  // spatial_hash.glsl:28-60
 __device__ V3 logluv_decode(uint32_t p) {  // spatial_hash.glsl:64-93
   const uint32_t Le = p >> 18;
   if (Le == 0) return mk(0, 0, 0);
-  const float logY = ((float)Le + 0.5f) / 409.6f - 20.0f;
+  const float logY = div_const((float)Le + 0.5f, 409.6f) - 20.0f;
   const float Y = __builtin_amdgcn_exp2f(logY);  // v_exp_f32
-  const float u = ((float)((p >> 9) & 0x1FFu) + 0.5f) / 820.0f, v = ((float)(p & 0x1FFu) + 0.5f) / 820.0f;
+  const float u = div_const((float)((p >> 9) & 0x1FFu) + 0.5f, 820.0f), v = div_const((float)(p & 0x1FFu) + 0.5f, 820.0f);
   const float invDenom = 1.0f / ((6.0f * u - 16.0f * v) + 12.0f);
   const float x = (9.0f * u) * invDenom, y = (4.0f * v) * invDenom;
   const float s = Y / y;
@@ -1349,7 +1349,7 @@ __device__ void hash_insert(const DUST_CONST_AS DevGI& gi, HashKey key, V3 value
 }
 __device__ __forceinline__ float srgb_to_linear(float c) {  // color.glsl:1-5
   // pow(x, 2.4) as exp2(2.4 log2 x) on the hardware transcendentals: radiance (1e-3 tolerance), a fifth of the libm routine
-  return c < 0.04045f ? c / 12.92f : __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(fabsf(c + 0.055f) / 1.055f));
+  return c < 0.04045f ? div_const(c, 12.92f) : __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf(div_const(fabsf(c + 0.055f), 1.055f)));
 }
 __device__ V3 modulate_by_avg_albedo(V3 r, uint32_t packed) {  // final_gather.rchit:68-80, surfel.rchit:60-71
   const V3 alb = mk(srgb_to_linear(div_const((float)((packed >> 22) & 1023u), 1023.0f)), srgb_to_linear(div_const((float)((packed >> 12) & 1023u), 1023.0f)),
