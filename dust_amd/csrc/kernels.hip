@@ -4,13 +4,15 @@
 // (crates/render/src/pipeline/standard.rs:477-725, assets/shaders/{primary,final_gather,surfel})
 // is done here by walking the VDB hierarchy directly:
 //   * persistent workgroups, one 64-lane wavefront per 8x8 pixel packet, packets pulled from
-//     per-XCD-region atomic counters (block b runs on XCD b%8, so a region stays in one L2);
+//     per-XCD-region atomic counters (block b runs on XCD b%8, so a region stays in one L2) through a
+//     small LDS queue per workgroup; the launch descriptor is read in place from the kernarg segment;
 //   * the root node (4096-bit child mask + rank prefix) of every model is staged in LDS once per
 //     workgroup; mid nodes and brick masks come from HBM/L2 (16 B and 8 B loads);
 //   * the packet's rays are bounded once (DPP wave reductions) and tested against all instance boxes
 //     64 at a time (__ballot compaction into a per-wave LDS candidate list, rank-sorted front to back);
 //   * incoherent rays are regrouped before they are traced: gather rays by direction octant inside
-//     32x32 pixel tiles (k_gather_order), surfels by position (k_surfel_keys + a radix sort);
+//     32x32 pixel tiles (k_gather_order), surfels by position (k_surfel_keys + a radix sort); and their
+//     lanes visit instances independently (a uniform box scan leaves each lane its own candidate mask);
 //   * per ray, a hierarchical DDA over 16^3 / 4^3 cells finds candidate bricks front to back; the
 //     brick test itself is the reference's intersection shader arithmetic, bit for bit
 //     (primary/hit.rint:43-131, final_gather/ambient_occlusion.rint:46-134, rough.rint:42-59).
