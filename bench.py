@@ -84,6 +84,10 @@ def main():
     W, H = args.width, args.height
     Hband = H
     stream = torch.cuda.current_stream().cuda_stream
+    if world > 1:
+        # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
+        # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1
+        os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
     ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(stream))
 
     t0 = time.time()

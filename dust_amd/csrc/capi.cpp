@@ -819,7 +819,15 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8 + 16;
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
-  const uint32_t grid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (total_tiles + 7) / 8));
+  // Workgroups per persistent launch: every slot of every CU, minus what the caller asks to be left free. The traversal
+  // kernels hold all VGPRs of the SIMDs they run on, so a kernel of another queue (an RCCL send/receive moving the previous
+  // frame to another GPU) can only become resident next to them where a workgroup slot was left empty.
+  uint32_t resident = uint32_t(ctx->num_cus) * bpc;
+  if (const char* env = std::getenv("DUST_HIP_RESERVE_BLOCKS")) {
+    const uint32_t r = uint32_t(std::strtoul(env, nullptr, 10)) & ~7u;  // whole rounds over the 8 XCDs
+    if (r + 8u <= resident) resident -= r;
+  }
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
   a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);
@@ -874,7 +882,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
       g.tiles_x = otx * oty * 16;  // 16 packets of 64 per tile, the empty ones skipped by the kernel
       g.tiles_y = 1;
-      ggrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (g.tiles_x + 7) / 8));
+      ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
     take_counters(p, 2, g);
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
@@ -898,7 +906,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     } else if (ctx->timing) {
       HIP_TRY(hipEventRecord(p->ev[6], st));
     }
-    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus) * bpc, (b.tiles_x + 7) / 8));
+    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
     HIP_TRY(dust::launch_surfel(b, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
   }
