@@ -241,6 +241,33 @@ def test_moving_instance_motion_vectors(ctx, noise5):
         assert (P.half_to_float(hip["motion"])[hit][:, :3] != 0).any()   # something actually moved
 
 
+def test_launch_shape_does_not_change_results(ctx, noise5, monkeypatch):
+    """Workgroup size, workgroups per CU and slots left free for other queues (DUST_HIP_BLOCK / _BLOCKS_PER_CU /
+    _RESERVE_BLOCKS) decide which wavefront traces which tile and through which LDS queue -- never what a pixel gets."""
+    data, _ = synth.castle_scene(scale=0.15)
+    desc = P.SceneDesc.from_vox(data)
+    scene = P.hip_scene(ctx, desc)
+    s = 0.15
+    cam, sky = P.camera_for((122.0 * s, 300.61 * s, 54.45 * s)), P.sky_state()
+    keys = ("DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RESERVE_BLOCKS")
+    outs = []
+    for env in ({}, {"DUST_HIP_BLOCK": "256"}, {"DUST_HIP_BLOCK": "64", "DUST_HIP_BLOCKS_PER_CU": "1"}, {"DUST_HIP_RESERVE_BLOCKS": "64"},
+                {"DUST_HIP_RESERVE_BLOCKS": "100000"}):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pipe = api.StandardPipeline(ctx, 384, 216)
+        pipe.set_noise(5, noise5)
+        pipe.render(scene, cam, sky, L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION, frame_index=3, rand=99)
+        outs.append(P.read_hip_gbuffer(pipe))
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    for other in outs[1:]:
+        for k in outs[0]:
+            assert outs[0][k].tobytes() == other[k].tobytes(), k
+
+
 def test_bound_plane_equals_own_storage():
     """dust_hip_pipeline_bind_plane: a frame rendered into caller-owned storage (here: a second pipeline's depth-sized
     scratch is not needed -- a raw hipMalloc through torch) carries the same bits as the pipeline's own plane, the other
