@@ -199,3 +199,47 @@ def test_castle_gi_matches_oracle(monkeypatch):
     a, b = P.half_to_float(g.illuminance)[..., :3], P.half_to_float(ill)[..., :3]
     assert np.sqrt(((a - b) ** 2).sum()) / np.sqrt((a ** 2).sum()) <= 1e-3
     assert np.array_equal(g.illuminance[..., 3], ill[..., 3])   # hit distances: bit-exact
+
+
+def test_gi_on_mixed_two_and_three_level_trees_matches_oracle():
+    """A sparse 4096^3 model (root -> level-2 nodes in memory -> mid nodes) and ordinary 256^3 models in one scene: with
+    per-lane instance visits the lanes of one wavefront walk both kinds of hierarchy at the same time. All five passes,
+    three frames, against the oracle."""
+    blocks, mats = synth.procedural_deep_blocks(occupancy=3e-5, sample=True)
+    pal = synth.make_palette(5)
+    small = P.small_scene(seed=31, n_models=2, n_instances=5, size=(40, 36, 44))
+    ctx = api.Context(device=0)
+    deep = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
+    models = [api.Model(ctx, b, m, pal) for b, m in small.models]
+    scene, oscene = api.Scene(ctx), O.Scene()
+    oscene.add_model(blocks, mats, pal, extent=4096)
+    for b, m in small.models:
+        oscene.add_model(b, m, pal)
+    xf = np.eye(3, 4, dtype=np.float32)
+    xf[:, 3] = (-2048.0, -2048.0, -2048.0)
+    scene.add_instance(deep, xf.reshape(12))
+    oscene.add_instance(0, xf.reshape(12))
+    for mid, t in small.instances:
+        scene.add_instance(models[mid], t)
+        oscene.add_instance(1 + mid, t)
+    scene.commit()
+    oscene.commit()
+    sky, cam = P.sky_state(), P.camera_for((150.0, 110.0, 170.0))
+    w, h = 128, 80
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    pipe = api.StandardPipeline(ctx, w, h)
+    pipe.set_noise(0, n0)
+    pipe.set_noise(5, n5)
+    pipe.configure_gi(1 << 14, 1024)
+    gi = O.GI(1 << 14, 1024)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    for f in range(1, 4):
+        rnd = synth.frame_rand(2, f)
+        pipe.render(scene, cam, sky, passes | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
+        g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f)
+        hip = P.read_hip_gbuffer(pipe)
+        P.assert_parity(P.compare_gbuffers(g, hip))
+        used, valid = compare_gi(gi, pipe)
+    ids = hip["voxel_id"][np.isfinite(hip["depth"])] & 0xFFFF
+    assert (ids == 0).any() and (ids != 0).any()   # both kinds of model are on screen
+    assert used > 20 and valid > 20
