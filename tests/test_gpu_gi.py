@@ -243,3 +243,41 @@ def test_gi_on_mixed_two_and_three_level_trees_matches_oracle():
     ids = hip["voxel_id"][np.isfinite(hip["depth"])] & 0xFFFF
     assert (ids == 0).any() and (ids != 0).any()   # both kinds of model are on screen
     assert used > 20 and valid > 20
+
+
+def test_candidate_list_overflow_matches_oracle():
+    """More instances in a packet's way than its candidate list holds (kMaxCand = 160): the packet falls back to walking
+    every instance box in index order. 220 small overlapping instances stacked in front of the camera, all five passes."""
+    rng = np.random.default_rng(77)
+    pal = synth.make_palette(9)
+    xyzi = P.random_model(rng, (12, 12, 12))
+    model_data = api.flatten_model(xyzi, (12, 12, 12), pal)
+    ctx = api.Context(device=0)
+    model = api.Model(ctx, model_data[0], model_data[1], pal)
+    scene, oscene = api.Scene(ctx), O.Scene()
+    oscene.add_model(model_data[0], model_data[1], pal)
+    n = 220
+    for i in range(n):
+        t = np.eye(3, 4, dtype=np.float32)
+        t[:, 3] = (float(rng.integers(-10, 10)), float(rng.integers(-10, 10)), float(-4 * (i % 55)))   # a deep stack along the view axis
+        scene.add_instance(model, t.reshape(12))
+        oscene.add_instance(0, t.reshape(12))
+    scene.commit()
+    oscene.commit()
+    sky, cam = P.sky_state(), P.camera_for((3.0, 5.0, 40.0), target=(0.0, 0.0, -100.0))   # looking down the stack: every
+    w, h = 64, 40                                                                           # central packet's bundle meets > 160 boxes
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    pipe = api.StandardPipeline(ctx, w, h)
+    pipe.set_noise(0, n0)
+    pipe.set_noise(5, n5)
+    pipe.configure_gi(1 << 12, 512)
+    gi = O.GI(1 << 12, 512)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    for f in range(1, 3):
+        rnd = synth.frame_rand(4, f)
+        pipe.render(scene, cam, sky, passes | L.PASS_GI_ORDERED | L.PASS_COUNT_STATS, frame_index=f, rand=rnd)
+        g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f)
+        P.assert_parity(P.compare_gbuffers(g, P.read_hip_gbuffer(pipe)))
+        compare_gi(gi, pipe)
+    st = pipe.pass_stats(0)
+    assert st.hits > 100 and st.instances_tested > st.hits   # the stack is on screen and rays cross several of its boxes
