@@ -814,6 +814,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   uint32_t block = 512;
   if (const char* env = std::getenv("DUST_HIP_BLOCK")) block = uint32_t(std::strtoul(env, nullptr, 10));
+  block = std::min(512u, std::max(64u, block & ~63u));  // whole wavefronts, at most what the kernels are compiled for (__launch_bounds__)
   uint32_t bpc = 2;
   if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
   const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8 + 16;
