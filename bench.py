@@ -298,7 +298,7 @@ def main():
                                    "(all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of winning surfels), "
                                    "surfel pass replicated, RCCL gather of the bands to rank 0") if gi_bands else
                                   f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",
-                   "models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
+                   "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": desc.n_bricks(), "scene_build_s": round(t_load, 3),
                    "rays_per_step": {n: int(x.rays) for n, x in zip(names, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},
         "roofline": roofline,
