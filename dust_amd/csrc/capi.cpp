@@ -26,8 +26,8 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t);
-hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                          uint32_t* vals_out, uint32_t n, uint32_t key_bits, hipStream_t s);
+hipError_t sort_pairs_u16(void* tmp, size_t* tmp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, hipStream_t s);
 hipError_t launch_surfel(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
@@ -896,13 +896,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
     if (!std::getenv("DUST_HIP_NO_SURFEL_SORT")) {  // phase 0: Morton keys + radix sort -> gi.perm
-      b.gi.sort_keys = static_cast<uint32_t*>(p->gi_sort_keys.p);
+      b.gi.sort_keys = static_cast<uint16_t*>(p->gi_sort_keys.p);
       b.gi.sort_vals = static_cast<uint32_t*>(p->gi_sort_vals.p);
       if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
       HIP_TRY(dust::launch_surfel_keys(b, st));
       size_t tmp_bytes = p->gi_sort_tmp_bytes;
-      HIP_TRY(dust::sort_pairs_u32(p->gi_sort_tmp.p, &tmp_bytes, b.gi.sort_keys, static_cast<uint32_t*>(p->gi_sort_keys_out.p),
-                                   b.gi.sort_vals, static_cast<uint32_t*>(p->gi_perm.p), p->gi_pool_size, 32, st));
+      HIP_TRY(dust::sort_pairs_u16(p->gi_sort_tmp.p, &tmp_bytes, b.gi.sort_keys, static_cast<uint16_t*>(p->gi_sort_keys_out.p),
+                                   b.gi.sort_vals, static_cast<uint32_t*>(p->gi_perm.p), p->gi_pool_size, st));
       b.gi.perm = static_cast<const uint32_t*>(p->gi_perm.p);
     } else if (ctx->timing) {
       HIP_TRY(hipEventRecord(p->ev[6], st));
@@ -984,7 +984,7 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys, &p->gi_sort_vals, &p->gi_sort_keys_out, &p->gi_perm}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
   p->gi_sort_tmp_bytes = 0;
-  HIP_TRY(dust::sort_pairs_u32(nullptr, &p->gi_sort_tmp_bytes, nullptr, nullptr, nullptr, nullptr, surfel_pool_size, 32, p->ctx->stream));
+  HIP_TRY(dust::sort_pairs_u16(nullptr, &p->gi_sort_tmp_bytes, nullptr, nullptr, nullptr, nullptr, surfel_pool_size, p->ctx->stream));
   HIP_TRY(p->gi_sort_tmp.alloc(p->gi_sort_tmp_bytes));
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;

@@ -1572,8 +1572,8 @@ __global__ void k_gi_import(const FrameArgs) {
 
 // ==================================================================== surfel pass, phase 0: order the pool by position
 // Consecutive pool slots hold the hit points of unrelated final-gather rays, scattered over the whole scene: a packet of
-// 64 of them bounds nothing and walks a dozen instances per ray. Sorting the slots by a 30-bit Morton code of their
-// position (1024^3 cells over the scene's bounds; dead slots last) makes a packet's origins neighbours, so the packet culling works again.
+// 64 of them bounds nothing and walks a dozen instances per ray. Sorting the slots by a 16-bit Morton key of their
+// position (32 x 32 x 64 cells over the scene's bounds; dead slots last) makes a packet's origins neighbours, so the packet culling works again.
 // Only the grouping into packets changes: every surfel still computes and writes exactly what it did, at its own slot.
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
   v &= 1023u;
@@ -1587,7 +1587,7 @@ __global__ void k_surfel_keys(const FrameArgs) {
   ArgsRef a = launch_args();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.gi.pool_size; i += gridDim.x * blockDim.x) {
     const DevSurfel e = a.gi.pool[i];
-    uint32_t key = 0xFFFFFFFFu;  // dead slots sort last
+    uint32_t key = 0xFFFFu;  // dead slots sort last
     if (e.direction < 6u) {
       const float q[3] = {e.x, e.y, e.z};
       uint32_t c[3];
@@ -1597,9 +1597,12 @@ __global__ void k_surfel_keys(const FrameArgs) {
         const float f = fminf(fmaxf((q[k] - a.world_min[k]) * (1024.0f / span), 0.0f), 1023.0f);  // NaN -> 0
         c[k] = (uint32_t)f;
       }
-      key = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+      // the top 16 bits of the 30-bit Morton code: five full levels of the octree over the scene's bounds and one more
+      // split (see sort.hip for why the key is this narrow)
+      key = (spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2)) >> 14;
+      key = key < 0xFFFEu ? key : 0xFFFEu;
     }
-    a.gi.sort_keys[i] = key;
+    a.gi.sort_keys[i] = (uint16_t)key;
     a.gi.sort_vals[i] = i;
   }
 }
