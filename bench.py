@@ -83,7 +83,13 @@ def main():
 
     W, H = args.width, args.height
     Hband = H
-    stream = torch.cuda.current_stream().cuda_stream
+    # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
+    # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
+    # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
+    torch_stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
+    assert stream != 0
     if world > 1:
         # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
         # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1

@@ -143,7 +143,8 @@ typedef struct DustHipPipeline DustHipPipeline;
 typedef struct DustHipConfig {
   uint32_t struct_size;     /* sizeof(DustHipConfig) */
   int32_t device;           /* HIP device ordinal; -1 = current device */
-  void* stream;             /* hipStream_t to launch on; NULL = a stream owned by the context */
+  void* stream;             /* hipStream_t to launch on; NULL = a non-blocking stream owned by the context (note that the
+                               legacy default stream IS the null handle: to share a stream with other code, create one) */
   uint32_t lds_root_bytes;  /* LDS budget for staged root nodes per workgroup; 0 = default (64 KiB) */
   uint32_t flags;           /* DUST_HIP_CONTEXT_* */
 } DustHipConfig;
