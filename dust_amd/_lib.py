@@ -116,6 +116,7 @@ SYMBOLS = {
     "dust_vdb_bitmask_set": (None, [_u64p, C.c_size_t, C.c_int32]),
     "dust_vdb_bitmask_iter_set_bits": (C.c_size_t, [_u64p, C.c_size_t, _u32p, C.c_size_t]),
     "dust_vox_load": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "dust_vox_load_frame": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "dust_vox_scene_destroy": (None, [_P]),
     "dust_vox_scene_counts": (C.c_int, [_P, _u32p, _u32p]),
     "dust_vox_scene_model_info": (C.c_int, [_P, C.c_uint32, C.POINTER(VoxModelInfo)]),
@@ -126,6 +127,9 @@ SYMBOLS = {
                                          C.POINTER(_u8p), _u64p]),
     "dust_vox_free": (None, [_P]),
     "dust_png_load_array": (C.c_int, [_P, C.c_size_t, C.POINTER(PngInfo), C.POINTER(_u8p)]),
+    "dust_sky_dataset_create": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(_P)]),
+    "dust_sky_dataset_destroy": (None, [_P]),
+    "dust_sky_bake": (C.c_int, [_P, C.c_float, _f32p, _f32p, C.POINTER(Sky)]),
     "dust_hip_context_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "dust_hip_context_destroy": (None, [_P]),
     "dust_hip_sync": (C.c_int, [_P]),
@@ -152,6 +156,7 @@ SYMBOLS = {
     "dust_hip_tone_map": (C.c_int, [_P, C.POINTER(ToneMapParams)]),
     "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
+    "dust_hip_device_eval": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

@@ -129,11 +129,14 @@ def flatten_model(xyzi, size, palette256):
 class VoxScene:
     """What VoxLoader::load yields before upload (loader.rs:322-415): models, palette, instances."""
 
-    def __init__(self, data: bytes):
+    def __init__(self, data: bytes, frame: int = 0):
         self._lib = L.load()
         self._h = C.c_void_p()
         buf = np.frombuffer(data, np.uint8)
-        L.check(self._lib.dust_vox_load(_ptr(buf), buf.size, C.byref(self._h)))
+        if frame:  # animation frame: multi-frame nTRN / multi-model nSHP nodes (loader.rs:103-105,149-151 are unimplemented!())
+            L.check(self._lib.dust_vox_load_frame(_ptr(buf), buf.size, int(frame), C.byref(self._h)))
+        else:
+            L.check(self._lib.dust_vox_load(_ptr(buf), buf.size, C.byref(self._h)))
         nm, ni = C.c_uint32(), C.c_uint32()
         L.check(self._lib.dust_vox_scene_counts(self._h, C.byref(nm), C.byref(ni)))
         self.n_models, self.n_instances = nm.value, ni.value
@@ -220,6 +223,37 @@ def color_space_conversion(src=ACES_AP1, dst=BT709):
     return m.T.reshape(9).astype(np.float32)
 
 
+class SkyDataset:
+    """The Hosek-Wilkie tables Sunlight::bake reads (sky.rs:25-64), handed over as the bytes of the reference's
+    dataset.bin and datasetSolar.bin."""
+
+    def __init__(self, dataset_bin: bytes, dataset_solar_bin: bytes):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        a, b = np.frombuffer(dataset_bin, np.uint8), np.frombuffer(dataset_solar_bin, np.uint8)
+        L.check(self._lib.dust_sky_dataset_create(_ptr(a), a.size, _ptr(b), b.size, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_sky_dataset_destroy(self._h)
+            self._h = None
+
+
+class Sunlight:
+    """dust_render::Sunlight (crates/render/src/pipeline/sky.rs:6-23): turbidity, ground albedo, direction eye -> sun."""
+
+    def __init__(self, turbidity=1.0, albedo=(0.2, 0.2, 0.2), direction=(0.0, 0.80114365, -0.5984721)):
+        self.turbidity, self.albedo, self.direction = float(turbidity), tuple(albedo), tuple(direction)
+
+    def bake(self, dataset: SkyDataset):
+        """Sunlight::bake (sky.rs:90-132) -> the 56 floats of SkyModelState."""
+        out = L.Sky()
+        alb = (C.c_float * 3)(*self.albedo)
+        d = (C.c_float * 3)(*self.direction)
+        L.check(dataset._lib.dust_sky_bake(dataset._h, self.turbidity, alb, d, C.byref(out)))
+        return np.array(out.state, np.float32)
+
+
 class Context:
     def __init__(self, device=-1, timing=True, stream=None, lds_root_bytes=0):
         self._lib = L.load()
@@ -234,6 +268,14 @@ class Context:
 
     def sync(self):
         L.check(self._lib.dust_hip_sync(self._h))
+
+    def device_eval(self, fn, rows, out_words):
+        """dust_hip_device_eval: rows is an (n, in_words) array of 32-bit words (float32 or uint32); returns (n, out_words) uint32."""
+        rows = np.ascontiguousarray(rows)
+        assert rows.dtype.itemsize == 4 and rows.ndim == 2
+        out = np.zeros((rows.shape[0], out_words), np.uint32)
+        L.check(self._lib.dust_hip_device_eval(self._h, fn, _ptr(rows), rows.shape[1], _ptr(out), out_words, rows.shape[0]))
+        return out
 
 
 class Model:

@@ -16,6 +16,7 @@
 #include "vdb.hpp"
 #include "png.hpp"
 #include "vox.hpp"
+#include "sky.hpp"
 
 namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
@@ -33,6 +34,7 @@ hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
+hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s);
 }  // namespace dust
 
 namespace {
@@ -83,6 +85,13 @@ DustStatus hip_fail(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
   } while (0)
 
+// struct_size is the caller's sizeof of a versioned struct: at least the layout this build knows (a newer caller may pass
+// more; the known prefix is what is read)
+template <class T>
+bool struct_ok(const T* s) { return s->struct_size >= sizeof(T); }
+#define STRUCT_TRY(ptr, name) \
+  do { if (!struct_ok(ptr)) return fail(DUST_ERR_INVALID_ARGUMENT, name ".struct_size is smaller than this library's " name); } while (0)
+
 template <class F>
 DustStatus guarded(F&& f) {  // nothing may unwind across the C boundary
   try {
@@ -124,6 +133,7 @@ struct DustVdbTree { dust::vdb::Tree tree; DustVdbTree(const uint32_t* f, int n)
 struct DustVdbAccessor { dust::vdb::Tree::Accessor acc; explicit DustVdbAccessor(const dust::vdb::Tree& t) : acc(t) {} };
 struct DustVdbPool { dust::vdb::Pool pool; DustVdbPool(size_t b, unsigned c) : pool(b, c) {} };
 struct DustVoxScene { dust::vox::Scene scene; };
+struct DustSkyDataset { dust::sky::Dataset data; };
 
 struct DustHipContext {
   int device = 0;
@@ -160,8 +170,35 @@ struct DustHipScene {
   bool committed = false;
 };
 
+// DUST_HIP_* diagnostic switches, read ONCE when a pipeline is created (not per frame: a frame is ~0.3 ms of GPU time)
+struct Tuning {
+  uint32_t debug = 0;           // DUST_HIP_DEBUG ablation bits (FrameArgs::debug)
+  uint32_t block = 512;         // DUST_HIP_BLOCK: threads per workgroup, whole wavefronts, <= the kernels' launch bounds
+  uint32_t blocks_per_cu = 2;   // DUST_HIP_BLOCKS_PER_CU
+  uint32_t reserve_blocks = 0;  // DUST_HIP_RESERVE_BLOCKS: workgroup slots left free for another queue's kernels
+  bool no_fuse = false;         // DUST_HIP_NO_FUSE: primary and AO passes as two launches (the reference's shape)
+  bool no_gather_order = false; // DUST_HIP_NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
+  bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
+  static uint32_t num(const char* name, uint32_t dflt) {
+    const char* e = std::getenv(name);
+    return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
+  }
+  static Tuning from_environment() {
+    Tuning t;
+    t.debug = num("DUST_HIP_DEBUG", 0);
+    t.block = std::min(512u, std::max(64u, num("DUST_HIP_BLOCK", 512) & ~63u));
+    t.blocks_per_cu = std::max(1u, num("DUST_HIP_BLOCKS_PER_CU", 2));
+    t.reserve_blocks = num("DUST_HIP_RESERVE_BLOCKS", 0) & ~7u;  // whole rounds over the 8 XCDs
+    t.no_fuse = std::getenv("DUST_HIP_NO_FUSE") != nullptr;
+    t.no_gather_order = std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;
+    t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
+    return t;
+  }
+};
+
 struct DustHipPipeline {
   DustHipContext* ctx = nullptr;
+  Tuning tune;
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   void* bound[DUST_PLANE_COUNT] = {};  // caller-owned storage a plane was redirected to (dust_hip_pipeline_bind_plane), or null
@@ -384,6 +421,8 @@ DustStatus dust_vdb_accessor_create(const DustVdbTree* t, DustVdbAccessor** out)
 void dust_vdb_accessor_destroy(DustVdbAccessor* a) { delete a; }
 DustStatus dust_vdb_accessor_get(DustVdbAccessor* a, uint32_t x, uint32_t y, uint32_t z, int32_t* value) {
   if (!a || !value) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  const uint32_t e = 1u << a->acc.tree().extent_log2();
+  if (x >= e || y >= e || z >= e) return fail(DUST_ERR_INVALID_ARGUMENT, "coordinate outside the tree extent");
   *value = a->acc.get(x, y, z);
   return DUST_OK;
 }
@@ -392,9 +431,15 @@ DustStatus dust_vdb_pool_create(size_t item_size, uint32_t chunk_size_log2, Dust
   return guarded([&] { *out = new DustVdbPool(item_size, chunk_size_log2); return DUST_OK; });
 }
 void dust_vdb_pool_destroy(DustVdbPool* p) { delete p; }
-uint32_t dust_vdb_pool_alloc(DustVdbPool* p) { return p->pool.alloc(); }
-void dust_vdb_pool_free(DustVdbPool* p, uint32_t index) { p->pool.free(index); }
-size_t dust_vdb_pool_num_chunks(const DustVdbPool* p) { return p->pool.num_chunks(); }
+uint32_t dust_vdb_pool_alloc(DustVdbPool* p) {
+  if (!p) { (void)fail(DUST_ERR_INVALID_ARGUMENT, "null pool"); return 0xFFFFFFFFu; }
+  try { return p->pool.alloc(); } catch (...) { (void)fail(DUST_ERR_OUT_OF_MEMORY, "pool chunk allocation failed"); return 0xFFFFFFFFu; }
+}
+void dust_vdb_pool_free(DustVdbPool* p, uint32_t index) {
+  if (!p || !p->pool.owns(index)) { (void)fail(DUST_ERR_INVALID_ARGUMENT, "index was not allocated from this pool"); return; }
+  p->pool.free(index);
+}
+size_t dust_vdb_pool_num_chunks(const DustVdbPool* p) { return p ? p->pool.num_chunks() : 0; }
 void dust_vdb_bitmask_set(uint64_t* words, size_t index, int32_t value) { dust::vdb::bit_set(words, index, value != 0); }
 size_t dust_vdb_bitmask_iter_set_bits(const uint64_t* words, size_t n_words, uint32_t* out, size_t cap) {
   size_t n = 0;
@@ -406,15 +451,16 @@ size_t dust_vdb_bitmask_iter_set_bits(const uint64_t* words, size_t n_words, uin
 }
 
 // ===================================================================== vox
-DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** out) {
+DustStatus dust_vox_load_frame(const uint8_t* bytes, size_t n_bytes, uint32_t frame, DustVoxScene** out) {
   if (!bytes || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&] {
     std::unique_ptr<DustVoxScene> s(new DustVoxScene);
-    s->scene = dust::vox::load(bytes, n_bytes);
+    s->scene = dust::vox::load(bytes, n_bytes, frame);
     *out = s.release();
     return DUST_OK;
   });
 }
+DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** out) { return dust_vox_load_frame(bytes, n_bytes, 0, out); }
 void dust_vox_scene_destroy(DustVoxScene* s) { delete s; }
 DustStatus dust_png_load_array(const uint8_t* bytes, size_t n_bytes, DustPngInfo* info, uint8_t** texels) {
   if (!bytes || !info || !texels) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
@@ -489,9 +535,29 @@ DustStatus dust_vox_flatten_model(const uint8_t* xyzi, size_t n_voxels, const ui
 }
 void dust_vox_free(void* p) { std::free(p); }
 
+// ===================================================================== sky
+DustStatus dust_sky_dataset_create(const uint8_t* dataset, size_t n_dataset, const uint8_t* solar, size_t n_solar, DustSkyDataset** out) {
+  if (!dataset || !solar || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&] {
+    std::unique_ptr<DustSkyDataset> d(new DustSkyDataset);
+    if (!dust::sky::load_dataset(dataset, n_dataset, solar, n_solar, d->data))
+      return fail(DUST_ERR_INVALID_ARGUMENT, "sky tables must be 14400 bytes (dataset.bin) and 21672 bytes (datasetSolar.bin)");
+    *out = d.release();
+    return DUST_OK;
+  });
+}
+void dust_sky_dataset_destroy(DustSkyDataset* d) { delete d; }
+DustStatus dust_sky_bake(const DustSkyDataset* d, float turbidity, const float albedo[3], const float direction[3], DustHipSky* out) {
+  if (!d || !albedo || !direction || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (!dust::sky::bake(d->data, turbidity, albedo, direction, out->state))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "turbidity must lie in [1, 10] and the sun above the horizon (0 < direction.y <= 1)");
+  return DUST_OK;
+}
+
 // ===================================================================== device side
 DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** out) {
   if (!out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (cfg) STRUCT_TRY(cfg, "DustHipConfig");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return fail(DUST_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
@@ -510,7 +576,10 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024;
   if (const char* env = std::getenv("DUST_HIP_LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));
-  const size_t cap = c->max_lds > 8192 ? c->max_lds - 8192 : 0;
+  // what a 512-thread workgroup needs besides the staged roots: 8 candidate lists, the tile queue, and the static
+  // buckets of the profiling / debug builds (kernels.hip lds_bytes(), configure_kernels())
+  const size_t reserve = size_t(8) * dust::kMaxCand * 8 + 16 + 4096;
+  const size_t cap = c->max_lds > reserve ? c->max_lds - reserve : 0;
   if (c->lds_root_bytes > cap) c->lds_root_bytes = uint32_t(cap);
   HIP_TRY(dust::configure_kernels(c->max_lds));
   *out = c.release();
@@ -707,6 +776,7 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     HIP_TRY(hipSetDevice(ctx->device));
     std::unique_ptr<DustHipPipeline> p(new DustHipPipeline);
     p->ctx = ctx;
+    p->tune = Tuning::from_environment();
     p->width = width; p->height = height;
     const size_t px = size_t(width) * height;
     for (int i = 0; i < DUST_PLANE_COUNT; ++i) {
@@ -755,6 +825,7 @@ static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a)
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
                                  const DustHipSky* sky, const DustHipFrameParams* fp) {
   if (!p || !s || !cam || !sky || !fp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  STRUCT_TRY(fp, "DustHipFrameParams");
   if (p->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "pipeline and scene belong to different contexts");
   if (!s->committed) return fail(DUST_ERR_NOT_READY, "scene has uncommitted changes (call dust_hip_scene_commit)");
   const uint32_t need5 = DUST_PASS_AMBIENT_OCCLUSION | DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL;
@@ -810,24 +881,20 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (p->noise5.p) a.noise5 = static_cast<const uint8_t*>(p->noise5.p) + size_t(fp->frame_index % p->noise5_layers) * 128 * 128 * 4;  // noise.rs:50
   a.stats = static_cast<dust::DevStats*>(p->stats.p);
   a.accum_count = p->accum_count;
-  if (const char* env = std::getenv("DUST_HIP_DEBUG")) a.debug = uint32_t(std::strtoul(env, nullptr, 10));
+  const Tuning& tune = p->tune;
+  a.debug = tune.debug;
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
-  uint32_t block = 512;
-  if (const char* env = std::getenv("DUST_HIP_BLOCK")) block = uint32_t(std::strtoul(env, nullptr, 10));
-  block = std::min(512u, std::max(64u, block & ~63u));  // whole wavefronts, at most what the kernels are compiled for (__launch_bounds__)
-  uint32_t bpc = 2;
-  if (const char* env = std::getenv("DUST_HIP_BLOCKS_PER_CU")) bpc = std::max(1u, uint32_t(std::strtoul(env, nullptr, 10)));
+  const uint32_t block = tune.block;
+  uint32_t bpc = tune.blocks_per_cu;
   const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8 + 16;
+  if (lds > ctx->max_lds) return fail(DUST_ERR_INVALID_ARGUMENT, "staged roots and candidate lists exceed the device's LDS");
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
   // Workgroups per persistent launch: every slot of every CU, minus what the caller asks to be left free. The traversal
   // kernels hold all VGPRs of the SIMDs they run on, so a kernel of another queue (an RCCL send/receive moving the previous
   // frame to another GPU) can only become resident next to them where a workgroup slot was left empty.
   uint32_t resident = uint32_t(ctx->num_cus) * bpc;
-  if (const char* env = std::getenv("DUST_HIP_RESERVE_BLOCKS")) {
-    const uint32_t r = uint32_t(std::strtoul(env, nullptr, 10)) & ~7u;  // whole rounds over the 8 XCDs
-    if (r + 8u <= resident) resident -= r;
-  }
+  if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
   const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
@@ -842,7 +909,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.gi.sun_payload = static_cast<float*>(p->gi_sun_payload.p);
   if (count) HIP_TRY(hipMemsetAsync(p->stats.p, 0, 8 * sizeof(dust::DevStats), st));
   // primary + AO in one launch unless told otherwise (DUST_HIP_NO_FUSE=1 keeps the reference's one-launch-per-pass shape)
-  const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !std::getenv("DUST_HIP_NO_FUSE");
+  const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !tune.no_fuse;
   p->fused_last = fuse;
   if (fuse) {
     take_counters(p, 0, a);
@@ -875,7 +942,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
     dust::FrameArgs g = a;
     uint32_t ggrid = grid;
-    if (!std::getenv("DUST_HIP_NO_GATHER_ORDER")) {  // pre-pass: regroup the band's live pixels by ray-direction octant
+    if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
       const uint32_t otx = (p->width + 31) / 32, oty = (a.row_end - a.row_begin + 31) / 32;
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
@@ -895,7 +962,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     b.tiles_y = 1;
     take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
-    if (!std::getenv("DUST_HIP_NO_SURFEL_SORT")) {  // phase 0: Morton keys + radix sort -> gi.perm
+    if (!tune.no_surfel_sort) {  // phase 0: Morton keys + radix sort -> gi.perm
       b.gi.sort_keys = static_cast<uint16_t*>(p->gi_sort_keys.p);
       b.gi.sort_vals = static_cast<uint32_t*>(p->gi_sort_vals.p);
       if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
@@ -995,6 +1062,7 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
 }
 DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_rows, DustHipGiExchange* out) {
   if (!p || !out || padded_rows < p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "padded_rows must cover the frame");
+  STRUCT_TRY(out, "DustHipGiExchange");
   HIP_TRY(hipSetDevice(p->ctx->device));
   if (!p->gi_hash.p) {
     DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
@@ -1053,6 +1121,7 @@ DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* d
 }
 DustStatus dust_hip_tone_map(DustHipPipeline* p, const DustHipToneMapParams* tp) {
   if (!p || !tp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  STRUCT_TRY(tp, "DustHipToneMapParams");
   if (tp->transfer_function > 8) return fail(DUST_ERR_INVALID_ARGUMENT, "transfer function must be 0..8");
   if (!(tp->max_log_luminance > tp->min_log_luminance)) return fail(DUST_ERR_INVALID_ARGUMENT, "empty luminance range");
   HIP_TRY(hipSetDevice(p->ctx->device));
@@ -1072,6 +1141,22 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
   float* avg = reinterpret_cast<float*>(static_cast<uint32_t*>(p->exposure.p) + 256);
   if (set_to) HIP_TRY(hipMemcpy(avg, set_to, 4, hipMemcpyHostToDevice));
   if (avg_luminance) HIP_TRY(hipMemcpy(avg_luminance, avg, 4, hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
+                                uint32_t out_words, uint32_t n) {
+  static const uint32_t kWords[12][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}};
+  if (!ctx || !in || !out || fn >= 12) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
+  if (in_words != kWords[fn][0] || out_words != kWords[fn][1]) return fail(DUST_ERR_INVALID_ARGUMENT, "row width does not match the function");
+  if (n == 0) return DUST_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DeviceBuffer din, dout;
+  HIP_TRY(din.upload(in, size_t(n) * in_words * 4));
+  HIP_TRY(dout.alloc(size_t(n) * out_words * 4));
+  HIP_TRY(hipMemsetAsync(dout.p, 0, size_t(n) * out_words * 4, ctx->stream));
+  HIP_TRY(dust::launch_device_eval(fn, static_cast<const uint32_t*>(din.p), in_words, static_cast<uint32_t*>(dout.p), out_words, n, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out, dout.p, size_t(n) * out_words * 4, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {

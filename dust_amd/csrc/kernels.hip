@@ -153,11 +153,14 @@ __device__ __forceinline__ uint32_t unorm(float v, float scale) {
 __device__ __forceinline__ uint32_t pack_rgb10a2(float r, float g, float b, float a) {
   return unorm(r, 1023.0f) | (unorm(g, 1023.0f) << 10) | (unorm(b, 1023.0f) << 20) | (unorm(a, 3.0f) << 30);
 }
-__device__ __forceinline__ void store_half4(DUST_RW(uint16_t) plane, size_t pix, float a, float b, float c, float d) {
+__device__ __forceinline__ u32x2 pack_half4(float a, float b, float c, float d) {
   u32x2 v;
   v.x = (uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16);
   v.y = (uint32_t)f2h(c) | ((uint32_t)f2h(d) << 16);
-  __builtin_nontemporal_store(v, (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));  // written once, read by a later pass: do not displace the scene in L2
+  return v;
+}
+__device__ __forceinline__ void store_half4(DUST_RW(uint16_t) plane, size_t pix, float a, float b, float c, float d) {
+  __builtin_nontemporal_store(pack_half4(a, b, c, d), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));  // written once, read by a later pass: do not displace the scene in L2
 }
 
 // ------------------------------------------------------------------ headers/normal.glsl, nrd.glsl
@@ -200,12 +203,15 @@ __device__ __forceinline__ V3 nrd_unpack_normal(uint32_t p) {  // nrd.glsl:54-94
   n.y -= t * (gstep(0.0f, n.y) * 2.0f - 1.0f);
   return normalize3(n);
 }
-__device__ __forceinline__ void store_radiance(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {  // nrd.glsl:127-147
+__device__ __forceinline__ u32x2 pack_radiance(V3 r, float hitdist) {  // nrd.glsl:127-147, as four fp16 values
   if (hitdist != 0.0f) hitdist = fmaxf(hitdist, 1e-7f);
   float Y = (r.x * 0.25f + r.y * 0.5f) + r.z * 0.25f;
   float Co = (r.x * 0.5f + r.y * 0.0f) + r.z * -0.5f;
   float Cg = (r.x * -0.25f + r.y * 0.5f) + r.z * -0.25f;
-  store_half4(plane, pix, Y, Co, Cg, hitdist);
+  return pack_half4(Y, Co, Cg, hitdist);
+}
+__device__ __forceinline__ void store_radiance(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {
+  __builtin_nontemporal_store(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
 }
 __device__ __forceinline__ V3 decode_radiance(u32x2 v, float& w);
 __device__ __forceinline__ V3 load_radiance(DUST_RW(uint16_t) plane, size_t pix, float& w) {  // a G-buffer plane
@@ -1878,6 +1884,70 @@ hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t
   t.src = src; t.albedo = albedo; t.dst = dst; t.avg = avg; t.n_pixels = n_pixels; t.transfer_function = tf;
   for (int i = 0; i < 9; ++i) t.conv[i] = conv[i];
   hipLaunchKernelGGL(k_tone_map, dim3(2048), dim3(256), 0, s, t);
+  return hipGetLastError();
+}
+
+// ==================================================================== device function evaluation (dust_hip_device_eval)
+// Runs ONE of the device functions the traversal and shading kernels are made of on n independent inputs, so that the
+// arithmetic that otherwise only shows through whole frames can be checked against vectors directly (tests/golden/*.npz:
+// an independent restatement of the shaders). The functions are the same inlined bodies the frame kernels use.
+struct EvalArgs {
+  const uint32_t* in;
+  uint32_t* out;
+  uint32_t fn, in_words, out_words, n;
+};
+__global__ void __launch_bounds__(256) k_device_eval(EvalArgs e) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e.n) return;
+  const uint32_t* in = e.in + (size_t)i * e.in_words;
+  uint32_t* out = e.out + (size_t)i * e.out_words;
+  auto f = [&](int k) { return __uint_as_float(in[k]); };
+  auto put3 = [&](V3 v) { out[0] = __float_as_uint(v.x); out[1] = __float_as_uint(v.y); out[2] = __float_as_uint(v.z); };
+  switch (e.fn) {
+    case 0: case 1: case 2: {  // in: o[3] d[3] tmin mask_lo mask_hi -> reported, t, voxel
+      const V3 o = mk(f(0), f(1), f(2)), d = mk(f(3), f(4), f(5));
+      const V3 tc = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // trace_instance's reciprocals: hit.rint:88 `1.0 / dir`
+      float t = 0.0f;
+      uint32_t vox = 0;
+      bool rep;
+      if (e.fn == 0) rep = brick_intersect<0>(o, d, tc, in[7], in[8], f(6), t, vox);
+      else if (e.fn == 1) rep = brick_intersect<1>(o, d, tc, in[7], in[8], f(6), t, vox);
+      else rep = brick_intersect<2>(o, d, tc, in[7], in[8], f(6), t, vox);
+      out[0] = rep ? 1u : 0u; out[1] = rep ? __float_as_uint(t) : 0u; out[2] = rep ? vox : 0u;
+      break;
+    }
+    case 3: out[0] = logluv_encode(mk(f(0), f(1), f(2))); break;
+    case 4: put3(logluv_decode(in[0])); break;
+    case 5: out[0] = nrd_pack_normal(mk(f(0), f(1), f(2)), 1.0f, f(3)); break;
+    case 6: put3(nrd_unpack_normal(in[0])); break;
+    case 7: {  // in: rgb[3] hitdist -> the four fp16 values store_radiance writes
+      const u32x2 v = pack_radiance(mk(f(0), f(1), f(2)), f(3));
+      out[0] = v.x; out[1] = v.y;
+      break;
+    }
+    case 8: {
+      u32x2 v;
+      v.x = in[0]; v.y = in[1];
+      float w;
+      put3(decode_radiance(v, w));
+      out[3] = __float_as_uint(w);
+      break;
+    }
+    case 9: out[0] = pack_rgb10a2(f(0), f(1), f(2), f(3)); break;
+    case 10: {
+      const V3 c = cubed_normalize(mk(f(0), f(1), f(2)));
+      put3(c);
+      out[3] = normal2faceid(c);
+      break;
+    }
+    case 11: put3(rotate_by_normal(mk(f(0), f(1), f(2)), mk(f(3), f(4), f(5)))); break;
+    default: break;
+  }
+}
+hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s) {
+  EvalArgs e;
+  e.in = in; e.out = out; e.fn = fn; e.in_words = in_words; e.out_words = out_words; e.n = n;
+  hipLaunchKernelGGL(k_device_eval, dim3((n + 255) / 256), dim3(256), 0, s, e);
   return hipGetLastError();
 }
 

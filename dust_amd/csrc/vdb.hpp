@@ -59,6 +59,7 @@ class Pool {
   const uint64_t* item(uint32_t id) const { return const_cast<Pool*>(this)->item(id); }
   size_t num_chunks() const { return chunks_.size(); }
   uint32_t count() const { return count_; }
+  bool owns(uint32_t id) const { return id < top_; }  // handed out by alloc() at some point (the C ABI's range check)
 
  private:
   static constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -98,6 +99,7 @@ class Tree {
    public:
     explicit Accessor(const Tree& t) : tree_(t) { last_[0] = last_[1] = last_[2] = 0xFFFFFFFFu; }
     int get(uint32_t x, uint32_t y, uint32_t z);
+    const Tree& tree() const { return tree_; }
    private:
     const Tree& tree_;
     uint32_t path_[kMaxLevels] = {};

@@ -60,18 +60,35 @@ struct Rotation {  // the "_r" byte of an nTRN frame: a signed permutation matri
   }
 };
 
+struct Keyframe {  // one frame dictionary of an nTRN node: {_t, _r, _f}
+  uint32_t frame = 0;  // "_f": the animation frame this key applies from (0 when absent)
+  int32_t t[3] = {0, 0, 0};
+  Rotation rot = Rotation::identity();
+};
+struct ShapeModel {  // one (model id, attributes) pair of an nSHP node; "_f": the frame the model is shown from
+  uint32_t model = 0, frame = 0;
+};
 struct Node {
   enum Kind { kNone, kTransform, kGroup, kShape } kind = kNone;
   // transform
   uint32_t child = 0;
-  uint32_t n_frames = 0;
-  int32_t t[3] = {0, 0, 0};
-  Rotation rot = Rotation::identity();
+  std::vector<Keyframe> frames;
   // group
   std::vector<uint32_t> children;
   // shape
-  std::vector<uint32_t> model_ids;
+  std::vector<ShapeModel> models;
 };
+// The entry in force at animation frame `frame`: the one with the largest "_f" <= frame, or the first when the
+// animation starts later. (MagicaVoxel holds a key until the next one.) The reference stops at unimplemented!()
+// for nodes with more than one entry (loader.rs:103-105,149-151); with one entry this is that entry, whatever the frame.
+template <class T>
+const T& in_force(const std::vector<T>& v, uint32_t frame) {
+  const T* best = &v[0];
+  bool found = v[0].frame <= frame;
+  for (const T& e : v)
+    if (e.frame <= frame && (!found || e.frame >= best->frame)) { best = &e; found = true; }
+  return *best;
+}
 
 // 4x4 affine, row-major 3x4 kept as doubles while composing
 struct Affine {
@@ -128,17 +145,22 @@ Affine to_transform(const int32_t t[3], const Rotation& rot, const uint32_t size
 struct Walker {
   const std::map<uint32_t, Node>& nodes;
   Scene& scene;
+  uint32_t frame = 0;    // animation frame the scene is instantiated at
+  uint32_t visits = 0;   // a file is untrusted input: a graph whose groups list the same child over and over is a DAG that
+                         // unfolds exponentially, so the walk as a whole is bounded, not just its depth
   // traverse_recursive (loader.rs:87-176)
   void walk(uint32_t id, const Affine& parent, int32_t tx, int32_t ty, int32_t tz, const Rotation& rot, int depth) {
     if (depth > 256) throw ParseError{"scene graph too deep"};
+    if (++visits > (1u << 20)) throw ParseError{"scene graph unfolds into more than 2^20 nodes"};
     auto it = nodes.find(id);
     if (it == nodes.end()) throw ParseError{"scene graph references a missing node"};
     const Node& n = it->second;
     switch (n.kind) {
       case Node::kTransform: {
-        if (n.n_frames != 1) throw ParseError{"Multiple frame in transform node", true};  // loader.rs:103-105
+        if (n.frames.empty()) throw ParseError{"transform node without a frame"};
+        const Keyframe& k = in_force(n.frames, frame);  // one frame: loader.rs:107-116; several: loader.rs:103-105 is unimplemented!()
         // translation accumulates, rotation is replaced (loader.rs:117-121)
-        walk(n.child, parent, tx + n.t[0], ty + n.t[1], tz + n.t[2], n.rot, depth + 1);
+        walk(n.child, parent, tx + k.t[0], ty + k.t[1], tz + k.t[2], k.rot, depth + 1);
         break;
       }
       case Node::kGroup: {
@@ -149,8 +171,9 @@ struct Walker {
         break;
       }
       case Node::kShape: {
-        if (n.model_ids.size() != 1) throw ParseError{"Multiple shape models in Shape node", true};  // loader.rs:149-151
-        const uint32_t mid = n.model_ids[0];
+        if (n.models.empty()) throw ParseError{"shape node without a model"};
+        const uint32_t mid = in_force(n.models, frame).model;  // one model: loader.rs:152; several: loader.rs:149-151 is unimplemented!()
+        if (scene.instances.size() >= 65535) throw ParseError{"more than 65535 instances"};
         if (mid >= scene.models.size()) throw ParseError{"shape references a missing model"};
         Model& m = scene.models[mid];
         if (m.xyzi.empty()) return;  // loader.rs:154-156
@@ -267,7 +290,7 @@ void flatten_model(const uint8_t* xyzi, size_t n_voxels, const uint32_t size[3],
   });
 }
 
-Scene load(const uint8_t* bytes, size_t n) {
+Scene load(const uint8_t* bytes, size_t n, uint32_t frame) {
   Reader rd{bytes, n};
   if (!rd.has(8) || std::memcmp(bytes, "VOX ", 4) != 0) throw ParseError{"Not a valid MagicaVoxel .vox file"};
   rd.pos = 4;
@@ -303,7 +326,10 @@ Scene load(const uint8_t* bytes, size_t n) {
       Model m;
       std::memcpy(m.size, pending_size, sizeof(m.size));
       m.xyzi.assign(c.p + c.pos, c.p + c.pos + size_t(k) * 4);
-      for (size_t v = 0; v < k; ++v) m.xyzi[v * 4 + 3] = static_cast<uint8_t>(m.xyzi[v * 4 + 3] - 1);  // dot_vox: i = index - 1
+      for (size_t v = 0; v < k; ++v) {  // dot_vox: i = index.saturating_sub(1) (file indices are 1-based; 0 is not a colour)
+        const uint8_t ci = m.xyzi[v * 4 + 3];
+        m.xyzi[v * 4 + 3] = static_cast<uint8_t>(ci ? ci - 1 : 0);
+      }
       scene.models.push_back(std::move(m));
       have_size = false;
     } else if (!std::strcmp(id, "RGBA")) {
@@ -318,18 +344,22 @@ Scene load(const uint8_t* bytes, size_t n) {
       nd.child = c.u32();
       c.i32();  // reserved
       c.i32();  // layer
-      nd.n_frames = c.u32();
-      for (uint32_t f = 0; f < nd.n_frames; ++f) {
+      const uint32_t n_frames = c.u32();
+      if (n_frames > content / 4) throw ParseError{"nTRN frame count exceeds the chunk"};
+      for (uint32_t f = 0; f < n_frames; ++f) {
         auto d = c.dict();
-        if (f != 0) continue;
+        Keyframe k;
         auto t = d.find("_t");
         if (t != d.end()) {
           long a = 0, b = 0, e = 0;
           if (std::sscanf(t->second.c_str(), "%ld %ld %ld", &a, &b, &e) != 3) throw ParseError{"bad _t in nTRN frame"};
-          nd.t[0] = int32_t(a); nd.t[1] = int32_t(b); nd.t[2] = int32_t(e);
+          k.t[0] = int32_t(a); k.t[1] = int32_t(b); k.t[2] = int32_t(e);
         }
         auto r = d.find("_r");
-        if (r != d.end()) nd.rot = Rotation::from_byte(static_cast<uint8_t>(std::strtoul(r->second.c_str(), nullptr, 10)));
+        if (r != d.end()) k.rot = Rotation::from_byte(static_cast<uint8_t>(std::strtoul(r->second.c_str(), nullptr, 10)));
+        auto fi = d.find("_f");
+        if (fi != d.end()) k.frame = uint32_t(std::strtoul(fi->second.c_str(), nullptr, 10));
+        nd.frames.push_back(k);
       }
       nodes[node_id] = std::move(nd);
     } else if (!std::strcmp(id, "nGRP")) {
@@ -338,6 +368,7 @@ Scene load(const uint8_t* bytes, size_t n) {
       const uint32_t node_id = c.u32();
       c.dict();
       const uint32_t k = c.u32();
+      if (k > content / 4) throw ParseError{"nGRP child count exceeds the chunk"};
       for (uint32_t i = 0; i < k; ++i) nd.children.push_back(c.u32());
       nodes[node_id] = std::move(nd);
     } else if (!std::strcmp(id, "nSHP")) {
@@ -346,9 +377,14 @@ Scene load(const uint8_t* bytes, size_t n) {
       const uint32_t node_id = c.u32();
       c.dict();
       const uint32_t k = c.u32();
+      if (k > content / 8) throw ParseError{"nSHP model count exceeds the chunk"};
       for (uint32_t i = 0; i < k; ++i) {
-        nd.model_ids.push_back(c.u32());
-        c.dict();
+        ShapeModel sm;
+        sm.model = c.u32();
+        auto d = c.dict();
+        auto fi = d.find("_f");
+        if (fi != d.end()) sm.frame = uint32_t(std::strtoul(fi->second.c_str(), nullptr, 10));
+        nd.models.push_back(sm);
       }
       nodes[node_id] = std::move(nd);
     }  // PACK, MATL, LAYR, rOBJ, rCAM, NOTE, IMAP ...: not consumed by the reference loader
@@ -367,7 +403,7 @@ Scene load(const uint8_t* bytes, size_t n) {
       scene.models[0].used = true;
     }
   } else {
-    Walker w{nodes, scene};
+    Walker w{nodes, scene, frame};
     w.walk(0, Affine::identity(), 0, 0, 0, Rotation::identity(), 0);
   }
 

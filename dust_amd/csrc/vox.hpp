@@ -32,7 +32,9 @@ struct Scene {
 
 // Throws ParseError. Builds blocks/materials for every model an instance references,
 // one thread per model as the reference does with rayon (loader.rs:360-372).
-Scene load(const uint8_t* bytes, size_t n);
+// frame: the animation frame at which multi-frame transform nodes and multi-model shape nodes are instantiated (the
+// reference stops at unimplemented!() for both, loader.rs:103-105,149-151; files without animation ignore it).
+Scene load(const uint8_t* bytes, size_t n, uint32_t frame = 0);
 
 // load_model + from_tree for one model (hierarchy!(4,2,2), crates/vox/src/lib.rs:19-20).
 void flatten_model(const uint8_t* xyzi, size_t n_voxels, const uint32_t size[3], const uint8_t* palette_rgba256,

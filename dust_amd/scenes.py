@@ -11,10 +11,37 @@ from . import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_SWEEP = None
+
+
+def _sweep():
+    global _SWEEP
+    if _SWEEP is None:
+        with open(os.path.join(ROOT, "dust_amd", "data", "sky_sweep.json")) as f:
+            _SWEEP = json.load(f)
+    return _SWEEP
+
+
 def sky_state(name="default"):
-    """56 baked sky floats (pipeline/sky.rs:78-85) from tests/golden/sky_states.json (made by tests/golden/make_sky_fixtures.py)."""
-    with open(os.path.join(ROOT, "tests", "golden", "sky_states.json")) as f:
-        return np.asarray(json.load(f)[name]["state"], np.float32)
+    """56 baked sky floats (pipeline/sky.rs:78-85) of Sunlight::default(), from the packaged sweep (dust_amd/data/sky_sweep.json,
+    made by tests/golden/make_sky_fixtures.py from the reference's tables). Hosts that hold the tables bake any sun exactly
+    with api.Sunlight(...).bake(api.SkyDataset(...)) (dust_sky_bake)."""
+    if name != "default":
+        raise KeyError(f"packaged sky states: 'default' and sky_sweep(); not {name!r}")
+    return np.asarray(_sweep()["default"]["state"], np.float32)
+
+
+def sky_sweep(turbidity, elevation_deg, azimuth_deg=180.0):
+    """Pre-baked state for hosts without the model's tables: the swept state nearest in (turbidity, solar elevation), with
+    the sun placed at `azimuth_deg` (0 = +z, 90 = +x; the default sun stands at 180). The baked coefficients depend on the
+    direction only through its elevation, so the state is exact for the swept elevation it snaps to (ground albedo 0.2)."""
+    sw = _sweep()
+    ti = int(np.argmin(np.abs(np.asarray(sw["turbidity"], float) - float(turbidity))))
+    ei = int(np.argmin(np.abs(np.asarray(sw["elevation_deg"], float) - float(elevation_deg))))
+    st = np.asarray(sw["states"][ti][ei], np.float32).copy()
+    e, a = np.deg2rad(float(sw["elevation_deg"][ei])), np.deg2rad(float(azimuth_deg))
+    st[48:51] = np.array([np.cos(e) * np.sin(a), min(1.0, np.sin(e)), np.cos(e) * np.cos(a)], np.float32)
+    return st
 
 
 class SceneDesc:

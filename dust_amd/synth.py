@@ -33,11 +33,14 @@ def _dict(d: dict) -> bytes:
     return out
 
 
-def write_vox(models, instances, palette=None, groups=None, scene_graph=True) -> bytes:
+def write_vox(models, instances, palette=None, groups=None, scene_graph=True, anim=None) -> bytes:
     """models: list of (size_xyz, xyzi uint8[n,4] with 1-based colour index as stored in files).
     instances: list of (model_id, (tx,ty,tz), rotation_byte) in file axes.
     groups: optional list of (translation, rotation_byte, [instance indices]) wrapping some instances in an nGRP.
+    anim: optional {instance index: {"frames": [(frame, (tx,ty,tz), rotation_byte), ...], "models": [(frame, model_id), ...]}}:
+          MagicaVoxel animation -- several keyframes in the instance's nTRN and / or several models in its nSHP ("_f" attributes).
     """
+    anim = anim or {}
     body = b""
     for size, xyzi in models:
         xyzi = np.ascontiguousarray(xyzi, np.uint8).reshape(-1, 4)
@@ -52,16 +55,24 @@ def write_vox(models, instances, palette=None, groups=None, scene_graph=True) ->
             next_id[0] += 1
             return i
 
-        def trn(node_id, child, t, r):
-            frame = {}
-            if r != ROT_IDENTITY:
-                frame["_r"] = str(int(r))
-            if tuple(t) != (0, 0, 0):
-                frame["_t"] = "%d %d %d" % tuple(int(v) for v in t)
-            return _chunk(b"nTRN", struct.pack("<I", node_id) + _dict({}) + struct.pack("<IiiI", child, -1, 0, 1) + _dict(frame))
+        def trn(node_id, child, t, r, keys=None):
+            frames = b""
+            keys = keys or [(None, t, r)]
+            for f, kt, kr in keys:
+                frame = {}
+                if kr != ROT_IDENTITY:
+                    frame["_r"] = str(int(kr))
+                if tuple(kt) != (0, 0, 0):
+                    frame["_t"] = "%d %d %d" % tuple(int(v) for v in kt)
+                if f is not None:
+                    frame["_f"] = str(int(f))
+                frames += _dict(frame)
+            return _chunk(b"nTRN", struct.pack("<I", node_id) + _dict({}) + struct.pack("<IiiI", child, -1, 0, len(keys)) + frames)
 
-        def shp(node_id, model):
-            return _chunk(b"nSHP", struct.pack("<I", node_id) + _dict({}) + struct.pack("<I", 1) + struct.pack("<I", model) + _dict({}))
+        def shp(node_id, model, keys=None):
+            keys = keys or [(None, model)]
+            body_ = b"".join(struct.pack("<I", m) + _dict({} if f is None else {"_f": str(int(f))}) for f, m in keys)
+            return _chunk(b"nSHP", struct.pack("<I", node_id) + _dict({}) + struct.pack("<I", len(keys)) + body_)
 
         def grp(node_id, children):
             return _chunk(b"nGRP", struct.pack("<I", node_id) + _dict({}) + struct.pack("<I", len(children)) +
@@ -77,7 +88,7 @@ def write_vox(models, instances, palette=None, groups=None, scene_graph=True) ->
                 grouped.add(idx)
                 mid, t, r = instances[idx]
                 a, b = new_id(), new_id()
-                out_nodes += trn(a, b, t, r) + shp(b, mid)
+                out_nodes += trn(a, b, t, r, anim.get(idx, {}).get("frames")) + shp(b, mid, anim.get(idx, {}).get("models"))
                 kids.append(a)
             out_nodes += trn(g_trn, g_grp, gt, gr) + grp(g_grp, kids)
             root_children.append(g_trn)
@@ -85,7 +96,7 @@ def write_vox(models, instances, palette=None, groups=None, scene_graph=True) ->
             if idx in grouped:
                 continue
             a, b = new_id(), new_id()
-            out_nodes += trn(a, b, t, r) + shp(b, mid)
+            out_nodes += trn(a, b, t, r, anim.get(idx, {}).get("frames")) + shp(b, mid, anim.get(idx, {}).get("models"))
             root_children.append(a)
         body += trn(0, 1, (0, 0, 0), ROT_IDENTITY) + grp(1, root_children) + out_nodes
     if palette is not None:

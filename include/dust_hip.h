@@ -27,7 +27,7 @@ typedef enum DustStatus {
   DUST_ERR_HIP = -3,            /* a HIP call or kernel launch failed; see dust_hip_last_error() */
   DUST_ERR_OUT_OF_MEMORY = -4,
   DUST_ERR_PARSE = -5,          /* VoxLoadingError::ParseError (crates/vox/src/loader.rs:311-317) */
-  DUST_ERR_UNSUPPORTED = -6,    /* the reference's unimplemented!() paths (loader.rs:103-105,149-151) */
+  DUST_ERR_UNSUPPORTED = -6,    /* paths the reference leaves todo!() (node/internal.rs:121-124) / image kinds its loader rejects */
   DUST_ERR_NOT_READY = -7       /* StandardPipeline::render returning None (standard.rs:254-266) */
 } DustStatus;
 
@@ -103,6 +103,11 @@ typedef struct DustVoxInstance {
 } DustVoxInstance;
 
 DustStatus dust_vox_load(const uint8_t* bytes, size_t n_bytes, DustVoxScene** out);
+/* The same at animation frame `frame`. Where the reference stops at unimplemented!() -- transform nodes with several
+ * frames (loader.rs:103-105) and shape nodes with several models (loader.rs:149-151), i.e. MagicaVoxel animations -- the
+ * entry in force at `frame` is used: the one with the largest "_f" attribute <= frame, or the first one before the
+ * animation starts. dust_vox_load is frame 0; files without animation give the same scene at every frame. */
+DustStatus dust_vox_load_frame(const uint8_t* bytes, size_t n_bytes, uint32_t frame, DustVoxScene** out);
 void dust_vox_scene_destroy(DustVoxScene*);
 DustStatus dust_vox_scene_counts(const DustVoxScene*, uint32_t* n_models, uint32_t* n_instances);
 DustStatus dust_vox_scene_model_info(const DustVoxScene*, uint32_t model, DustVoxModelInfo* out);
@@ -131,6 +136,21 @@ typedef struct DustPngInfo {
   uint32_t bytes_per_channel;  /* 1 or 2 */
 } DustPngInfo;
 DustStatus dust_png_load_array(const uint8_t* bytes, size_t n_bytes, DustPngInfo* info, uint8_t** texels /* dust_vox_free */);
+
+/* ===================================================================== sky bake (host)
+ * Sunlight::bake (crates/render/src/pipeline/sky.rs:90-268): Hosek-Wilkie sky + solar-disc state for a sun direction,
+ * turbidity (1..10) and ground albedo -- the 56 floats DustHipSky carries to the shaders. The reference embeds the
+ * model's tables with include_bytes! (sky.rs:34-63: dataset.bin, 1200 x vec3 = 14400 bytes; datasetSolar.bin,
+ * 1806 x vec3 = 21672 bytes); this library does not contain them: the host passes the two files' bytes once.
+ * (A host without the tables can use the pre-baked sweep under dust_amd/data/, see INTEGRATION.md.) */
+typedef struct DustSkyDataset DustSkyDataset;
+/* SkyModelState as Sunlight::bake() produces it, 56 floats (pipeline/sky.rs:66-132; layout.playout:35-51) */
+typedef struct DustHipSky { float state[56]; } DustHipSky;
+DustStatus dust_sky_dataset_create(const uint8_t* dataset_bin, size_t n_dataset, const uint8_t* dataset_solar_bin, size_t n_solar,
+                                   DustSkyDataset** out);
+void dust_sky_dataset_destroy(DustSkyDataset*);
+/* direction: unit vector from eye to sun, y up, y > 0; albedo: ground albedo per XYZ channel (Sunlight::albedo) */
+DustStatus dust_sky_bake(const DustSkyDataset*, float turbidity, const float albedo[3], const float direction[3], DustHipSky* out);
 
 /* ===================================================================== device side
  * Replaces the Vulkan objects the render plugin owns (crates/render/src/lib.rs:58-134): device,
@@ -185,8 +205,6 @@ typedef struct DustHipCamera {
   float tan_half_fov, far_, near_;
 } DustHipCamera;
 
-/* SkyModelState as Sunlight::bake() produces it, 56 floats (pipeline/sky.rs:66-132; layout.playout:35-51) */
-typedef struct DustHipSky { float state[56]; } DustHipSky;
 
 /* GBuffer planes (standard.rs:881-917; formats :974-1050) */
 typedef enum DustHipPlane {
@@ -304,6 +322,27 @@ DustStatus dust_hip_tone_map(DustHipPipeline*, const DustHipToneMapParams*);
 DustStatus dust_hip_pipeline_exposure(DustHipPipeline*, float* avg_luminance, const float* set_to);
 /* zero every plane and the accumulation count */
 DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
+
+/* Device function evaluation: runs ONE of the device functions the traversal / shading kernels are built from on n
+ * independent inputs (host arrays in, host arrays out, synchronous). The reference has no counterpart -- its shaders are
+ * only reachable through vkCmdTraceRaysKHR -- this is how vectors of (ray, brick mask) -> (t, voxel) pairs and codec
+ * round trips are checked against the device code directly (tests/golden/). Each input / output is a row of 32-bit
+ * words (floats by bit pattern):
+ *   fn  function (reference)                                          in words                          out words
+ *   0   primary/hit.rint dda()            :43-131                      o[3] d[3] tmin mask_lo mask_hi    reported t voxel
+ *   1   final_gather/ambient_occlusion.rint dda() :46-134              (same)                            (same; voxel 0xFF = threshold hit)
+ *   2   final_gather/rough.rint dda()     :42-59                       (same)                            (same)
+ *   3   EncodeRGBToLogLuv  (spatial_hash.glsl:28-60)                   rgb[3]                            packed
+ *   4   DecodeLogLuvToRGB  (spatial_hash.glsl:64-93)                   packed                            rgb[3]
+ *   5   NRD_FrontEnd_PackNormalAndRoughness -> A2B10G10R10 (nrd.glsl:25-52), roughness 1   n[3] materialID   texel
+ *   6   NRD_FrontEnd_UnpackNormalAndRoughness (nrd.glsl:54-94)         texel                             n[3]
+ *   7   REBLUR_FrontEnd_PackRadianceAndNormHitDist -> RGBA16F (nrd.glsl:127-147)   rgb[3] hitdist         2 words (4 halves)
+ *   8   REBLUR_BackEnd_UnpackRadianceAndNormHitDist (nrd.glsl:107-125) 2 words                           rgb[3] hitdist
+ *   9   float4 -> A2B10G10R10_UNORM                                    v[4]                              texel
+ *   10  CubedNormalize + normal2FaceID (normal.glsl:9-18,39-43)        d[3]                              n[3] face
+ *   11  rotateVectorByNormal (normal.glsl:31-37)                       n[3] target[3]                    v[3] */
+DustStatus dust_hip_device_eval(DustHipContext*, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
+                                uint32_t out_words, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -10,9 +10,18 @@ import oracle_lib as O
 from dust_amd import _lib as L
 from dust_amd import api, synth
 
-from dust_amd.scenes import SceneDesc, camera_for, hip_scene, sky_state  # noqa: F401  (oracle-free, shared with bench.py)
+from dust_amd.scenes import SceneDesc, camera_for, hip_scene  # noqa: F401  (oracle-free, shared with bench.py)
+from dust_amd import scenes as _scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sky_state(name="default"):
+    """The packaged default sun, or one of the named test suns of tests/golden/sky_states.json (make_sky_fixtures.py)."""
+    if name == "default":
+        return _scenes.sky_state()
+    with open(os.path.join(ROOT, "tests", "golden", "sky_states.json")) as f:
+        return np.asarray(json.load(f)[name]["state"], np.float32)
 
 
 def random_model(rng, size=(48, 40, 56), fill=0.08, blobs=6):
@@ -141,6 +150,70 @@ def assert_parity(res):
         assert res.get(k, 0) == 0, f"{k}: {res[k]} pixels differ ({res})"
     for k in ("denoised_rel_l2", "illuminance_rel_l2"):
         assert res.get(k, 0.0) <= 1e-3, f"{k} = {res[k]} exceeds 1e-3 ({res})"  # north_star tolerance
+
+
+def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n5, seed=3):
+    """SURVEY 8e option i with the collectives done by hand: `world` pipelines on one GPU play the ranks (row bands for the
+    pixel passes, the exchange of dust_hip_pipeline_gi_exchange, replicated ordered surfel pass); asserts that every rank's
+    spatial hash, surfel pool and own illuminance band equal the single-pipeline run bit for bit. Returns the reference hash."""
+    from dust_amd import sharding
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def d2h(ptr, n):
+        out = np.empty(n, np.int32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) == 0
+        return out
+
+    def h2d(ptr, arr):
+        arr = np.ascontiguousarray(arr, np.int32)
+        assert hip.hipMemcpy(C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+
+    def make():
+        p = api.StandardPipeline(ctx, w, h)
+        p.set_noise(0, n0)
+        p.set_noise(5, n5)
+        return p
+
+    ref, ranks = make(), [make() for _ in range(world)]
+    per = sharding.gi_band_rows(world, h)
+    bands = [(min(h, r * per), min(h, (r + 1) * per)) for r in range(world)]
+    exs = [p.gi_exchange(world * per) for p in ranks]
+    pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER
+    for frame in range(1, frames + 1):
+        rnd = synth.frame_rand(seed, frame)
+        ref.render(scene, cam, sky, pix | L.PASS_SURFEL | L.PASS_GI_ORDERED, frame, rnd)
+        for r, p in enumerate(ranks):
+            if bands[r][0] < bands[r][1]:
+                p.render(scene, cam, sky, pix | L.PASS_GI_SHARDED, frame, rnd, rows=bands[r])
+        ctx.sync()
+        owner = np.max([d2h(e.slot_owner, e.pool_size) for e in exs], axis=0)                 # all-reduce MAX
+        touched = np.zeros(world * per * w, np.int32)
+        for r, e in enumerate(exs):                                                           # all-gather of the bands
+            touched[r * per * w:(r + 1) * per * w] = d2h(e.touched, world * per * w)[r * per * w:(r + 1) * per * w]
+        for e in exs:
+            h2d(e.slot_owner, owner)
+            h2d(e.touched, touched)
+        for r, p in enumerate(ranks):
+            if bands[r][0] < bands[r][1]:
+                p.gi_export(*bands[r])
+        ctx.sync()
+        merged = np.sum([d2h(e.merged, e.pool_size * 4) for e in exs], axis=0, dtype=np.int64).astype(np.int32)  # all-reduce SUM
+        for r, (p, e) in enumerate(zip(ranks, exs)):
+            h2d(e.merged, merged)
+            if bands[r][0] < bands[r][1]:
+                p.gi_import(bands[r][0], bands[r][1], frame)
+            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
+        ctx.sync()
+    h_ref, s_ref = ref.read_gi()
+    ill_ref = ref.read_plane(L.PLANE_ILLUMINANCE)
+    for r, p in enumerate(ranks):
+        hh, sp = p.read_gi()
+        assert np.array_equal(hh, h_ref), f"rank {r}: hash differs"
+        assert np.array_equal(sp.view(np.uint32), s_ref.view(np.uint32)), f"rank {r}: surfel pool differs"
+        ill = p.read_plane(L.PLANE_ILLUMINANCE)
+        assert np.array_equal(ill[bands[r][0]:bands[r][1]], ill_ref[bands[r][0]:bands[r][1]]), f"rank {r}: band differs"
+    return h_ref
 
 
 def run_smoke():

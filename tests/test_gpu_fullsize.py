@@ -84,61 +84,6 @@ def test_full_size_bands_and_fusion(castle, monkeypatch):
 def test_full_size_sharded_gi_equals_single_device(castle):
     """Default hash capacity (32 Mi entries) and surfel pool (345 600): two ranks on row bands, collectives by hand."""
     ctx, desc, scene, _ = castle
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-
-    def d2h(ptr, n):
-        out = np.empty(n, np.int32)
-        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes, 2) == 0
-        return out
-
-    def h2d(ptr, arr):
-        arr = np.ascontiguousarray(arr, np.int32)
-        assert hip.hipMemcpy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, 1) == 0
-
-    n0, n5 = synth.stbn_scalar(), synth.stbn_unitvec3_cosine()
-    cam, sky = P.camera_for(EYE), P.sky_state()
-
-    def make():
-        p = api.StandardPipeline(ctx, W, H)
-        p.set_noise(0, n0)
-        p.set_noise(5, n5)
-        return p
-
-    world = 2
-    ref, ranks = make(), [make() for _ in range(world)]
-    per = sharding.gi_band_rows(world, H)
-    bands = [(min(H, r * per), min(H, (r + 1) * per)) for r in range(world)]
-    exs = [p.gi_exchange(world * per) for p in ranks]
-    pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER
-    for frame in (1, 2):
-        rnd = synth.frame_rand(3, frame)
-        ref.render(scene, cam, sky, pix | L.PASS_SURFEL | L.PASS_GI_ORDERED, frame, rnd)
-        for r, p in enumerate(ranks):
-            p.render(scene, cam, sky, pix | L.PASS_GI_SHARDED, frame, rnd, rows=bands[r])
-        ctx.sync()
-        owner = np.max([d2h(e.slot_owner, e.pool_size) for e in exs], axis=0)
-        touched = np.zeros(world * per * W, np.int32)
-        for r, e in enumerate(exs):
-            touched[r * per * W:(r + 1) * per * W] = d2h(e.touched, world * per * W)[r * per * W:(r + 1) * per * W]
-        for e in exs:
-            h2d(e.slot_owner, owner)
-            h2d(e.touched, touched)
-        for r, p in enumerate(ranks):
-            p.gi_export(*bands[r])
-        ctx.sync()
-        merged = np.sum([d2h(e.merged, e.pool_size * 4) for e in exs], axis=0, dtype=np.int64).astype(np.int32)
-        for r, (p, e) in enumerate(zip(ranks, exs)):
-            h2d(e.merged, merged)
-            p.gi_import(bands[r][0], bands[r][1], frame)
-            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
-        ctx.sync()
-    h_ref, s_ref = ref.read_gi()
-    ill_ref = ref.read_plane(L.PLANE_ILLUMINANCE)
+    h_ref = P.sharded_gi_vs_single_device(ctx, scene, P.camera_for(EYE), P.sky_state(), W, H, world=2, frames=2,
+                                          n0=synth.stbn_scalar(), n5=synth.stbn_unitvec3_cosine())
     assert int((h_ref[:, 0] != 0).sum()) > 10_000
-    for r, p in enumerate(ranks):
-        h, sp = p.read_gi()
-        assert np.array_equal(h, h_ref), f"rank {r}: hash differs"
-        assert np.array_equal(sp.view(np.uint32), s_ref.view(np.uint32)), f"rank {r}: surfel pool differs"
-        ill = p.read_plane(L.PLANE_ILLUMINANCE)
-        assert np.array_equal(ill[bands[r][0]:bands[r][1]], ill_ref[bands[r][0]:bands[r][1]])

@@ -1,0 +1,73 @@
+"""The HIP device functions against the INDEPENDENT numpy witness in tests/golden/ (make_shader_fixtures.py, SURVEY 8c ii-iv),
+through the C ABI (dust_hip_device_eval runs the same inlined bodies the frame kernels use). tests/test_golden_fixtures.py checks
+the C oracle against the same files on the CPU, so oracle, device code and the witness are pairwise pinned."""
+import os
+
+import numpy as np
+import pytest
+
+from dust_amd import api
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return api.Context(device=0)
+
+
+def words(*cols):
+    """columns (float32 / uint32 arrays, 1-D or 2-D) -> (n, k) uint32 rows by bit pattern"""
+    parts = []
+    for c in cols:
+        c = np.asarray(c)
+        c = c.reshape(len(c), -1)
+        parts.append(c.astype(np.float32).view(np.uint32) if c.dtype.kind == "f" else c.astype(np.uint32))
+    return np.ascontiguousarray(np.concatenate(parts, axis=1))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_device_dda_matches_independent_witness(ctx, kind):
+    """hit.rint / ambient_occlusion.rint / rough.rint on 12 000 (ray, mask) pairs each: reported, t and voxel bit-exact."""
+    fx = np.load(os.path.join(GOLD, "dda_pairs.npz"))
+    out = ctx.device_eval(kind, words(fx["o"], fx["d"], fx["tmin"], fx["mask_lo"], fx["mask_hi"]), 3)
+    rep = fx[f"reported{kind}"]
+    assert np.array_equal(out[:, 0] != 0, rep)
+    want_t = np.where(rep, fx[f"t{kind}"], np.float32(0)).astype(np.float32)
+    got_t = out[:, 1].view(np.float32)
+    same = (out[:, 1] == want_t.view(np.uint32)) | (got_t == want_t)  # +0 / -0 compare equal
+    assert same.all(), f"{int((~same).sum())} hit distances differ, first at {int(np.flatnonzero(~same)[0])}"
+    assert np.array_equal(out[:, 2] & 0xFF, np.where(rep, fx[f"voxel{kind}"], 0))
+
+
+def test_device_codecs_match_independent_witness(ctx):
+    cd = np.load(os.path.join(GOLD, "codecs.npz"))
+    # LogLuv32: the device takes log2 / exp2 from v_log_f32 / v_exp_f32 (1 ulp): one quantisation step of slack on the
+    # luminance field where the witness flags the input as sitting on a step, exact elsewhere for chroma
+    enc = ctx.device_eval(3, words(cd["logluv_rgb"]), 1)[:, 0]
+    want = cd["logluv_packed"]
+    dl = np.abs((enc >> 18).astype(np.int64) - (want >> 18).astype(np.int64))
+    du = np.abs(((enc >> 9) & 511).astype(np.int64) - ((want >> 9) & 511).astype(np.int64))
+    dv = np.abs((enc & 511).astype(np.int64) - (want & 511).astype(np.int64))
+    zero = want == 0
+    assert np.array_equal(enc[zero & ~cd["logluv_borderline"]], want[zero & ~cd["logluv_borderline"]])
+    assert dl[~zero].max() <= 1 and du[~zero].max() <= 1 and dv[~zero].max() <= 1
+    assert (dl[~cd["logluv_borderline"] & ~zero] == 0).mean() > 0.995  # off the steps the fields agree
+    dec = ctx.device_eval(4, words(cd["logluv_words"]), 3).view(np.float32)
+    scale = np.abs(cd["logluv_decoded"]).max(axis=1, keepdims=True)
+    assert (np.abs(dec - cd["logluv_decoded"]) <= 2e-5 * scale).all()
+    # exact formats
+    assert np.array_equal(ctx.device_eval(5, words(cd["normal_in"], cd["normal_material_id"]), 1)[:, 0], cd["normal_packed"])
+    assert ctx.device_eval(6, words(cd["normal_texels"]), 3).view(np.float32).tobytes() == cd["normal_texels_unpacked"].tobytes()
+    half4 = ctx.device_eval(7, words(cd["radiance_in"], cd["radiance_hitdist"]), 2)
+    assert np.array_equal(half4.view(np.uint16).reshape(-1, 4), cd["radiance_half4"])
+    un = ctx.device_eval(8, np.ascontiguousarray(cd["radiance_half4"]).view(np.uint32).reshape(-1, 2), 4).view(np.float32)
+    assert un.tobytes() == cd["radiance_unpacked"].tobytes()
+    assert np.array_equal(ctx.device_eval(9, words(cd["rgb10a2_in"]), 1)[:, 0], cd["rgb10a2_packed"])
+    cub = ctx.device_eval(10, words(cd["cubed_in"]), 4)
+    assert np.array_equal(cub[:, :3].view(np.float32), cd["cubed_out"])
+    faces = ctx.device_eval(10, words(cd["face_in"]), 4)
+    assert faces[:, 3].tolist() == cd["face_id"].tolist()
+    rot = ctx.device_eval(11, words(cd["rotate_normal"], cd["rotate_target"]), 3).view(np.float32)
+    assert rot.tobytes() == cd["rotate_out"].tobytes()

@@ -128,17 +128,55 @@ def test_vox_errors():
     with pytest.raises(L.DustError) as e:
         api.VoxScene(good[: len(good) // 2])
     assert e.value.status == L.ERR_PARSE
-    # multi-frame transform is unimplemented!() in the reference (loader.rs:103-105)
+    # a frame count the chunk does not hold
     import struct
     idx = good.index(b"nTRN")
-    # patch the frame count of the first nTRN from 1 to 2 (the chunk then fails to parse or is unsupported)
     bad = bytearray(good)
     off = idx + 12 + 4 + 4 + 4 + 4 + 4  # header, node id, empty dict, child, reserved, layer
     assert struct.unpack_from("<I", bad, off)[0] == 1
     struct.pack_into("<I", bad, off, 2)
     with pytest.raises(L.DustError) as e:
         api.VoxScene(bytes(bad))
-    assert e.value.status in (L.ERR_UNSUPPORTED, L.ERR_PARSE)
+    assert e.value.status == L.ERR_PARSE
+    # colour index 0 is not a colour: dot_vox saturates `i - 1` at 0, nothing wraps to 255
+    xyzi = np.array([[1, 1, 1, 0], [2, 1, 1, 7]], np.uint8)
+    vs = api.VoxScene(synth.write_vox([((4, 4, 4), xyzi)], [(0, (0, 0, 0), synth.ROT_IDENTITY)], synth.make_palette(1)))
+    _, mats = vs.model_data(0)
+    assert sorted(mats.tolist()) == [0, 6]
+
+
+def test_vox_animation_frames():
+    """MagicaVoxel animations -- transform nodes with several keyframes, shape nodes with several models -- are
+    unimplemented!() in the reference (loader.rs:103-105,149-151). Here the entry in force at the requested frame is used:
+    each frame of the animated file must load exactly like the plain file that spells that frame out."""
+    rng = np.random.default_rng(5)
+    pal = synth.make_palette(2)
+    models = []
+    for sz in ((10, 12, 9), (6, 6, 6), (7, 5, 11)):
+        x = P.random_model(rng, sz, fill=0.3, blobs=0)
+        x[:, 3] = x[:, 3] % 254 + 1
+        models.append((sz, x))
+    static = [(0, (3, 4, 5), synth.ROT_IDENTITY), (1, (-20, 0, 7), synth.ROT_Z90), (2, (9, 9, 9), synth.ROT_IDENTITY)]
+    keys1 = [(0, (-20, 0, 7), synth.ROT_Z90), (4, (-10, 2, 7), synth.ROT_IDENTITY), (9, (0, 4, 7), synth.ROT_MIRROR_X)]
+    shapes2 = [(0, 2), (5, 1), (8, 0)]
+    anim = {1: {"frames": keys1}, 2: {"models": shapes2}}
+    data = synth.write_vox(models, static, pal, anim=anim, groups=[((1, 2, 3), synth.ROT_IDENTITY, [1])])
+
+    def at(frame):
+        k = max((f, t, r) for f, t, r in keys1 if f <= frame)
+        m = max((f, mid) for f, mid in shapes2 if f <= frame)[1]
+        return [static[0], (1, k[1], k[2]), (m, (9, 9, 9), synth.ROT_IDENTITY)]
+
+    for frame in (0, 1, 4, 5, 8, 9, 100):
+        got = api.VoxScene(data, frame=frame)
+        want = api.VoxScene(synth.write_vox(models, at(frame), pal, groups=[((1, 2, 3), synth.ROT_IDENTITY, [1])]))
+        assert got.n_instances == want.n_instances == 3
+        key = lambda s_: sorted((m, tuple(np.round(t, 4).tolist())) for m, t in s_.instances)
+        assert key(got) == key(want), frame
+        for i in range(3):
+            if want.model_info(i).used:
+                assert got.model_data(i)[0].tobytes() == want.model_data(i)[0].tobytes()
+    assert api.VoxScene(data).n_instances == 3  # dust_vox_load == frame 0
 
 
 def test_castle_standin_small():
