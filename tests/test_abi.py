@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "dust_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dust_(?:hip|vdb|vox|png)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(dust_(?:hip|vdb|vox|png|sky)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
