@@ -27,9 +27,11 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t);
-hipError_t sort_pairs_u16(void* tmp, size_t* tmp_bytes, const uint16_t* keys_in, uint16_t* keys_out, const uint32_t* vals_in,
-                          uint32_t* vals_out, uint32_t n, hipStream_t s);
-hipError_t launch_surfel(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t);
+size_t radix_sort_scratch_bytes(uint32_t n);
+hipError_t radix_sort_pairs(void* scratch, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                            uint32_t key_bits, bool* in_b, hipStream_t s);
+hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
@@ -208,8 +210,7 @@ struct DustHipPipeline {
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
-  DeviceBuffer gi_sort_keys, gi_sort_vals, gi_sort_keys_out, gi_perm, gi_sort_tmp;  // position order of the surfel pool
-  size_t gi_sort_tmp_bytes = 0;
+  DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 32x32 tile grouped by ray octant
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
@@ -962,20 +963,36 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     b.tiles_y = 1;
     take_counters(p, 3, b);
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
-    if (!tune.no_surfel_sort) {  // phase 0: Morton keys + radix sort -> gi.perm
-      b.gi.sort_keys = static_cast<uint16_t*>(p->gi_sort_keys.p);
-      b.gi.sort_vals = static_cast<uint32_t*>(p->gi_sort_vals.p);
-      if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
+    uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
+    uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
+    b.gi.sort_keys = sk[0];
+    b.gi.sort_vals = sv[0];
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
+    if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
       HIP_TRY(dust::launch_surfel_keys(b, st));
-      size_t tmp_bytes = p->gi_sort_tmp_bytes;
-      HIP_TRY(dust::sort_pairs_u16(p->gi_sort_tmp.p, &tmp_bytes, b.gi.sort_keys, static_cast<uint16_t*>(p->gi_sort_keys_out.p),
-                                   b.gi.sort_vals, static_cast<uint32_t*>(p->gi_perm.p), p->gi_pool_size, st));
-      b.gi.perm = static_cast<const uint32_t*>(p->gi_perm.p);
-    } else if (ctx->timing) {
-      HIP_TRY(hipEventRecord(p->ev[6], st));
+      bool in_b = false;
+      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
+      b.gi.perm = sv[in_b ? 1 : 0];
     }
     const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
-    HIP_TRY(dust::launch_surfel(b, sgrid, block, count, (fp->passes & DUST_PASS_GI_ORDERED) != 0, st));
+    HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+    // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
+    // result of applying them in surfel-index order -- in parallel over independent probe-window clusters (the serial
+    // one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
+    if (!(fp->passes & DUST_PASS_GI_ORDERED)) {
+      HIP_TRY(dust::launch_surfel_apply(b, 0, st));
+    } else if (tune.debug & 16u) {
+      HIP_TRY(dust::launch_surfel_apply(b, 1, st));
+    } else {
+      HIP_TRY(dust::launch_surfel_apply(b, 2, st));
+      uint32_t bits = 1;
+      while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
+      bool in_b = false;
+      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
+      b.gi.apply_keys = sk[in_b ? 1 : 0];
+      b.gi.apply_vals = sv[in_b ? 1 : 0];
+      HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+    }
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
@@ -1049,10 +1066,8 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));
   HIP_TRY(p->gi_replacement.alloc(size_t(surfel_pool_size) * 16));
   HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
-  for (DeviceBuffer* b : {&p->gi_sort_keys, &p->gi_sort_vals, &p->gi_sort_keys_out, &p->gi_perm}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
-  p->gi_sort_tmp_bytes = 0;
-  HIP_TRY(dust::sort_pairs_u16(nullptr, &p->gi_sort_tmp_bytes, nullptr, nullptr, nullptr, nullptr, surfel_pool_size, p->ctx->stream));
-  HIP_TRY(p->gi_sort_tmp.alloc(p->gi_sort_tmp_bytes));
+  for (DeviceBuffer* b : {&p->gi_sort_keys[0], &p->gi_sort_keys[1], &p->gi_sort_vals[0], &p->gi_sort_vals[1]}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
+  HIP_TRY(p->gi_sort_scratch.alloc(dust::radix_sort_scratch_bytes(surfel_pool_size)));
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;
   p->gi_touched_rows = 0;  // the exchange buffers follow the pool size: dust_hip_pipeline_gi_exchange re-creates them
@@ -1145,11 +1160,27 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
 }
 DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
                                 uint32_t out_words, uint32_t n) {
-  static const uint32_t kWords[12][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}};
-  if (!ctx || !in || !out || fn >= 12) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
+  static const uint32_t kWords[13][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}, {2, 2}};
+  if (!ctx || !in || !out || fn >= 13) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
   if (in_words != kWords[fn][0] || out_words != kWords[fn][1]) return fail(DUST_ERR_INVALID_ARGUMENT, "row width does not match the function");
   if (n == 0) return DUST_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  if (fn == 12) {  // the surfel pass's radix sort on caller-given (key, value) rows, all 32 key bits
+    std::vector<uint32_t> k(n), v(n);
+    for (uint32_t i = 0; i < n; ++i) { k[i] = in[size_t(i) * 2]; v[i] = in[size_t(i) * 2 + 1]; }
+    DeviceBuffer ka, va, kb, vb, scratch;
+    HIP_TRY(ka.upload(k.data(), size_t(n) * 4)); HIP_TRY(va.upload(v.data(), size_t(n) * 4));
+    HIP_TRY(kb.alloc(size_t(n) * 4)); HIP_TRY(vb.alloc(size_t(n) * 4));
+    HIP_TRY(scratch.alloc(dust::radix_sort_scratch_bytes(n)));
+    bool in_b = false;
+    HIP_TRY(dust::radix_sort_pairs(scratch.p, static_cast<uint32_t*>(ka.p), static_cast<uint32_t*>(va.p), static_cast<uint32_t*>(kb.p),
+                                   static_cast<uint32_t*>(vb.p), n, in_words == 2 ? 32u : 32u, &in_b, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(k.data(), in_b ? kb.p : ka.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v.data(), in_b ? vb.p : va.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) { out[size_t(i) * 2] = k[i]; out[size_t(i) * 2 + 1] = v[i]; }
+    return DUST_OK;
+  }
   DeviceBuffer din, dout;
   HIP_TRY(din.upload(in, size_t(n) * in_words * 4));
   HIP_TRY(dout.alloc(size_t(n) * out_words * 4));

@@ -124,8 +124,10 @@ struct DevGI {
   DevSurfel* replacement;   // pool_size: direction == 0xFFFFFFFF means "keep"
   float* sun_payload;       // pool_size x 4: what the surfel's sun ray adds to the value of its request (zero when shadowed)
   const uint32_t* perm;     // surfel indices ordered by position (k_surfel_keys + radix sort), or null = pool order
-  uint16_t* sort_keys;      // pool_size 16-bit position keys / indices the sort consumes (k_surfel_keys fills them)
-  uint32_t* sort_vals;
+  uint32_t* sort_keys;      // pool_size keys / indices a radix sort consumes: k_surfel_keys fills them with 16-bit position keys,
+  uint32_t* sort_vals;      //   k_surfel_apply_keys with the hash location of each insert request (the deterministic apply)
+  const uint32_t* apply_keys;  // the insert requests ordered by hash location (pool_size = "no insert", sorted last) ...
+  const uint32_t* apply_vals;  // ... and the surfel index each one belongs to
   uint32_t* order;          // final gather: per 32x32-pixel tile, its live pixels grouped by ray-direction octant (1024 slots per tile)
   uint32_t* order_count;    // live pixels per tile; null order = plain 8x8 pixel packets
   uint32_t order_tiles_x;   // 32x32 tiles per row

@@ -65,7 +65,7 @@ __shared__ unsigned long long g_dbg_mask[16];  // per wave: lanes being traced v
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
        P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
-enum { P_L_TRIPS = 16, P_L_BRICK, P_L_EMPTY4, P_L_EMPTY16 };  // lane-level trip outcomes  // the P_N_* buckets count events, not cycles
+enum { P_L_TRIPS = 16, P_L_BRICK, P_L_EMPTY4, P_L_EMPTY16, P_SETUP = 20, P_PRIMARY_SHADE = 21, P_AO_SETUP = 22, P_CAND = 23 };  // lane-level trip outcomes  // the P_N_* buckets count events, not cycles
 
 namespace {
 
@@ -552,9 +552,13 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
 template <int RT, bool COUNT>
 __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                                Hit& best, LaneStats& st) {
+  PROF_ENTER(P_SETUP);
   const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   float te, tx;
-  if (!slab_box(o, d, inv_d, m.bmin, m.bmax, te, tx)) return;
+  const bool in_bounds = slab_box(o, d, inv_d, m.bmin, m.bmax, te, tx);
+  PROF_LEAVE(P_SETUP);
+  if (!in_bounds) return;
+  PROF_ENTER(P_CAND);
   const int E = (int)m.extent;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, inv[3] = {inv_d.x, inv_d.y, inv_d.z};
   float t = fmaxf(te, 0.0f);
@@ -591,6 +595,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   MidCache mc;
   mc.key = -1;
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
+  PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
     PROF_COUNT(P_N_STEPS, 1);
     {
@@ -1082,7 +1087,9 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   h.found = false;
   if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
-  return primary_shade<COUNT>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
+  PROF_ENTER(P_PRIMARY_SHADE);
+  primary_shade<COUNT>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
+  PROF_LEAVE(P_PRIMARY_SHADE);
 }
 template <bool COUNT>
 __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
@@ -1141,6 +1148,7 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
 template <bool COUNT>
 __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st_sun, LaneStats& st_ao,
                                           float hitT, uint32_t normal_packed, V3 payload) {
+  PROF_ENTER(P_AO_SETUP);
   const V3 sun = mk(a.sky[48], a.sky[49], a.sky[50]);
   const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
   const bool live = p.valid && !(hitT == INFINITY);
@@ -1161,6 +1169,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   const bool sun_live = live && dot3(sun, n) > 0.0f;
   const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);  // normalize(sun)
   const Range3 org = wave_range(live, loc);  // both rays leave from the same points (sun_live is a subset of live)
+  PROF_LEAVE(P_AO_SETUP);
   Hit h;
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
@@ -1604,11 +1613,11 @@ __global__ void k_surfel_keys(const FrameArgs) {
         c[k] = (uint32_t)f;
       }
       // the top 16 bits of the 30-bit Morton code: five full levels of the octree over the scene's bounds and one more
-      // split (see sort.hip for why the key is this narrow)
+      // split (16 bits: two 8-bit digit passes of radix.hip; a finer order costs more in the sort than it saves in the trace)
       key = (spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2)) >> 14;
       key = key < 0xFFFEu ? key : 0xFFFEu;
     }
-    a.gi.sort_keys[i] = (uint16_t)key;
+    a.gi.sort_keys[i] = key;
     a.gi.sort_vals[i] = i;
   }
 }
@@ -1740,6 +1749,57 @@ __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs) {
         const DevSurfel r = a.gi.replacement[j];
         if (r.direction != 0xFFFFFFFFu) a.gi.pool[j % a.gi.pool_size] = r;
       }
+    }
+  }
+}
+// Deterministic mode at full width. A SpatialHashInsert touches the three entries of its probe window and nothing else, so
+// two requests only interact when their windows overlap -- hash locations at most 2 apart. Requests sorted by location
+// (radix.hip; stable, so equal locations stay in surfel order) therefore fall into CLUSTERS, maximal runs whose consecutive
+// locations differ by <= 2; different clusters touch disjoint entries and commute. One thread per cluster applies its
+// requests in surfel-index order: the hash ends up exactly as the serial loop above leaves it, at the speed of the racy kernel.
+__global__ void k_surfel_apply_keys(const FrameArgs) {  // hash location of every insert request -> sort keys
+  ArgsRef a = launch_args();
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
+    const DevHashRequest rq = a.gi.requests[j];
+    uint32_t loc = a.gi.hash_capacity;  // "no insert": sorts behind every real location
+    if (rq.dir_flags & 0x100u) {
+      HashKey k;
+      k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+      loc = key_location(k, a.gi.hash_capacity);
+    }
+    a.gi.sort_keys[j] = loc;
+    a.gi.sort_vals[j] = j;
+    const DevSurfel r = a.gi.replacement[j];  // slot replacements are independent of each other and of the hash
+    if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
+  }
+}
+__global__ void k_surfel_apply_clusters(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t n = a.gi.pool_size, none = a.gi.hash_capacity;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t loc = a.gi.apply_keys[i];
+    if (loc == none) continue;
+    if (i > 0 && loc - a.gi.apply_keys[i - 1] <= 2u) continue;  // not the first request of its cluster
+    uint32_t end = i + 1;
+    for (uint32_t prev = loc; end < n; ++end) {
+      const uint32_t next = a.gi.apply_keys[end];
+      if (next == none || next - prev > 2u) break;
+      prev = next;
+    }
+    // apply [i, end) in ascending surfel index: selection by repeated minimum (clusters are a handful of requests)
+    uint32_t last = 0;
+    for (uint32_t done = 0; done < end - i; ++done) {
+      uint32_t j = 0xFFFFFFFFu;
+      for (uint32_t k = i; k < end; ++k) {
+        const uint32_t v = a.gi.apply_vals[k];
+        if ((done == 0 || v > last) && v < j) j = v;
+      }
+      last = j;
+      const DevHashRequest rq = a.gi.requests[j];
+      HashKey key;
+      key.x = rq.kx; key.y = rq.ky; key.z = rq.kz; key.dir = rq.dir_flags & 0xFFu;
+      const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
+      hash_insert(a.gi, key, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
     }
   }
 }
@@ -1998,12 +2058,19 @@ hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_surfel(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool ordered, hipStream_t s) {
+hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
   if (count) hipLaunchKernelGGL(k_surfel_trace<true>, dim3(grid), dim3(block), lds, s, a);
   else hipLaunchKernelGGL(k_surfel_trace<false>, dim3(grid), dim3(block), lds, s, a);
-  if (ordered) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+// mode 0: concurrent (racy, as the reference); 1: serial in surfel order (one wavefront); 2: keys for the clustered apply;
+// 3: the clustered apply itself (after the sort)
+hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL(k_surfel_apply_keys, dim3(512), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_surfel_apply_clusters, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_accumulate(const FrameArgs& a, hipStream_t s) {

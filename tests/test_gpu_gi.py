@@ -281,3 +281,35 @@ def test_candidate_list_overflow_matches_oracle():
         compare_gi(gi, pipe)
     st = pipe.pass_stats(0)
     assert st.hits > 100 and st.instances_tested > st.hits   # the stack is on screen and rays cross several of its boxes
+
+
+def test_clustered_apply_equals_serial_apply(monkeypatch):
+    """DUST_PASS_GI_ORDERED applies the surfel pass's inserts in parallel over independent probe-window clusters; the serial
+    one-wavefront loop (DUST_HIP_DEBUG bit 16) is its definition: hash, pool and radiance plane must agree bit for bit, on a
+    crowded table (every window collides) and on a sparse one."""
+    data, _ = synth.castle_scene(scale=0.15)
+    desc = P.SceneDesc.from_vox(data)
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    s = 0.15
+    sky, cam = P.sky_state(), P.camera_for((122.0 * s, 300.61 * s, 54.45 * s))
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    for capacity, pool in ((257, 4096), (1 << 20, 20000)):
+        states = []
+        for dbg in (None, "16"):
+            monkeypatch.delenv("DUST_HIP_DEBUG", raising=False)
+            if dbg:
+                monkeypatch.setenv("DUST_HIP_DEBUG", dbg)
+            pipe = api.StandardPipeline(ctx, 256, 144)
+            pipe.set_noise(0, n0)
+            pipe.set_noise(5, n5)
+            pipe.configure_gi(capacity, pool)
+            for f in range(1, 5):
+                pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(9, f))
+            h, sp = pipe.read_gi()
+            states.append((h, sp.view(np.uint32).copy(), pipe.read_plane(L.PLANE_ILLUMINANCE)))
+        monkeypatch.delenv("DUST_HIP_DEBUG", raising=False)
+        assert (states[0][0][:, 0] != 0).sum() > 100
+        for x, y in zip(*states):
+            assert np.array_equal(x, y), capacity

@@ -71,3 +71,15 @@ def test_device_codecs_match_independent_witness(ctx):
     assert faces[:, 3].tolist() == cd["face_id"].tolist()
     rot = ctx.device_eval(11, words(cd["rotate_normal"], cd["rotate_target"]), 3).view(np.float32)
     assert rot.tobytes() == cd["rotate_out"].tobytes()
+
+
+def test_device_radix_sort_is_a_stable_sort(ctx):
+    """radix.hip (the surfel pass's position order and the deterministic apply's cluster order) against numpy's stable sort:
+    sizes around the 2048-item tile and the 512-item wave run, heavy duplicates, all 32 key bits."""
+    rng = np.random.default_rng(12)
+    for n, hi in ((1, 10), (63, 4), (512, 1 << 32), (2048, 300), (2049, 1 << 16), (5000, 7), (345_600, 1 << 25), (100_003, 1 << 32)):
+        keys = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+        rows = np.stack([keys, np.arange(n, dtype=np.uint32)], axis=1)
+        out = ctx.device_eval(12, np.ascontiguousarray(rows), 2)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(out[:, 0], keys[order]) and np.array_equal(out[:, 1], order.astype(np.uint32)), (n, hi)

@@ -44,10 +44,12 @@ def report(title, b, ms):
     excl = {
         "stage_roots": v["stage_roots"], "grab (work counters)": v["grab"], "cull (bundle vs instance boxes, sort)": v["cull"],
         "candidate loop (slab tests, early exit)": v["trace_ray"] - v["instance"],
-        "instance setup + loop control": v["instance"] - v["find_brick"] - v["brick_test"] - v["screen"] - v["advance"],
+        "instance setup: 1/d + bounds slab": b[20], "instance setup: first cell, tolerances": b[23],
+        "loop control + lane wait in the walk": v["instance"] - v["find_brick"] - v["brick_test"] - v["screen"] - v["advance"] - b[20] - b[23],
         "find_brick (root/mid lookup, mask load)": v["find_brick"], "brick test (4^3 DDA)": v["brick_test"],
         "near-plane screen / neighbour queue": v["screen"], "advance (exit planes, cell step)": v["advance"],
-        "ray setup, shading, G-buffer stores": v["total"] - v["stage_roots"] - v["grab"] - v["cull"] - v["trace_ray"],
+        "primary shading + G-buffer stores": b[21], "AO pass ray setup (normal, noise, ranges)": b[22],
+        "other ray setup, shading, stores": v["total"] - v["stage_roots"] - v["grab"] - v["cull"] - v["trace_ray"] - b[21] - b[22],
     }
     print(f"\n== {title}: {ms:.3f} ms (instrumented), {tot / 1e9:.2f} G wave-cycles")
     for k, x in excl.items():
