@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s of the HIP ray-tracing hot path on the castle stand-in (BASELINE.json configs[1]).
+"""bench.py -- Mrays/s of the HIP ray-tracing hot path, one command per BASELINE.json configuration.
 
-One "step" = one frame of the hot path over resident inputs: primary visibility + sun-shadow + ambient
-occlusion passes (StandardPipeline::render's first two vkCmdTraceRaysKHR calls, standard.rs:477-577) at
-1920x1080, 1 spp. "N spp" in the reference means N consecutive frames (frame_index -> STBN slice, fresh
-rand), and those frames are independent for these passes, so with N GPUs a step renders N
-samples of the same view -- rank r takes frame_index k*N + r -- and every rank's RGBA16F illuminance
-frame is gathered to rank 0 over RCCL inside the timed region (weak scaling: 1080p x 1 spp per GPU).
-Row-band sharding of one frame (dust_hip_render_frame row_begin/row_end) is covered by the tests.
-A ray = one traceRayEXT equivalent actually issued (primary / sun-shadow / AO), counted by the counting
-build of the kernels in an untimed frame.
+  --workload primary_ao   configs[1] (the headline, default): castle stand-in, 1920x1080, primary + sun-shadow + AO rays
+  --workload gi           configs[2]/[3]: the same scene, all four passes + accumulation (--width 3840 --height 2160 for [3])
+  --workload deep         configs[4]: procedural 4096^3 tree (hierarchy (4,4,2,2)) at 1 % brick occupancy, GI frame
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-algorithmic bytes / HIP-event time) and `cpu_baseline` (the C oracle's hierarchical traversal, a port
-of the algorithm -- the reference has no CPU ray traversal at all, SURVEY F2 -- on a bounded row sample).
+One "step" = one frame of the hot path over resident inputs (StandardPipeline::render, standard.rs:477-725).
+With N GPUs (one process per GPU, torch.distributed over RCCL) the work is cut one of two ways:
+  --shard samples (default)  "N spp" in the reference is N consecutive frames (frame_index -> STBN slice, fresh rand):
+                             rank r renders sample k*N + r of the same view; weak scaling, one whole frame per GPU and step.
+  --shard bands              ONE frame per step, cut into N row bands (DustHipFrameParams.row_begin/row_end): strong
+                             scaling. GI workloads keep an identical spatial hash + surfel pool on every GPU through the
+                             exchange of dust_hip_pipeline_gi_exchange (three small collectives per frame) and the
+                             deterministic apply (DUST_PASS_GI_ORDERED); the surfel pass is replicated.
+Either way every rank's RGBA16F illuminance (frame or band) is gathered to rank 0 over RCCL inside the timed region.
+A ray = one traceRayEXT equivalent actually issued, counted per class by the counting build of the kernels in an untimed frame.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes / HIP-event
+time) and `cpu_baseline` (the C oracle's hierarchical traversal, a port -- the reference has no CPU ray traversal at all,
+SURVEY F2 -- on a bounded row sample of the same frame).
 """
 import argparse
 import ctypes
@@ -27,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+NAMES = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_sun", "surfel_cosine")
 
 
 def parse():
@@ -37,22 +43,22 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale", type=float, default=1.0, help="castle stand-in scale (1.0 = BASELINE config)")
-    ap.add_argument("--workload", choices=["primary_ao", "gi"], default="primary_ao",
-                    help="primary_ao = BASELINE configs[1] (the headline); gi = configs[2]: all four passes + accumulation")
-    ap.add_argument("--gi-shard", choices=["samples", "bands"], default="samples",
-                    help="--workload gi on N GPUs: samples = one whole frame per GPU, independent GI state per GPU; bands = ONE "
-                         "frame cut into row bands, hash and surfel pool kept identical on every GPU by the exchange of "
-                         "dust_hip_pipeline_gi_exchange (strong scaling)")
+    ap.add_argument("--workload", choices=["primary_ao", "gi", "deep"], default="primary_ao")
+    ap.add_argument("--shard", choices=["samples", "bands"], default=None)
+    ap.add_argument("--gi-shard", choices=["samples", "bands"], default=None, help="older spelling of --shard")
+    ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.shard = a.shard or a.gi_shard or "samples"
+    return a
 
 
-def algorithmic_bytes(st, gbuffer_bytes_per_ray):
+def algorithmic_bytes(st, gbuffer_bytes):
     """64 B per instance tested, 8+4 per root/mid child descended, 24 per brick tested,
     1+4 per hit (material byte + palette entry), plus the pass's G-buffer traffic."""
     return (st.instances_tested * 64 + (st.upper_descents + st.mid_descents) * 12 + st.bricks_tested * 24 + st.hits * 5
-            + gbuffer_bytes_per_ray)
+            + gbuffer_bytes)
 
 
 def main():
@@ -79,10 +85,9 @@ def main():
 
     from dust_amd import _lib as L
     from dust_amd import api, sharding, synth
-    from dust_amd import scenes as P  # scene description helpers + sky fixture; the oracle is only imported in the cpu_baseline leg
+    from dust_amd import scenes as P  # scene description helpers + packaged sky; the oracle is only imported in the cpu_baseline leg
 
     W, H = args.width, args.height
-    Hband = H
     # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
     # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
     # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
@@ -96,43 +101,62 @@ def main():
         os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
     ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(stream))
 
+    # ------------------------------------------------------------------ scene
+    gi_mode = args.workload in ("gi", "deep")
+    deep = args.workload == "deep"
     t0 = time.time()
-    data, info = synth.castle_scene(scale=args.scale)
-    t_gen = time.time() - t0
-    t0 = time.time()
-    desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
-    t_load = time.time() - t0
-    scene = P.hip_scene(ctx, desc)
+    if deep:  # brick occupied iff hash(seed, bx, by, bz) < occupancy, voxels set with p = 0.5
+        blocks, mats = synth.procedural_deep_blocks(occupancy=args.deep_occupancy, sample=True)
+        pal = synth.make_palette(5)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
+        scene = api.Scene(ctx)
+        xf = np.eye(3, 4, dtype=np.float32)
+        xf[:, 3] = (-2048.0, -2048.0, -2048.0)
+        scene.add_instance(model, xf.reshape(12))
+        scene.commit()
+        t_load = time.time() - t0
+        info = {"n_models": 1, "n_instances": 1, "n_voxels": int(len(mats))}
+        n_bricks = int(len(blocks))
+        eye, target = (300.0, 200.0, -150.0), (0.0, 0.0, 0.0)  # inside the volume
+        desc = None
+    else:
+        data, info = synth.castle_scene(scale=args.scale)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
+        t_load = time.time() - t0
+        scene = P.hip_scene(ctx, desc)
+        n_bricks = desc.n_bricks()
+        s = args.scale
+        eye, target = (122.0 * s, 300.61 * s, 54.45 * s), (0.0, 0.0, 0.0)  # examples/castle.rs:120-129, fov pi/4
     pipe = api.StandardPipeline(ctx, W, H)
     noise5 = synth.stbn_unitvec3_cosine()
     pipe.set_noise(5, noise5)
     sky = P.sky_state("default")
-    s = args.scale
-    proj = api.PinholeProjection()
-    # examples/castle.rs:120-129: eye (122, 300.61, 54.45) -> origin, fov pi/4
-    eye = (122.0 * s, 300.61 * s, 54.45 * s)
-    cam = api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), proj)
-    rows = (0, H)
+    cam = api.make_camera(eye, api.look_at_rotation(eye, target), api.PinholeProjection())
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
-    gi_mode = args.workload == "gi"
-    if gi_mode:  # configs[2]: diffuse GI through the surfel-fed spatial hash (concurrent apply, as the reference)
+    if gi_mode:  # diffuse GI through the surfel-fed spatial hash
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
         pipe.set_noise(0, synth.stbn_scalar())
-        args.no_cpu_baseline = True
-    gi_bands = gi_mode and args.gi_shard == "bands"
+
+    # ------------------------------------------------------------------ partition
+    bands = args.shard == "bands" and world >= 1
+    per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
+    have_rows = rows[0] < rows[1]                                        # a rank past the end of the frame renders no pixels
+    gi_bands = gi_mode and bands
     if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
-        per_rows = sharding.gi_band_rows(world, H)
-        rows = (min(H, rank * per_rows), min(H, (rank + 1) * per_rows))
-        Hband = per_rows
         ex = pipe.gi_exchange(world * per_rows)
         ex_owner, ex_touched, ex_merged = sharding.alias_exchange_buffers(ex)
 
-    # framebuffer gather: two full-frame illuminance targets in torch tensors, bound to the pipeline in turn
-    # (dust_hip_pipeline_bind_plane), so RCCL moves frame k straight out of its render target while frame k+1 renders
-    # into the other one -- no staging copy
-    own_rows = rows[1] - rows[0]
-    targets = [torch.zeros((H, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
-    gather = sharding.AsyncGather(dist, targets[0][rows[0]:rows[1]])  # step k's gather overlaps step k+1's rendering
+    # Framebuffer gather: two illuminance targets in torch tensors, bound to the pipeline in turn (dust_hip_pipeline_bind_plane),
+    # so RCCL moves frame k straight out of its render target while frame k+1 renders into the other one -- no staging copy.
+    # With bands the targets are padded to world * per_rows rows: every rank sends a slice of the SAME size (its band padded to
+    # per_rows rows; a collective with unequal counts is undefined), and rank 0 keeps the first H rows of the assembly.
+    tgt_rows = world * per_rows if bands else H
+    targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
+    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]])  # step k's gather overlaps step k+1's rendering
 
     pix_stats = []
 
@@ -144,19 +168,27 @@ def main():
             frame_index = 1 + k  # every rank works on the same frame
             rnd = synth.frame_rand(1, frame_index)
             pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_GI_SHARDED
-            pipe.render(scene, cam, sky, pix | cs, frame_index=frame_index, rand=rnd, rows=rows)
+            if have_rows:
+                pipe.render(scene, cam, sky, pix | cs, frame_index=frame_index, rand=rnd, rows=rows)
             if count:  # the second call restarts the counters: keep the pixel passes' now
                 torch.cuda.synchronize()
-                pix_stats[:] = [pipe.pass_stats(i) for i in range(4)]
+                pix_stats[:] = [pipe.pass_stats(i) for i in range(4)] if have_rows else []
             sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
-                                      lambda: pipe.gi_export(*rows), lambda: pipe.gi_import(rows[0], rows[1], frame_index))
-            pipe.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_ACCUMULATE | L.PASS_GI_SHARDED | cs, frame_index=frame_index,
-                        rand=rnd, rows=rows)
+                                      (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: None),
+                                      (lambda: pipe.gi_import(rows[0], rows[1], frame_index)) if have_rows else
+                                      (lambda: pipe.gi_import(H, H, frame_index)))  # empty own range: every stamp is another band's
+            # the replicated surfel pass must leave the SAME hash on every GPU: deterministic apply, not the racy one
+            sp = L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED | cs | (L.PASS_ACCUMULATE if have_rows else 0)
+            pipe.render(scene, cam, sky, sp, frame_index=frame_index, rand=rnd, rows=rows if have_rows else (0, 0))
+        elif bands:
+            frame_index = 1 + k
+            if have_rows:
+                pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index), rows=rows)
         else:
             frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
             pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         if world > 1:
-            gather.submit_view(targets[k % 2][rows[0]:rows[1]])  # asynchronous gather to rank 0, straight from the target
+            gather.submit_view(targets[k % 2][send[0]:send[1]])  # asynchronous gather to rank 0, straight from the target
 
     def barrier():
         gather.finish()
@@ -167,18 +199,21 @@ def main():
     # untimed counting frame: rays per class and algorithmic bytes per launch
     step(0, count=True)
     barrier()
-    st = [pipe.pass_stats(i) for i in range(6 if gi_mode else 3)]
+    n_classes = 6 if gi_mode else 3
+    st = [pipe.pass_stats(i) for i in range(n_classes)]
     if gi_bands:
-        st[:4] = pix_stats
+        st[:4] = pix_stats if pix_stats else [L.PassStats() for _ in range(4)]
+    if bands and not have_rows:
+        st[:min(4, n_classes)] = [L.PassStats() for _ in range(min(4, n_classes))]
     rays_rank = sum(x.rays for x in st)
     if gi_bands and rank != 0:
         rays_rank -= st[4].rays + st[5].rays  # the replicated surfel pass counts once
     # self-check of the plumbing the gather relies on (untimed): the bound torch tensor is where the frame went
     # (tests/test_gpu_parity.py::test_bound_plane_equals_own_storage shows a bound target gets the same bits as the
     # pipeline's own plane)
-    own = torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE)[rows[0]:rows[1]].view(np.int16))
-    assert bool((own != 0).any()) and torch.equal(targets[0][rows[0]:rows[1]].cpu().view(torch.int16), own)
-    names = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_sun", "surfel_cosine")
+    if have_rows:
+        own = torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE)[rows[0]:rows[1]].view(np.int16))
+        assert bool((own != 0).any()) and torch.equal(targets[0][rows[0]:rows[1]].cpu().view(torch.int16), own)
     hit_px = st[0].hits
     miss_px = st[0].rays - st[0].hits
     bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
@@ -197,24 +232,28 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     gc.enable()
-    # kernel durations from the HIP events the library recorded on the launch stream (last timed step)
-    ms_primary = pipe.pass_stats(0).ms
-    ms_ao = pipe.pass_stats(1).ms
-    # average the event timing over a few more (untimed) frames so it is not a single sample
-    acc_p, acc_a, reps = ms_primary, ms_ao, 1
-    for i in range(min(8, max(0, args.steps - 1))):
-        step(100 + i)
+    # kernel durations from the HIP events the library recorded on the launch stream, averaged over a few more (untimed) frames
+    acc, reps = [0.0, 0.0, 0.0, 0.0], 0
+    for i in range(min(8, max(1, args.steps))):
+        step(1 + args.warmup + args.steps + i)
         torch.cuda.synchronize()
-        acc_p += pipe.pass_stats(0).ms
-        acc_a += pipe.pass_stats(1).ms
+        for j, slot in enumerate((0, 1, 3, 4)):
+            acc[j] += pipe.pass_stats(slot).ms if (have_rows or slot == 4) else 0.0
         reps += 1
-    ms_primary, ms_ao = acc_p / reps, acc_a / reps
+    barrier()
+    ms_primary, ms_ao, ms_fg, ms_sf = [x / reps for x in acc]
+    if not gi_mode:
+        ms_fg = ms_sf = 0.0
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays_all = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
+    mine = torch.tensor([ms_primary, ms_ao, ms_fg, ms_sf], dtype=torch.float64, device="cuda")
+    per_rank = [mine]
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     elapsed = float(t_max.item())
     total_rays_per_step = float(rays_all.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -226,8 +265,8 @@ def main():
         return
 
     kernels_ms_extra = {}
+    bytes_fg = bytes_sf = 0
     if gi_mode:
-        ms_fg, ms_sf = pipe.pass_stats(3).ms, pipe.pass_stats(4).ms
         # final gather: depth 4 + normal 4 + illuminance 8 read, 8 written, one 12-byte hash entry + 16-byte surfel per hit
         bytes_fg = algorithmic_bytes(st[3], st[3].rays * 24 + st[3].hits * 28) - st[3].hits * 5
         # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
@@ -240,32 +279,51 @@ def main():
     else:
         dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
     achieved = dominant[1] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
-    traffic = None
+    # HBM-side traffic per launch: NOT measured by this process -- rocprofv3 counter passes need their own runs
+    # (tools/profile_round.sh); the committed summary of the latest one is quoted with its provenance, or nothing is
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and not bands and (W, H) == (1920, 1080):
         try:
             pm = json.load(open(pmc_path))
-            if pm.get("workload") == "castle-standin" and abs(pm.get("scale", 1.0) - args.scale) < 1e-9:
+            key = "castle-standin" if not deep else "deep-tree"
+            if pm.get("workload") == key and abs(pm.get("scale", 1.0) - args.scale) < 1e-9:
                 traffic = pm.get("hbm_bytes_per_launch", {}).get(dominant[0])
+            if deep:
+                traffic = pm.get("deep", {}).get("hbm_bytes_per_launch", {}).get(dominant[0])
+            if traffic is not None:
+                traffic_source = (f"profiles/pmc_summary.json (round {pm.get('round')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes of this command, 2 x FETCH + WRITE per MI355X_MICROARCH.md; not measured in this run)")
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
                 "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if ms_ao == 0.0 else
                                    {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
+                "per_rank_kernel_ms": [{"primary_ao" if ms_ao == 0.0 else "primary": round(float(v[0]), 4),
+                                        **({"ambient_occlusion": round(float(v[1]), 4)} if ms_ao != 0.0 else {}),
+                                        **({"final_gather": round(float(v[2]), 4), "surfel": round(float(v[3]), 4)} if gi_mode else {})}
+                                       for v in per_rank],
                 "bytes_per_ray": {"primary": round(bytes_primary / max(1, st[0].rays), 1),
                                   "ao_pass": round(bytes_ao / max(1, st[1].rays + st[2].rays), 1)}}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O  # the checker, used here only as the reported CPU baseline (never in the timed GPU path)
         import parity_util
-        oscene = parity_util.oracle_scene(desc)
+        if deep:
+            oscene = O.Scene()
+            oscene.add_model(blocks, mats, pal, extent=4096)
+            oscene.add_instance(0, xf.reshape(12))
+            oscene.commit()
+        else:
+            oscene = parity_util.oracle_scene(desc)
         cores = os.cpu_count() or 1
-        n_rows = args.cpu_rows or max(cores, min(Hband, 8 * cores))
-        y0 = (Hband - n_rows) // 2
+        n_rows = args.cpu_rows or max(cores, min(H, (2 if deep else 8) * cores))
+        n_rows = min(n_rows, H)
+        y0 = (H - n_rows) // 2
         g = O.GBuffer(W, H)
         oc, osky = O.camera_from(cam), O.sky_from(sky)
         n5 = np.ascontiguousarray(noise5[1 % len(noise5)])
@@ -287,26 +345,32 @@ def main():
         dt = time.perf_counter() - t0
         cpu_rays = sum(s_.rays for ss in stats for s_ in ss)
         cpu = {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"rows {y0}..{y0 + n_rows} of the same frame ({cpu_rays} rays, {dt:.1f} s), oracle hierarchical mode, "
-                         f"{cores} threads; tree build + flatten of the whole scene took {t_load:.2f} s on the same cores"}
+               "sample": f"primary + sun-shadow + AO rays of rows {y0}..{y0 + n_rows} of the same frame ({cpu_rays} rays, {dt:.1f} s), oracle "
+                         f"hierarchical mode, {cores} threads; scene build (tree build + flatten / hierarchy upload) took {t_load:.2f} s on the same cores"}
 
+    what = {"primary_ao": "1spp primary+shadow+AO", "gi": "1 GI frame: primary+shadow+AO+final gather+surfel",
+            "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
+    scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
+                  ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}"))
+    if bands:
+        par = (f"bands x{world}: one frame in {world} row bands of {per_rows} rows"
+               + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
+                  "winning surfels, deterministic apply), surfel pass replicated" if gi_mode else "")
+               + ", RCCL gather of the (equal-size, padded) bands to rank 0")
+    else:
+        par = f"spp x{world}: one {W}x{H} sample per GPU, RCCL gather of RGBA16F frames to rank 0"
+    metric = {"primary_ao": f"Mrays/s at {W}x{H} 1spp castle.vox (primary + sun-shadow + AO rays)",
+              "gi": f"Mrays/s at {W}x{H} castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
+              "deep": f"Mrays/s at {W}x{H} procedural 4096^3 sparse vdb, diffuse GI frame (deep-tree stress)"}[args.workload]
     out = {
-        "metric": "Mrays/s at 1920x1080 1spp castle.vox (primary + sun-shadow + AO rays)" if not gi_mode else
-                  "Mrays/s at 1920x1080 castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
-        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if gi_bands else "weak", "vs_baseline": None,
+        "metric": metric, "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("castle.vox stand-in (synth.castle_scene seed 0xD057), 1920x1080 per GPU, "
-                                + ("1 GI frame: primary+shadow+AO+final gather+surfel" if gi_mode else "1spp primary+shadow+AO"))
-                   if args.scale == 1.0 else f"castle stand-in at scale {args.scale}",
-                   "frame": [W, H], "spp_per_step": 1 if gi_bands else world,
-                   "parallelism": (f"bands x{world}: one frame in {world} row bands, identical hash + surfel pool on every GPU "
-                                   "(all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of winning surfels), "
-                                   "surfel pass replicated, RCCL gather of the bands to rank 0") if gi_bands else
-                                  f"spp x{world}: one 1080p sample per GPU, RCCL gather of RGBA16F frames to rank 0",
+        "config": {"workload": f"{scene_name}, {W}x{H}{'' if bands else ' per GPU'}, {what}",
+                   "frame": [W, H], "spp_per_step": 1 if bands else world, "parallelism": par,
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
-                   "bricks": desc.n_bricks(), "scene_build_s": round(t_load, 3),
-                   "rays_per_step": {n: int(x.rays) for n, x in zip(names, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},
+                   "bricks": n_bricks, "scene_build_s": round(t_load, 3),
+                   "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -1336,33 +1336,65 @@ __device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t fr
   }
   return false;
 }
-// SpatialHashInsert (spatial_hash.glsl:147-195)
-__device__ void hash_insert(const DUST_CONST_AS DevGI& gi, HashKey key, V3 value, uint32_t frame_index) {
-  const uint32_t fp = key_fingerprint(key), loc = key_location(key, gi.hash_capacity);
-  uint32_t i_min = 0, min_frame = 0;
+// SpatialHashInsert (spatial_hash.glsl:147-195) over an accessor to the three entries of the probe window: the entries
+// in memory (the shader's own form: the fingerprint is claimed with an atomic compare-and-swap), or a copy of the window
+// held in registers (HashWindow: the deterministic apply runs a whole cluster of requests on it between one load and one
+// store). One body, so both forms take the same decisions in the same order.
+struct HashMemory {
+  uint32_t* base;  // first entry of the window
+  __device__ __forceinline__ uint32_t claim(uint32_t i, uint32_t fp) { return atomicCAS(&base[i * 3], 0u, fp); }
+  __device__ __forceinline__ uint32_t meta(uint32_t i) const { return base[i * 3 + 2]; }
+  __device__ __forceinline__ uint32_t radiance(uint32_t i) const { return base[i * 3 + 1]; }
+  __device__ __forceinline__ void set(uint32_t i, uint32_t rad, uint32_t meta_) { base[i * 3 + 1] = rad; base[i * 3 + 2] = meta_; }
+  __device__ __forceinline__ void set_fingerprint(uint32_t i, uint32_t fp) { base[i * 3] = fp; }
+};
+struct HashWindow {
+  uint32_t w[9];
+  __device__ __forceinline__ uint32_t claim(uint32_t i, uint32_t fp) {
+    const uint32_t old = w[i * 3];
+    if (old == 0u) w[i * 3] = fp;
+    return old;
+  }
+  __device__ __forceinline__ uint32_t meta(uint32_t i) const { return w[i * 3 + 2]; }
+  __device__ __forceinline__ uint32_t radiance(uint32_t i) const { return w[i * 3 + 1]; }
+  __device__ __forceinline__ void set(uint32_t i, uint32_t rad, uint32_t meta_) { w[i * 3 + 1] = rad; w[i * 3 + 2] = meta_; }
+  __device__ __forceinline__ void set_fingerprint(uint32_t i, uint32_t fp) { w[i * 3] = fp; }
+};
+template <class Entries>
+__device__ __forceinline__ void hash_insert_window(Entries& e, uint32_t fp, V3 value, uint32_t frame_index) {
+  uint32_t min_frame = 0;
+  bool evict[3] = {true, false, false};  // which probe is the least recently accessed so far (the first of equals)
+#pragma unroll
   for (uint32_t i = 0; i < 3; ++i) {
-    uint32_t* e = gi.hash + (size_t)(loc + i) * 3;
-    const uint32_t cur = atomicCAS(&e[0], 0u, fp);
-    const uint32_t w2 = e[2];
+    const uint32_t cur = e.claim(i, fp);
+    const uint32_t w2 = e.meta(i);
     const uint32_t cur_frame = w2 & 0xFFFFu;
-    if (i == 0 || cur_frame < min_frame) { i_min = i; min_frame = cur_frame; }
+    if (i == 0 || cur_frame < min_frame) {
+      min_frame = cur_frame;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) evict[k] = k == i;
+    }
     if (cur == fp || cur == 0) {
       V3 rad = mk(0, 0, 0);
       uint32_t count = 0;
-      if (cur == fp) { count = w2 >> 16; rad = logluv_decode(e[1]); }
+      if (cur == fp) { count = w2 >> 16; rad = logluv_decode(e.radiance(i)); }
       count = count < 403u ? count : 403u;
       const uint32_t next = count + 1;
       const float al = 1.0f / (float)next;
       const V3 out = mk(rad.x * (1.0f - al) + value.x * al, rad.y * (1.0f - al) + value.y * al, rad.z * (1.0f - al) + value.z * al);
-      e[1] = logluv_encode(out);
-      e[2] = (frame_index & 0xFFFFu) | (next << 16);
+      e.set(i, logluv_encode(out), (frame_index & 0xFFFFu) | (next << 16));
       return;
     }
   }
-  uint32_t* e = gi.hash + (size_t)(loc + i_min) * 3;  // evict the least recently accessed of the three probes
-  e[0] = fp;
-  e[1] = logluv_encode(value);
-  e[2] = (frame_index & 0xFFFFu) | (1u << 16);
+  const uint32_t rad = logluv_encode(value), meta = (frame_index & 0xFFFFu) | (1u << 16);
+#pragma unroll
+  for (uint32_t i = 0; i < 3; ++i)  // evict the least recently accessed of the three probes
+    if (evict[i]) { e.set_fingerprint(i, fp); e.set(i, rad, meta); }
+}
+__device__ void hash_insert(const DUST_CONST_AS DevGI& gi, HashKey key, V3 value, uint32_t frame_index) {
+  HashMemory m;
+  m.base = gi.hash + (size_t)key_location(key, gi.hash_capacity) * 3;
+  hash_insert_window(m, key_fingerprint(key), value, frame_index);
 }
 __device__ __forceinline__ float srgb_to_linear(float c) {  // color.glsl:1-5
   // pow(x, 2.4) as exp2(2.4 log2 x) on the hardware transcendentals: radiance (1e-3 tolerance), a fifth of the libm routine
@@ -1773,7 +1805,8 @@ __global__ void k_surfel_apply_keys(const FrameArgs) {  // hash location of ever
     if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
   }
 }
-__global__ void k_surfel_apply_clusters(const FrameArgs) {
+__shared__ uint32_t g_apply_slab[256][25];  // k_surfel_apply_clusters: a thread's staged probe windows (8 entries, padded to 25 words)
+__global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) {
   ArgsRef a = launch_args();
   const uint32_t n = a.gi.pool_size, none = a.gi.hash_capacity;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1786,20 +1819,103 @@ __global__ void k_surfel_apply_clusters(const FrameArgs) {
       if (next == none || next - prev > 2u) break;
       prev = next;
     }
-    // apply [i, end) in ascending surfel index: selection by repeated minimum (clusters are a handful of requests)
-    uint32_t last = 0;
-    for (uint32_t done = 0; done < end - i; ++done) {
-      uint32_t j = 0xFFFFFFFFu;
-      for (uint32_t k = i; k < end; ++k) {
-        const uint32_t v = a.gi.apply_vals[k];
-        if ((done == 0 || v > last) && v < j) j = v;
-      }
-      last = j;
+    auto request = [&](uint32_t j, uint32_t& fp, V3& value) {
       const DevHashRequest rq = a.gi.requests[j];
       HashKey key;
       key.x = rq.kx; key.y = rq.ky; key.z = rq.kz; key.dir = rq.dir_flags & 0xFFu;
       const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
-      hash_insert(a.gi, key, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
+      fp = key_fingerprint(key);
+      value = mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z);
+    };
+    if (a.gi.apply_keys[end - 1] == loc) {
+      // Every request of the cluster probes the same window (all but a handful of clusters: surfels of one brick face
+      // share a key). The sort is stable, so they already stand in surfel order: load the window once, run them on the
+      // register copy, store it once -- a chain of ALU work instead of several dependent memory round trips per request.
+      HashWindow win;
+      uint32_t* base = a.gi.hash + (size_t)loc * 3;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) win.w[k] = base[k];
+      // eight requests at a time: their (independent) loads are in flight together, then the eight inserts run as one chain
+      // of arithmetic on the register window
+      constexpr uint32_t kBatch = 8;
+      for (uint32_t k0 = i; k0 < end; k0 += kBatch) {
+        uint32_t fp[kBatch];
+        V3 value[kBatch];
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; ++b) {
+          const uint32_t k = k0 + b < end ? k0 + b : end - 1u;
+          request(a.gi.apply_vals[k], fp[b], value[b]);
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; ++b)
+          if (k0 + b < end) hash_insert_window(win, fp[b], value[b], a.frame_index);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) base[k] = win.w[k];
+      continue;
+    }
+    // Windows at different offsets (a few dozen clusters per pass, but some are long: two popular brick faces whose
+    // locations happen to lie within two entries of each other). Up to kRuns locations spanning up to kSpan entries: the union
+    // of the windows is staged in this thread's LDS slab, the runs (each already in surfel order) are merged by surfel index.
+    constexpr uint32_t kRuns = 4, kSpan = 8;
+    uint32_t run_at[kRuns], run_end[kRuns], run_loc[kRuns], n_runs = 0;
+    bool fits = true;
+    for (uint32_t k = i; k < end;) {
+      const uint32_t l = a.gi.apply_keys[k];
+      uint32_t e2 = k + 1;
+      while (e2 < end && a.gi.apply_keys[e2] == l) ++e2;
+      if (n_runs < kRuns) { run_at[n_runs] = k; run_end[n_runs] = e2; run_loc[n_runs] = l; }
+      else fits = false;
+      ++n_runs;
+      k = e2;
+    }
+    const uint32_t last_loc = a.gi.apply_keys[end - 1];
+    fits = fits && last_loc - loc + 3u <= kSpan;
+    if (fits) {
+      uint32_t* slab = &g_apply_slab[threadIdx.x][0];
+      const uint32_t words = (last_loc - loc + 3u) * 3u;
+      uint32_t* base = a.gi.hash + (size_t)loc * 3;
+      for (uint32_t k = 0; k < words; ++k) slab[k] = base[k];
+      uint32_t head[kRuns];
+#pragma unroll
+      for (uint32_t r = 0; r < kRuns; ++r) head[r] = r < n_runs ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
+      for (uint32_t done = 0; done < end - i; ++done) {
+        uint32_t best = 0;
+#pragma unroll
+        for (uint32_t r = 1; r < kRuns; ++r) best = head[r] < head[best] ? r : best;
+        uint32_t j = 0, l = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < kRuns; ++r)
+          if (r == best) {
+            j = head[r]; l = run_loc[r];
+            run_at[r] += 1;
+            head[r] = run_at[r] < run_end[r] ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
+          }
+        uint32_t fp;
+        V3 value;
+        request(j, fp, value);
+        HashMemory m;  // the same accessor: "memory" is the slab
+        m.base = slab + (l - loc) * 3u;
+        hash_insert_window(m, fp, value, a.frame_index);
+      }
+      for (uint32_t k = 0; k < words; ++k) base[k] = slab[k];
+      continue;
+    }
+    // anything wider: through memory, in ascending surfel index found by repeated minimum
+    uint32_t last = 0;
+    for (uint32_t done = 0; done < end - i; ++done) {
+      uint32_t j = 0xFFFFFFFFu, at = i;
+      for (uint32_t k = i; k < end; ++k) {
+        const uint32_t v = a.gi.apply_vals[k];
+        if ((done == 0 || v > last) && v < j) { j = v; at = k; }
+      }
+      last = j;
+      uint32_t fp;
+      V3 value;
+      request(j, fp, value);
+      HashMemory m;
+      m.base = a.gi.hash + (size_t)a.gi.apply_keys[at] * 3;
+      hash_insert_window(m, fp, value, a.frame_index);
     }
   }
 }

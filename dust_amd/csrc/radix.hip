@@ -3,15 +3,17 @@
 // Two users, both in the surfel pass (capi.cpp): the 16-bit Morton keys that put the surfel pool in position order before
 // it is traced (k_surfel_keys), and the 26-bit hash locations that group the pass's insert requests into independent
 // probe-window clusters for the deterministic parallel apply (k_surfel_apply_keys / k_surfel_apply_clusters).
-// A few hundred thousand items: the sort is launch-bound, so it is built to need ONE launch per digit plus one:
-//   k_radix_first     per-tile histogram of the first digit; clears the later passes' histograms
-//   k_radix_scatter   per pass. Every workgroup (a) works out where its tile's items of each digit go from the [tile][digit]
-//                     histogram itself -- digit totals and the counts of the tiles before it, ~2 x n_tiles coalesced loads per
-//                     thread, instead of a separate scan launch --, (b) ranks its items among the equal digits of the tile
-//                     with wave ballots (64 items match their digit bit by bit, popcount of the lower matching lanes) plus
-//                     per-wave running counters in LDS -- every wave owns a contiguous run of the tile, so (wave, round, lane)
-//                     order is index order and the sort is stable with no global atomics on the data path --, (c) scatters,
-//                     and (d) counts each item into the NEXT pass's histogram at the tile it lands in (fire-and-forget atomics).
+// A few hundred thousand items: the sort is launch- and latency-bound, so it is two small launches per digit:
+//   k_radix_histogram per-tile histogram of the digit (LDS atomics), written as a [tile][digit] table
+//   k_radix_scatter   every workgroup (a) works out where its tile's items of each digit go from that table itself -- digit
+//                     totals and the counts of the tiles before it, ~n_tiles coalesced loads per thread, instead of a separate
+//                     scan launch --, (b) ranks its items among the equal digits of the tile with wave ballots (64 items match
+//                     their digit bit by bit, popcount of the lower matching lanes) plus per-wave running counters in LDS --
+//                     every wave owns a contiguous run of the tile, so (wave, round, lane) order is index order and the sort
+//                     is stable with no global atomics anywhere --, (c) scatters.
+// (Measured and dropped: counting every scattered item into the NEXT pass's histogram at its destination tile with global
+// atomics, which saves the histogram launch: 19 us when the keys are spread, 150 us when a third of them are equal -- the
+// "no insert" requests of the apply order -- and the adds pile up on one counter.)
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -20,25 +22,22 @@
 namespace dust {
 namespace {
 
-constexpr uint32_t kThreads = 256, kWaves = kThreads / 64, kRounds = 8, kTile = kThreads * kRounds;  // 2048 items per workgroup
-constexpr uint32_t kMaxPasses = 4;
+constexpr uint32_t kThreads = 512, kWaves = kThreads / 64, kRounds = 16, kTile = kThreads * kRounds;  // 8192 items per workgroup: the
+// pool's 345 600 items are 43 tiles, so the [tile][digit] table every workgroup sums over stays a few thousand loads
 
 struct PassArgs {
   const uint32_t* keys_in;
   const uint32_t* vals_in;
   uint32_t* keys_out;
   uint32_t* vals_out;
-  uint32_t* hist;       // this pass: [tile][digit]
-  uint32_t* next_hist;  // the next pass's, or null
-  uint32_t n, n_tiles, shift, clear_words;
+  uint32_t* hist;       // [tile][digit]
+  uint32_t n, n_tiles, shift;
 };
 
 template <int BITS>
-__global__ void __launch_bounds__(kThreads) k_radix_first(PassArgs a) {
+__global__ void __launch_bounds__(kThreads) k_radix_histogram(PassArgs a) {
   __shared__ uint32_t bins[1 << BITS];
   for (uint32_t d = threadIdx.x; d < (1u << BITS); d += kThreads) bins[d] = 0;
-  // the histograms the scatter passes accumulate into (they follow this pass's in the scratch buffer)
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < a.clear_words; i += gridDim.x * kThreads) a.next_hist[i] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kTile;
 #pragma unroll
@@ -91,7 +90,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
   }
   __syncthreads();
   // (b) ranks
-  const uint32_t base = blockIdx.x * kTile + wave * (kRounds * 64u);  // a wave owns 512 consecutive items
+  const uint32_t base = blockIdx.x * kTile + wave * (kRounds * 64u);  // a wave owns 1024 consecutive items
   const uint64_t lower = (1ull << lane) - 1ull;
   uint32_t key[kRounds], val[kRounds], rank[kRounds];
 #pragma unroll
@@ -127,7 +126,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
     }
   }
   __syncthreads();
-  // (c) scatter, (d) the next digit's histogram at the destination tile
+  // (c) scatter
 #pragma unroll
   for (uint32_t r = 0; r < kRounds; ++r) {
     const uint32_t i = base + r * 64u + lane;
@@ -135,7 +134,6 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
       const uint32_t pos = cnt[wave][(key[r] >> a.shift) & (NB - 1u)] + rank[r];
       a.keys_out[pos] = key[r];
       a.vals_out[pos] = val[r];
-      if (a.next_hist) atomicAdd(&a.next_hist[(size_t)(pos / kTile) * NB + ((key[r] >> (a.shift + BITS)) & (NB - 1u))], 1u);
     }
   }
 }
@@ -143,23 +141,16 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
 template <int BITS>
 void run_passes(void* scratch, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t passes,
                 hipStream_t s) {
-  constexpr uint32_t NB = 1u << BITS;
   PassArgs p;
   p.n = n;
   p.n_tiles = (n + kTile - 1) / kTile;
-  uint32_t* hist = static_cast<uint32_t*>(scratch);
-  const size_t per_pass = (size_t)p.n_tiles * NB;
-  p.keys_in = keys_a; p.vals_in = vals_a; p.keys_out = keys_b; p.vals_out = vals_b;
-  p.hist = hist; p.next_hist = hist + per_pass; p.shift = 0;
-  p.clear_words = (uint32_t)(per_pass * (passes - 1));
-  hipLaunchKernelGGL(k_radix_first<BITS>, dim3(p.n_tiles), dim3(kThreads), 0, s, p);
+  p.hist = static_cast<uint32_t*>(scratch);
   bool from_a = true;
   for (uint32_t k = 0; k < passes; ++k) {
     p.keys_in = from_a ? keys_a : keys_b; p.vals_in = from_a ? vals_a : vals_b;
     p.keys_out = from_a ? keys_b : keys_a; p.vals_out = from_a ? vals_b : vals_a;
-    p.hist = hist + per_pass * k;
-    p.next_hist = k + 1 < passes ? hist + per_pass * (k + 1) : nullptr;
     p.shift = k * BITS;
+    hipLaunchKernelGGL(k_radix_histogram<BITS>, dim3(p.n_tiles), dim3(kThreads), 0, s, p);
     hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(p.n_tiles), dim3(kThreads), 0, s, p);
     from_a = !from_a;
   }
@@ -168,7 +159,7 @@ void run_passes(void* scratch, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 }  // namespace
 
 // bytes of scratch radix_sort_pairs needs for n items
-size_t radix_sort_scratch_bytes(uint32_t n) { return (size_t)((n + kTile - 1) / kTile) * (1u << 9) * sizeof(uint32_t) * kMaxPasses; }
+size_t radix_sort_scratch_bytes(uint32_t n) { return (size_t)((n + kTile - 1) / kTile) * (1u << 9) * sizeof(uint32_t); }
 
 // Stable sort of n pairs by the low `key_bits` bits of the key. Both buffer pairs are clobbered; *in_b says which one
 // holds the result (a: keys_a/vals_a, b: keys_b/vals_b). 8-bit digits for keys of up to 16 bits (two passes), 9-bit

@@ -17,6 +17,18 @@ def band_rows(rank: int, world: int, height: int, align: int = 8):
     return r0, r1
 
 
+def band_layout(rank: int, world: int, height: int, align: int = 8):
+    """How one frame is cut into `world` row bands for rendering AND for the gather: (per_rows, (r0, r1), (s0, s1)).
+    per_rows: common band height, a multiple of `align` (the 8-row ray packets); (r0, r1): the rows this rank renders -- shorter
+    than per_rows for the last band that reaches the frame's end, EMPTY (r0 == r1) for ranks past it; (s0, s1): the slice this
+    rank sends, in a render target padded to world * per_rows rows -- always per_rows rows, so every rank's send count is the
+    same (a gather with unequal counts is undefined under NCCL/RCCL). Rank 0 keeps the first `height` rows of the assembly."""
+    per = -(-height // world)
+    per = -(-per // align) * align
+    r0, r1 = min(height, rank * per), min(height, (rank + 1) * per)
+    return per, (r0, r1), (rank * per, (rank + 1) * per)
+
+
 def sample_frame_index(step: int, rank: int, world: int, first: int = 1) -> int:
     """frame_index of the sample rank `rank` renders in step `step` (frame_index starts at 1, standard.rs:252)."""
     return first + step * world + rank

@@ -51,7 +51,7 @@ def test_product_does_not_reference_the_oracle():
 
 def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
     text = open(os.path.join(ROOT, "bench.py")).read()
-    leg = text.index("if not args.no_cpu_baseline:")
+    leg = text.index("if not args.no_cpu_baseline")
     head = text[:leg]
     assert "import oracle_lib" not in head and "parity_util" not in head
     assert "import oracle_lib" in text[leg:]

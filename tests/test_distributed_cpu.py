@@ -119,6 +119,26 @@ WORKER = textwrap.dedent('''
         got = av.last()
         assert [tuple(x.shape) for x in got] == [(2, 4)] * world
         assert [int(x[0, 0]) for x in got] == [4000 + r for r in range(world)]
+    # --- bench.py --shard bands: render targets padded to world * per_rows rows, every rank gathers an EQUAL-size slice
+    # (its band padded to per_rows rows) straight from the target; heights where the last band is shorter (37 rows: 24 + 13)
+    # and where a rank's band is empty (8 rows: 8 + 0)
+    for Hb in (37, 8):
+        per, rows_b, send = sharding.band_layout(rank, world, Hb)
+        assert send[1] - send[0] == per and rows_b[1] - rows_b[0] <= per
+        full = P.render_oracle(s, cam, sky, W, Hb, passes, noise[1], 7)
+        tg = [torch.zeros((world * per, W, 4), dtype=torch.int32) for _ in range(2)]
+        bg = sharding.AsyncGather(dist, tg[0][send[0]:send[1]])
+        for k in range(3):
+            bg.wait_slot(k % 2)
+            if rows_b[0] < rows_b[1]:
+                gb = P.render_oracle(s, cam, sky, W, Hb, passes, noise[1], 7, rows=rows_b)
+                tg[k % 2][rows_b[0]:rows_b[1]] = torch.from_numpy(gb.illuminance[rows_b[0]:rows_b[1]].astype(np.int32))
+            bg.submit_view(tg[k % 2][send[0]:send[1]])
+        bg.finish()
+        if rank == 0:
+            frame = torch.cat(bg.last(), dim=0)[:Hb].numpy().astype(np.uint16)
+            assert np.array_equal(frame, full.illuminance), f"padded band gather != full frame at {Hb} rows"
+    if rank == 0:
         print("distributed ok")
     dist.barrier()
     dist.destroy_process_group()
@@ -128,6 +148,12 @@ WORKER = textwrap.dedent('''
 def test_band_rows_partition():
     sys.path.insert(0, ROOT)
     from dust_amd import sharding
+    for h, world in ((1080, 8), (1080, 2), (2160, 8), (37, 2), (8, 2), (20, 8)):
+        lay = [sharding.band_layout(r, world, h) for r in range(world)]
+        per = lay[0][0]
+        assert per % 8 == 0 and world * per >= h
+        assert [l[2] for l in lay] == [(r * per, (r + 1) * per) for r in range(world)]          # equal send slices
+        assert sum(l[1][1] - l[1][0] for l in lay) == h and all(l[1][0] <= l[1][1] for l in lay)  # bands tile the frame
     for h in (1080, 37, 8, 2160):
         for world in (1, 2, 4, 8):
             bands = [sharding.band_rows(r, world, h) for r in range(world)]
