@@ -135,6 +135,10 @@ SYMBOLS = {
     "dust_hip_sync": (C.c_int, [_P]),
     "dust_hip_model_create": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64, _P, C.c_uint32, C.POINTER(_P)]),
     "dust_hip_model_destroy": (None, [_P]),
+    "dust_hip_model_set_voxels": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "dust_hip_model_get_voxels": (C.c_int, [_P, _P, _P, C.c_uint32]),
+    "dust_hip_model_info": (C.c_int, [_P, _u32p, _u64p]),
+    "dust_hip_model_read": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
     "dust_hip_scene_create": (C.c_int, [_P, C.POINTER(_P)]),
     "dust_hip_scene_destroy": (None, [_P]),
     "dust_hip_scene_add_instance": (C.c_int, [_P, _P, _f32p, _f32p, _u32p]),

@@ -296,6 +296,30 @@ class Model:
             self._lib.dust_hip_model_destroy(self._h)
             self._h = None
 
+    def set_voxels(self, xyz, values):
+        """VoxGeometry::set on the device copy: xyz (n, 3) tree coordinates, values (n,) palette index or -1 to clear.
+        Scenes instancing the model must be committed again afterwards."""
+        xyz = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)
+        values = np.ascontiguousarray(values, np.int32).reshape(-1)
+        assert len(values) == len(xyz)
+        L.check(self._lib.dust_hip_model_set_voxels(self._h, _ptr(xyz), _ptr(values), len(values)))
+
+    def get_voxels(self, xyz):
+        """VoxGeometry::get: palette index per coordinate, -1 where the voxel is empty"""
+        xyz = np.ascontiguousarray(xyz, np.uint32).reshape(-1, 3)
+        out = np.zeros(len(xyz), np.int32)
+        L.check(self._lib.dust_hip_model_get_voxels(self._h, _ptr(xyz), _ptr(out), len(out)))
+        return out
+
+    def read(self):
+        """(blocks, materials) as they stand on the device"""
+        nb, nm = C.c_uint32(), C.c_uint64()
+        L.check(self._lib.dust_hip_model_info(self._h, C.byref(nb), C.byref(nm)))
+        blocks = np.zeros(max(nb.value, 1), BLOCK_DTYPE)
+        mats = np.zeros(max(nm.value, 1), np.uint8)
+        L.check(self._lib.dust_hip_model_read(self._h, _ptr(blocks), len(blocks), _ptr(mats), len(mats)))
+        return blocks[: nb.value], mats[: nm.value]
+
 
 class Scene:
     def __init__(self, ctx):

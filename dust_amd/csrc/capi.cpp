@@ -17,6 +17,8 @@
 #include "png.hpp"
 #include "vox.hpp"
 #include "sky.hpp"
+#include "edit.hpp"
+#include <unordered_set>
 
 namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
@@ -145,6 +147,13 @@ struct DustHipContext {
   bool timing = false;
   int num_cus = 256;
   size_t max_lds = 64 * 1024;
+  DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
+};
+
+// device-side voxel edits (edit.hip): the dense voxel grid and the scratch tables of the rebuild, created on a model's first edit
+struct EditState {
+  DeviceBuffer grid, brick_mask, flag_leaf, count_major, scan_tmp, header, xyz, values;
+  uint32_t batch_capacity = 0;
 };
 
 struct DustHipModel {
@@ -153,6 +162,9 @@ struct DustHipModel {
   std::vector<uint8_t> host_root;  // 640 B: mask + prefix, what the kernels stage in LDS
   dust::DevModel dev{};
   uint32_t id = 0;
+  uint64_t n_materials = 0;
+  uint32_t generation = 0;  // bumped by every edit: scenes record it at commit and refuse to render a stale copy
+  std::unique_ptr<EditState> edit;
 };
 
 struct HostInstance {
@@ -165,6 +177,7 @@ struct DustHipScene {
   DustHipContext* ctx = nullptr;
   std::vector<HostInstance> instances;
   std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
+  std::vector<uint32_t> model_generation;    // their edit generations when the scene was committed
   DeviceBuffer d_models, d_instances, d_root_table, d_boxes, d_visits;
   std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
@@ -643,11 +656,189 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     d.n_levels = tree_extent_log2 == 12 ? 3 : 2;
     d.n_blocks = n_blocks;
     d.lds_slot = -1;
+    m->n_materials = n_materials;
     *out = m.release();
     return DUST_OK;
   });
 }
 void dust_hip_model_destroy(DustHipModel* m) { delete m; }
+
+// ---------------------------------------------------------------- device-side edits (edit.hip)
+namespace {
+float linear2srgb_host(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * std::pow(c, 1.0f / 2.4f) - 0.055f; }  // geometry.rs:99-105
+
+DustStatus ensure_srgb_lut(DustHipContext* ctx) {
+  if (ctx->srgb_lut.p) return DUST_OK;
+  std::vector<uint16_t> lut(size_t(64) * dust::kSrgbRow, 0);
+  for (uint32_t n = 1; n <= 64; ++n) {
+    const float denom = float(n) * 255.0f;
+    for (uint32_t sum = 0; sum <= n * 255u; ++sum)
+      lut[size_t(n - 1) * dust::kSrgbRow + sum] = uint16_t(uint32_t(linear2srgb_host(float(sum) / denom) * 1023.0f));
+  }
+  HIP_TRY(ctx->srgb_lut.upload(lut.data(), lut.size() * 2));
+  return DUST_OK;
+}
+
+dust::EditArgs edit_args(DustHipModel* m) {
+  dust::EditArgs e{};
+  EditState& st = *m->edit;
+  e.grid = static_cast<uint8_t*>(st.grid.p);
+  e.brick_mask = static_cast<uint64_t*>(st.brick_mask.p);
+  e.flag_leaf = static_cast<uint32_t*>(st.flag_leaf.p);
+  e.count_major = static_cast<uint32_t*>(st.count_major.p);
+  e.scan_tmp = static_cast<uint32_t*>(st.scan_tmp.p);
+  e.blocks = static_cast<DustHipBlock*>(m->blocks.p);
+  e.materials = static_cast<uint8_t*>(m->materials.p);
+  e.palette = static_cast<const uint32_t*>(m->palette.p);
+  e.srgb_lut = static_cast<const uint16_t*>(m->ctx->srgb_lut.p);
+  e.root = static_cast<uint8_t*>(m->root.p);
+  e.mid = static_cast<dust::DevN4*>(m->mid.p);
+  e.dense_mask = static_cast<uint64_t*>(m->dense_mask.p);
+  e.header = static_cast<dust::EditHeader*>(st.header.p);
+  return e;
+}
+
+// run the rebuild kernels and bring the model record up to date (sizes, bounds, the root the scene stages in LDS)
+DustStatus rebuild_and_refresh(DustHipModel* m) {
+  hipStream_t st = m->ctx->stream;
+  HIP_TRY(dust::launch_edit_rebuild(edit_args(m), st));
+  dust::EditHeader h{};
+  HIP_TRY(hipMemcpyAsync(&h, m->edit->header.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  m->host_root.resize(dust::kN16LdsBytes);
+  HIP_TRY(hipMemcpyAsync(m->host_root.data(), m->root.p, dust::kN16LdsBytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  m->dev.n_blocks = h.n_blocks;
+  m->n_materials = h.n_materials;
+  std::memcpy(m->dev.bmin, h.bmin, sizeof(h.bmin));
+  std::memcpy(m->dev.bmax, h.bmax, sizeof(h.bmax));
+  m->generation += 1;
+  return DUST_OK;
+}
+
+// first edit: move the model into full-capacity buffers and expand its voxels into the dense grid
+DustStatus make_editable(DustHipModel* m) {
+  if (m->edit) return DUST_OK;
+  if (m->dev.extent != 256) return fail(DUST_ERR_UNSUPPORTED, "device-side edits cover hierarchy (4,2,2) models (256^3); rebuild larger trees with dust_hip_model_create");
+  DustStatus s = ensure_srgb_lut(m->ctx);
+  if (s != DUST_OK) return s;
+  hipStream_t st = m->ctx->stream;
+  std::unique_ptr<EditState> e(new EditState);
+  const size_t L = dust::kLattice;
+  HIP_TRY(e->grid.alloc(L * 64));
+  HIP_TRY(hipMemsetAsync(e->grid.p, 0, L * 64, st));
+  HIP_TRY(e->brick_mask.alloc(L * 8));
+  HIP_TRY(e->flag_leaf.alloc(L * 4));
+  HIP_TRY(e->count_major.alloc(L * 4));
+  HIP_TRY(e->scan_tmp.alloc(512 * 4));
+  HIP_TRY(e->header.alloc(sizeof(dust::EditHeader)));
+  DeviceBuffer blocks, materials, mid, dense_mask;
+  HIP_TRY(blocks.alloc(L * sizeof(DustHipBlock)));
+  HIP_TRY(materials.alloc(L * 64));
+  HIP_TRY(mid.alloc(4096 * sizeof(dust::DevN4)));
+  HIP_TRY(dense_mask.alloc(size_t(4096) * 64 * 8));
+  m->edit = std::move(e);
+  dust::EditArgs a = edit_args(m);
+  HIP_TRY(dust::launch_edit_expand(a, static_cast<const DustHipBlock*>(m->blocks.p), static_cast<const uint8_t*>(m->materials.p), m->dev.n_blocks, st));
+  HIP_TRY(hipStreamSynchronize(st));  // the old arrays are released below
+  std::swap(m->blocks.p, blocks.p); std::swap(m->blocks.bytes, blocks.bytes);
+  std::swap(m->materials.p, materials.p); std::swap(m->materials.bytes, materials.bytes);
+  std::swap(m->mid.p, mid.p); std::swap(m->mid.bytes, mid.bytes);
+  std::swap(m->dense_mask.p, dense_mask.p); std::swap(m->dense_mask.bytes, dense_mask.bytes);
+  m->dev.mid = static_cast<const dust::DevN4*>(m->mid.p);
+  m->dev.dense_mask = static_cast<const uint64_t*>(m->dense_mask.p);
+  m->dev.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
+  m->dev.materials = static_cast<const uint8_t*>(m->materials.p);
+  return rebuild_and_refresh(m);  // the same voxels, now in the full-capacity arrays
+}
+
+DustStatus upload_batch(DustHipModel* m, const uint32_t* xyz, const int32_t* values, uint32_t n, bool with_values) {
+  EditState& e = *m->edit;
+  if (n > e.batch_capacity) {
+    const uint32_t cap = std::max(n, 1024u);
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(e.xyz.alloc(size_t(cap) * 12));
+    HIP_TRY(e.values.alloc(size_t(cap) * 4));
+    e.batch_capacity = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(e.xyz.p, xyz, size_t(n) * 12, hipMemcpyHostToDevice, m->ctx->stream));
+  if (with_values) HIP_TRY(hipMemcpyAsync(e.values.p, values, size_t(n) * 4, hipMemcpyHostToDevice, m->ctx->stream));
+  return DUST_OK;
+}
+}  // namespace
+
+DustStatus dust_hip_model_set_voxels(DustHipModel* m, const uint32_t* xyz, const int32_t* values, uint32_t n) {
+  if (!m || (n && (!xyz || !values))) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  for (uint32_t i = 0; i < n; ++i) {
+    if (xyz[i * 3] >= m->dev.extent || xyz[i * 3 + 1] >= m->dev.extent || xyz[i * 3 + 2] >= m->dev.extent)
+      return fail(DUST_ERR_INVALID_ARGUMENT, "voxel coordinate outside the tree extent");
+    if (values[i] > 254) return fail(DUST_ERR_INVALID_ARGUMENT, "palette index must be 0..254 (or negative to clear the voxel)");
+  }
+  return guarded([&]() -> DustStatus {
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    DustStatus s = make_editable(m);
+    if (s != DUST_OK || n == 0) return s;
+    // a voxel named more than once takes its LAST value (what a sequence of set calls would leave): keep the last entry
+    std::vector<uint32_t> ux;
+    std::vector<int32_t> uv;
+    std::unordered_set<uint32_t> seen;
+    ux.reserve(size_t(n) * 3); uv.reserve(n);
+    for (uint32_t k = n; k-- > 0;) {
+      const uint32_t key = (xyz[k * 3] << 16) | (xyz[k * 3 + 1] << 8) | xyz[k * 3 + 2];
+      if (!seen.insert(key).second) continue;
+      ux.push_back(xyz[k * 3]); ux.push_back(xyz[k * 3 + 1]); ux.push_back(xyz[k * 3 + 2]);
+      uv.push_back(values[k]);
+    }
+    const uint32_t un = uint32_t(uv.size());
+    s = upload_batch(m, ux.data(), uv.data(), un, true);
+    if (s != DUST_OK) return s;
+    dust::EditArgs a = edit_args(m);
+    a.xyz = static_cast<const uint32_t*>(m->edit->xyz.p);
+    a.values = static_cast<const int32_t*>(m->edit->values.p);
+    a.n_edits = un;
+    HIP_TRY(dust::launch_edit_apply(a, false, m->ctx->stream));
+    return rebuild_and_refresh(m);  // synchronises: the host vectors above stay alive until the copies are done
+  });
+}
+
+DustStatus dust_hip_model_get_voxels(DustHipModel* m, const uint32_t* xyz, int32_t* values, uint32_t n) {
+  if (!m || (n && (!xyz || !values))) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  for (uint32_t i = 0; i < n; ++i)
+    if (xyz[i * 3] >= m->dev.extent || xyz[i * 3 + 1] >= m->dev.extent || xyz[i * 3 + 2] >= m->dev.extent)
+      return fail(DUST_ERR_INVALID_ARGUMENT, "voxel coordinate outside the tree extent");
+  return guarded([&]() -> DustStatus {
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    DustStatus s = make_editable(m);
+    if (s != DUST_OK || n == 0) return s;
+    s = upload_batch(m, xyz, nullptr, n, false);
+    if (s != DUST_OK) return s;
+    dust::EditArgs a = edit_args(m);
+    a.xyz = static_cast<const uint32_t*>(m->edit->xyz.p);
+    a.values_out = static_cast<int32_t*>(m->edit->values.p);
+    a.n_edits = n;
+    HIP_TRY(dust::launch_edit_apply(a, true, m->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(values, m->edit->values.p, size_t(n) * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return DUST_OK;
+  });
+}
+
+DustStatus dust_hip_model_info(const DustHipModel* m, uint32_t* n_blocks, uint64_t* n_materials) {
+  if (!m) return fail(DUST_ERR_INVALID_ARGUMENT, "null model");
+  if (n_blocks) *n_blocks = m->dev.n_blocks;
+  if (n_materials) *n_materials = m->n_materials;
+  return DUST_OK;
+}
+
+DustStatus dust_hip_model_read(const DustHipModel* m, DustHipBlock* blocks, uint32_t block_capacity, uint8_t* materials, uint64_t material_capacity) {
+  if (!m) return fail(DUST_ERR_INVALID_ARGUMENT, "null model");
+  if ((blocks && block_capacity < m->dev.n_blocks) || (materials && material_capacity < m->n_materials))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small (see dust_hip_model_info)");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  if (blocks && m->dev.n_blocks) HIP_TRY(hipMemcpy(blocks, m->blocks.p, size_t(m->dev.n_blocks) * sizeof(DustHipBlock), hipMemcpyDeviceToHost));
+  if (materials && m->n_materials) HIP_TRY(hipMemcpy(materials, m->materials.p, size_t(m->n_materials), hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
 
 DustStatus dust_hip_scene_create(DustHipContext* ctx, DustHipScene** out) {
   if (!ctx || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
@@ -765,6 +956,8 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       visits[i].pad[0] = visits[i].pad[1] = 0;
     }
     HIP_TRY(s->d_visits.upload(visits.data(), visits.size() * sizeof(dust::DevVisit)));
+    s->model_generation.clear();
+    for (const DustHipModel* m : s->models) s->model_generation.push_back(m->generation);
     s->committed = true;
     return DUST_OK;
   });
@@ -829,6 +1022,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   STRUCT_TRY(fp, "DustHipFrameParams");
   if (p->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "pipeline and scene belong to different contexts");
   if (!s->committed) return fail(DUST_ERR_NOT_READY, "scene has uncommitted changes (call dust_hip_scene_commit)");
+  for (size_t i = 0; i < s->models.size(); ++i)
+    if (s->models[i]->generation != s->model_generation[i])
+      return fail(DUST_ERR_NOT_READY, "a model of the scene was edited after the last dust_hip_scene_commit");
   const uint32_t need5 = DUST_PASS_AMBIENT_OCCLUSION | DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL;
   if ((fp->passes & need5) && !p->noise5.p)
     return fail(DUST_ERR_NOT_READY, "blue-noise texture 5 (unitvec3_cosine) not loaded");  // standard.rs:254

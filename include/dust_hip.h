@@ -183,6 +183,23 @@ DustStatus dust_hip_model_create(DustHipContext*, const DustHipBlock* blocks, ui
                                  const uint8_t* materials, uint64_t n_materials, const uint8_t* palette_rgba255x4,
                                  uint32_t tree_extent_log2, DustHipModel** out);
 void dust_hip_model_destroy(DustHipModel*);
+/* VoxGeometry::set / VoxGeometry::get (vox/src/geometry.rs:180-185; Tree::set_value / get_value, vdb/src/tree.rs:78-85) on the
+ * DEVICE copy of a hierarchy (4,2,2) model. The reference's set only touches the CPU tree -- a loaded model's GPU buffers never
+ * change -- so an edited voxel needs what that call does not carry, a material: values[i] >= 0 is Some(true) with palette
+ * index values[i] (0..254), values[i] < 0 is None (the voxel is removed; the reference's todo!() for clearing through internal
+ * nodes, node/internal.rs:121-124, does not apply: nothing is pointer-chased here). xyz: n coordinate triples in tree axes
+ * (what Tree::set_value takes), < 256 each; a voxel named twice takes its last value. The first edit of a model moves it into
+ * an editable form (a dense voxel grid on the device, ~44 MB); every batch then rewrites root, mid nodes, brick masks, Block
+ * records (material_ptr, avg_albedo) and the material stream on the GPU with scans over the brick lattice -- afterwards the
+ * device arrays are byte for byte what dust_hip_model_create builds from the same voxels. Asynchronous edits are not
+ * offered: the call returns when the model is rebuilt (it reads sizes and bounds back). Scenes that instance the model must
+ * be committed again (dust_hip_scene_commit) before they render: bounds and the staged root may have changed.
+ * DUST_ERR_UNSUPPORTED for 4096^3 models. */
+DustStatus dust_hip_model_set_voxels(DustHipModel*, const uint32_t* xyz, const int32_t* values, uint32_t n);
+DustStatus dust_hip_model_get_voxels(DustHipModel*, const uint32_t* xyz, int32_t* values /* palette index, or -1 = None */, uint32_t n);
+/* current size of a model's Block array and material stream, and a synchronous copy of both to the host */
+DustStatus dust_hip_model_info(const DustHipModel*, uint32_t* n_blocks, uint64_t* n_materials);
+DustStatus dust_hip_model_read(const DustHipModel*, DustHipBlock* blocks, uint32_t block_capacity, uint8_t* materials, uint64_t material_capacity);
 /* Lifetimes: a model must outlive every scene that instances it, a scene every frame in flight that renders it
  * (dust_hip_sync before destroying), a context everything created from it. Calls on one context are not thread-safe
  * against each other; dust_hip_last_error() is per thread. */
