@@ -25,6 +25,7 @@ PASS_AMBIENT_OCCLUSION = 1 << 1
 PASS_FINAL_GATHER = 1 << 2
 PASS_SURFEL = 1 << 3
 PASS_ACCUMULATE = 1 << 4
+PASS_DENOISE = 1 << 5
 PASS_COUNT_STATS = 1 << 16
 PASS_GI_ORDERED = 1 << 17
 PASS_GI_SHARDED = 1 << 18
@@ -75,6 +76,11 @@ class FrameParams(C.Structure):
 class ToneMapParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("transfer_function", C.c_uint32), ("color_space_conversion", C.c_float * 9),
                 ("min_log_luminance", C.c_float), ("max_log_luminance", C.c_float), ("time_coefficient", C.c_float)]
+
+
+class DenoiseParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_accumulated_frames", C.c_uint32), ("disocclusion_threshold", C.c_float),
+                ("antilag_sigma_scale", C.c_float), ("antilag_power", C.c_float), ("max_blur_radius", C.c_float)]
 
 
 class GiExchange(C.Structure):
@@ -160,6 +166,8 @@ SYMBOLS = {
     "dust_hip_tone_map": (C.c_int, [_P, C.POINTER(ToneMapParams)]),
     "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
+    "dust_hip_pipeline_set_denoiser": (C.c_int, [_P, C.POINTER(DenoiseParams)]),
+    "dust_hip_pipeline_restart_denoiser": (C.c_int, [_P]),
     "dust_hip_device_eval": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),
 }
 

@@ -412,6 +412,17 @@ class StandardPipeline:
     def clear(self):
         L.check(self._lib.dust_hip_pipeline_clear(self._h))
 
+    def set_denoiser(self, max_accumulated_frames=30, disocclusion_threshold=0.01, antilag_sigma_scale=2.0, antilag_power=0.8,
+                     max_blur_radius=15.0):
+        """ReblurSettings (nrd.rs:768-785) for DUST_PASS_DENOISE"""
+        dp = L.DenoiseParams(C.sizeof(L.DenoiseParams), max_accumulated_frames, disocclusion_threshold, antilag_sigma_scale,
+                             antilag_power, max_blur_radius)
+        L.check(self._lib.dust_hip_pipeline_set_denoiser(self._h, C.byref(dp)))
+
+    def restart_denoiser(self):
+        """DenoiserEvent::Restart"""
+        L.check(self._lib.dust_hip_pipeline_restart_denoiser(self._h))
+
     def tone_map(self, transfer_function=1, conversion=None, min_log=-6.0, max_log=8.5, time_coefficient=0.2):
         """AutoExposurePipeline + ToneMappingPipeline on the denoised plane -> PLANE_OUTPUT."""
         tp = L.ToneMapParams()

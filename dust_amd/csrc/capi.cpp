@@ -18,6 +18,7 @@
 #include "vox.hpp"
 #include "sky.hpp"
 #include "edit.hpp"
+#include "denoise.hpp"
 #include <unordered_set>
 
 namespace dust {
@@ -230,6 +231,13 @@ struct DustHipPipeline {
   uint32_t gi_capacity = 0, gi_pool_size = 0;
   uint32_t noise0_layers = 0, noise5_layers = 0;
   uint32_t accum_count = 0;
+  // DUST_PASS_DENOISE: two history sets used in turn {rgb + frame count (16 B), depth, normal, instance (4 B each)}, the camera
+  // of the frame that wrote the current one, and the filter's settings
+  DeviceBuffer hist_accum[2], hist_depth[2], hist_normal[2], hist_id[2];
+  uint32_t hist_parity = 0;
+  bool have_history = false;
+  dust::DevCamera prev_cam{};
+  DustHipDenoiseParams denoise{sizeof(DustHipDenoiseParams), 30, 0.01f, 2.0f, 0.8f, 15.0f};
   hipEvent_t ev[8] = {};
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
   bool stats_valid = false;
@@ -1195,6 +1203,41 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(dust::launch_accumulate(a, st));
     p->accum_count += 1;
   }
+  if (fp->passes & DUST_PASS_DENOISE) {
+    if (a.row_begin != 0 || a.row_end != p->height)
+      return fail(DUST_ERR_UNSUPPORTED, "DUST_PASS_DENOISE reprojects and blurs across rows: run it on the whole (gathered) frame");
+    const size_t px = size_t(p->width) * p->height;
+    if (!p->hist_accum[0].p) {
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(p->hist_accum[k].alloc(px * 16)); HIP_TRY(p->hist_depth[k].alloc(px * 4));
+        HIP_TRY(p->hist_normal[k].alloc(px * 4)); HIP_TRY(p->hist_id[k].alloc(px * 4));
+      }
+      p->have_history = false;
+    }
+    dust::DenoiseArgs d{};
+    d.illuminance = a.g.illuminance; d.denoised = a.g.denoised; d.normal = a.g.normal; d.depth = a.g.depth;
+    d.motion = a.g.motion; d.voxel_id = a.g.voxel_id;
+    const uint32_t in = p->hist_parity, out = in ^ 1u;
+    d.hist_in_accum = static_cast<const float*>(p->hist_accum[in].p); d.hist_in_depth = static_cast<const float*>(p->hist_depth[in].p);
+    d.hist_in_normal = static_cast<const uint32_t*>(p->hist_normal[in].p); d.hist_in_id = static_cast<const uint32_t*>(p->hist_id[in].p);
+    d.hist_out_accum = static_cast<float*>(p->hist_accum[out].p); d.hist_out_depth = static_cast<float*>(p->hist_depth[out].p);
+    d.hist_out_normal = static_cast<uint32_t*>(p->hist_normal[out].p); d.hist_out_id = static_cast<uint32_t*>(p->hist_id[out].p);
+    d.cam = a.cam; d.prev = p->prev_cam;
+    d.have_history = p->have_history ? 1u : 0u;
+    d.width = p->width; d.height = p->height; d.frame_index = fp->frame_index;
+    d.aspect = a.aspect;
+    d.max_frames = float(std::max(1u, p->denoise.max_accumulated_frames));
+    d.disocclusion = p->denoise.disocclusion_threshold;
+    d.antilag_sigma = p->denoise.antilag_sigma_scale;
+    d.antilag_power = p->denoise.antilag_power;
+    d.max_radius = p->denoise.max_blur_radius;
+    HIP_TRY(dust::launch_denoise(d, st));
+    // DUST_PLANE_ACCUM shows the temporal accumulation (rgb + frame count) of the frame just filtered
+    HIP_TRY(hipMemcpyAsync(p->plane(DUST_PLANE_ACCUM), d.hist_out_accum, px * 16, hipMemcpyDeviceToDevice, st));
+    p->hist_parity = out;
+    p->have_history = true;
+    p->prev_cam = a.cam;
+  }
   if (count) {
     HIP_TRY(hipMemcpyAsync(p->host_stats, p->stats.p, 8 * sizeof(dust::DevStats), hipMemcpyDeviceToHost, st));
     p->stats_valid = true;
@@ -1388,10 +1431,26 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
   HIP_TRY(hipMemcpy(out, dout.p, size_t(n) * out_words * 4, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
+DustStatus dust_hip_pipeline_set_denoiser(DustHipPipeline* p, const DustHipDenoiseParams* dp) {
+  if (!p || !dp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  STRUCT_TRY(dp, "DustHipDenoiseParams");
+  if (dp->max_accumulated_frames == 0 || !(dp->disocclusion_threshold > 0.0f) || !(dp->antilag_sigma_scale >= 0.0f) ||
+      !(dp->antilag_power >= 0.0f && dp->antilag_power <= 1.0f) || !(dp->max_blur_radius >= 0.0f && dp->max_blur_radius <= 64.0f))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "denoiser settings out of range");
+  p->denoise = *dp;
+  p->denoise.struct_size = sizeof(DustHipDenoiseParams);
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_restart_denoiser(DustHipPipeline* p) {
+  if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  p->have_history = false;  // DenoiserEvent::Restart (nrd.rs:749-755): the next frame starts a new accumulation
+  return DUST_OK;
+}
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
   for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->plane(i), 0, p->planes[i].bytes, p->ctx->stream));
+  p->have_history = false;
   p->accum_count = 0;
   return DUST_OK;
 }

@@ -232,7 +232,8 @@ typedef enum DustHipPlane {
   DUST_PLANE_DEPTH = 4,       /* R32F, 4 B/px */
   DUST_PLANE_MOTION = 5,      /* RGBA16F, 8 B/px */
   DUST_PLANE_VOXEL_ID = 6,    /* R32UI, 4 B/px */
-  DUST_PLANE_ACCUM = 7,       /* RGBA32F, 16 B/px: N-frame mean of unpacked illuminance (stands in for NRD) */
+  DUST_PLANE_ACCUM = 7,       /* RGBA32F, 16 B/px: accumulated unpacked illuminance + frame count (DUST_PASS_ACCUMULATE: plain
+                                 N-frame mean; DUST_PASS_DENOISE: the reprojected temporal accumulation) */
   DUST_PLANE_OUTPUT = 8,      /* RGBA16F, 8 B/px: tone-mapped display image (ToneMappingPipeline's dst) */
   DUST_PLANE_COUNT = 9
 } DustHipPlane;
@@ -243,6 +244,10 @@ typedef enum DustHipPlane {
 #define DUST_PASS_FINAL_GATHER (1u << 2)       /* standard.rs:627-640 */
 #define DUST_PASS_SURFEL (1u << 3)             /* standard.rs:712-725 */
 #define DUST_PASS_ACCUMULATE (1u << 4)         /* stands in for NRDPipeline::render (nrd.rs:272-617) */
+#define DUST_PASS_DENOISE (1u << 5)            /* NRDPipeline::render (nrd.rs:272-617) as a native spatiotemporal filter: temporal
+                                                  reprojection through the motion plane with disocclusion tests and antilag, then an
+                                                  edge-aware blur; writes img_illuminance_denoised (and DUST_PLANE_ACCUM: the temporal
+                                                  accumulation + frame count). Whole frames only. Settings: dust_hip_pipeline_set_denoiser */
 #define DUST_PASS_COUNT_STATS (1u << 16)       /* run the counting build of the kernels (slower) */
 #define DUST_PASS_GI_ORDERED (1u << 17)        /* apply the surfel pass's hash inserts in surfel-index order (bitwise
                                                   repeatable, serial); default: concurrently, as the reference's racy
@@ -337,7 +342,21 @@ typedef struct DustHipToneMapParams {
 DustStatus dust_hip_tone_map(DustHipPipeline*, const DustHipToneMapParams*);
 /* reads (and optionally first overwrites) the adapted average luminance the tone mapper divides by */
 DustStatus dust_hip_pipeline_exposure(DustHipPipeline*, float* avg_luminance, const float* set_to);
-/* zero every plane and the accumulation count */
+/* ReblurSettings + CommonSettings as far as this filter has the knob (nrd.rs:693-785; defaults = what the reference sets or
+ * NRD's own defaults): the reference's denoiser is NVIDIA NRD, a closed SDK -- DUST_PASS_DENOISE is a native filter of the same
+ * shape, not its arithmetic. */
+typedef struct DustHipDenoiseParams {
+  uint32_t struct_size;
+  uint32_t max_accumulated_frames; /* ReblurSettings::maxAccumulatedFrameNum, 30 */
+  float disocclusion_threshold;    /* CommonSettings::disocclusion_threshold, 0.01: plane distance / view distance */
+  float antilag_sigma_scale;       /* ReblurAntilagSettings::luminance_sigma_scale, 2.0 (nrd.rs:777) */
+  float antilag_power;             /* ReblurAntilagSettings::luminance_antilag_power, 0.8 (nrd.rs:778); 0 = no antilag */
+  float max_blur_radius;           /* ReblurSettings::blurRadius, 15 pixels; 0 = temporal accumulation only */
+} DustHipDenoiseParams;
+DustStatus dust_hip_pipeline_set_denoiser(DustHipPipeline*, const DustHipDenoiseParams*);
+/* DenoiserEvent::Restart (nrd.rs:749-755): discard the history; the next DUST_PASS_DENOISE frame starts a new accumulation */
+DustStatus dust_hip_pipeline_restart_denoiser(DustHipPipeline*);
+/* zero every plane, the accumulation count and the denoiser history */
 DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
 
 /* Device function evaluation: runs ONE of the device functions the traversal / shading kernels are built from on n

@@ -189,6 +189,31 @@ float orc_exposure_average(uint32_t hist[256], uint32_t w, uint32_t h, float min
 void orc_tone_map(const uint16_t* src, const uint32_t* albedo, uint32_t w, uint32_t h, float avg, const float conv[9], uint32_t tf,
                   uint16_t* dst);
 
+/* The product's spatiotemporal accumulation filter (dust_amd/csrc/denoise.hip), restated in denoise.c. PARITY UNPINNED
+ * against the reference: its denoiser is NVIDIA NRD, closed (nrd.rs:272-617). One frame: the temporal pass fills hist_out_*
+ * from hist_in_* and the current planes, the spatial pass writes `denoised` for hit pixels. */
+typedef struct OrcDenoise {
+  uint32_t width, height, frame_index, have_history;
+  OrcCamera cam, prev;
+  uint32_t max_accumulated_frames;
+  float disocclusion_threshold, antilag_sigma_scale, antilag_power, max_blur_radius;
+  const uint16_t* illuminance; /* 4 halves / px */
+  uint16_t* denoised;          /* 4 halves / px */
+  const uint32_t* normal;
+  const float* depth;
+  const uint16_t* motion;      /* 4 halves / px */
+  const uint32_t* voxel_id;
+  const float* hist_in_accum;  /* rgb + frame count */
+  const float* hist_in_depth;
+  const uint32_t* hist_in_normal;
+  const uint32_t* hist_in_id;
+  float* hist_out_accum;
+  float* hist_out_depth;
+  uint32_t* hist_out_normal;
+  uint32_t* hist_out_id;
+} OrcDenoise;
+void orc_denoise(const OrcDenoise*);
+
 /* encodings (headers/nrd.glsl, color.glsl, spatial_hash.glsl, normal.glsl) for unit tests */
 uint32_t orc_pack_rgb10a2(const float v[4]);
 void orc_unpack_rgb10a2(uint32_t p, float v[4]);

@@ -40,6 +40,17 @@ class OrcRayStats(C.Structure):
                 ("mid_descents", C.c_uint64), ("bricks_tested", C.c_uint64), ("hits", C.c_uint64)]
 
 
+class OrcDenoise(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("frame_index", C.c_uint32), ("have_history", C.c_uint32),
+                ("cam", OrcCamera), ("prev", OrcCamera), ("max_accumulated_frames", C.c_uint32),
+                ("disocclusion_threshold", C.c_float), ("antilag_sigma_scale", C.c_float), ("antilag_power", C.c_float),
+                ("max_blur_radius", C.c_float),
+                ("illuminance", C.c_void_p), ("denoised", C.c_void_p), ("normal", C.c_void_p), ("depth", C.c_void_p),
+                ("motion", C.c_void_p), ("voxel_id", C.c_void_p),
+                ("hist_in_accum", C.c_void_p), ("hist_in_depth", C.c_void_p), ("hist_in_normal", C.c_void_p), ("hist_in_id", C.c_void_p),
+                ("hist_out_accum", C.c_void_p), ("hist_out_depth", C.c_void_p), ("hist_out_normal", C.c_void_p), ("hist_out_id", C.c_void_p)]
+
+
 ORC_MODE_BRUTE, ORC_MODE_HIER = 0, 1
 _lib = None
 
@@ -121,6 +132,7 @@ def lib():
         l.orc_exposure_average.restype = C.c_float
         l.orc_exposure_average.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]
         l.orc_tone_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
+        l.orc_denoise.argtypes = [C.POINTER(OrcDenoise)]
         l.orc_pack_rgb10a2.restype = C.c_uint32
         l.orc_pack_rgb10a2.argtypes = [C.POINTER(C.c_float)]
         l.orc_unpack_rgb10a2.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
@@ -274,3 +286,39 @@ class GI:
         out, cnt = (C.c_float * 3)(), C.c_uint32()
         f = self.l.orc_hash_get(self.h, (C.c_int32 * 3)(*pos), direction, frame, out, C.byref(cnt))
         return bool(f), list(out), cnt.value
+
+
+class Denoiser:
+    """The oracle's copy of the spatiotemporal filter with its own history (oracle/denoise.c)."""
+
+    def __init__(self, w, h, max_frames=30, disocclusion=0.01, sigma=2.0, power=0.8, radius=15.0):
+        self.w, self.h = w, h
+        self.params = (max_frames, disocclusion, sigma, power, radius)
+        self.hist = [dict(accum=np.zeros((h, w, 4), np.float32), depth=np.zeros((h, w), np.float32),
+                          normal=np.zeros((h, w), np.uint32), id=np.zeros((h, w), np.uint32)) for _ in range(2)]
+        self.parity = 0
+        self.have = False
+        self.prev_cam = None
+
+    def frame(self, planes, cam, frame_index):
+        """planes: dict with illuminance, denoised (in: sky for misses), normal, depth, motion, voxel_id (numpy, as read from a
+        G-buffer). Returns (denoised plane, accumulation plane)."""
+        d = OrcDenoise()
+        d.width, d.height, d.frame_index, d.have_history = self.w, self.h, frame_index, 1 if self.have else 0
+        d.cam = camera_from(cam)
+        d.prev = self.prev_cam if self.prev_cam is not None else camera_from(cam)
+        d.max_accumulated_frames, d.disocclusion_threshold, d.antilag_sigma_scale, d.antilag_power, d.max_blur_radius = self.params
+        keep = {k: np.ascontiguousarray(planes[k]) for k in ("illuminance", "normal", "depth", "motion", "voxel_id")}
+        den = np.ascontiguousarray(planes["denoised"]).copy()
+        for k, v in keep.items():
+            setattr(d, k, v.ctypes.data)
+        d.denoised = den.ctypes.data
+        hin, hout = self.hist[self.parity], self.hist[self.parity ^ 1]
+        for k in ("accum", "depth", "normal", "id"):
+            setattr(d, "hist_in_" + k, hin[k].ctypes.data)
+            setattr(d, "hist_out_" + k, hout[k].ctypes.data)
+        lib().orc_denoise(C.byref(d))
+        self.parity ^= 1
+        self.have = True
+        self.prev_cam = camera_from(cam)
+        return den, hout["accum"].copy()
