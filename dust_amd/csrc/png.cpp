@@ -122,6 +122,11 @@ ImageArray load(const uint8_t* bytes, size_t n) {
   const uint32_t bpp = src_channels * img.bytes_per_channel;
   const size_t stride = size_t(img.width) * bpp;
   const size_t dst_px = size_t(img.channels) * img.bytes_per_channel;
+  // A file is untrusted input: IHDR and acTL alone must not decide how much memory is taken. Deflate expands at most ~1032:1,
+  // so a frame whose compressed stream is too short to inflate to (stride + 1) * height bytes is rejected before anything of
+  // that size is allocated.
+  for (uint32_t f = 0; f < num_frames; ++f)
+    if ((stride + 1) * img.height > streams[f].size() * 1032 + 1024) bad("image data too short for the announced size");
   img.texels.assign(size_t(num_frames) * img.height * img.width * dst_px, 0);
   std::vector<uint8_t> frame(stride * img.height);
   for (uint32_t f = 0; f < num_frames; ++f) {

@@ -85,7 +85,8 @@ def test_tone_map_gpu_matches_oracle(tf):
         fin = np.isfinite(a) & np.isfinite(b)   # the ACES fit dips below 0 for dark pixels: sqrt/log OETFs give NaN there
         assert (np.isfinite(a) != np.isfinite(b)).mean() < 1e-3
         rel = np.sqrt(((a[fin] - b[fin]) ** 2).sum()) / np.sqrt((a[fin] ** 2).sum())
-        assert rel <= 3e-3, (f, rel)
+        print('tone map rel L2', tf, f, rel)
+        assert rel <= 1e-3, (f, rel)   # north_star's tolerance
         avg = got_avg   # keep both sides on the same adaptation state
     # the accumulated mean really is the mean of the per-frame illuminance
     acc = pipe.read_plane(L.PLANE_ACCUM)
