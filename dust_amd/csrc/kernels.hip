@@ -603,12 +603,52 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       if (t * (1.0f - 2e-6f) > limit) return;
       if (any_hit && best.found) return;
     }
+    // The cell's lookup issues the one dependent memory access of the step (the brick mask). The step out of the cell
+    // needs none of it -- only the size of the cell, which the root lookup in LDS already decided -- so it is worked out
+    // HERE, while that load is in flight, into next-cell temporaries; the brick test and the neighbour visit then run on the
+    // current cell's state, and the temporaries are committed afterwards. Same operations in the same per-cell order as
+    // "test, visit neighbours, advance"; the load's latency is covered by ~100 instructions of the wave's own arithmetic.
+    uint32_t key;
+    PROF_ENTER(P_FIND);
+    const uint64_t mask = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true);
+    PROF_LEAVE(P_FIND);
+    // leave the cell of size 2^cl_main that contains ijk
+    PROF_ENTER(P_ADVANCE);
+    const int S = 1 << cl_main;
+    float ta[3], tn = INFINITY;
+    int cc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      cc[a] = ijk[a] & ~(S - 1);
+      if (dd[a] != 0.0f) {
+        const float plane = (float)(dd[a] > 0.0f ? cc[a] + S : cc[a]);
+        ta[a] = (plane - oo[a]) * inv[a];
+      } else {
+        ta[a] = INFINITY;
+      }
+      tn = fminf(tn, ta[a]);
+    }
+    const bool stuck = !(tn < INFINITY);
+    uint32_t next_stepped = 0;
+    int next_ijk[3];
+    bool outside = false, next_screen = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (ta[a] == tn) {
+        next_stepped |= 1u << a;
+        next_ijk[a] = dd[a] > 0.0f ? cc[a] + S : cc[a] - 1;
+        if (next_ijk[a] < 0 || next_ijk[a] >= E) outside = true;
+      } else {
+        const float p = oo[a] + dd[a] * tn;  // the next cell's entry point on an axis that does not cross a plane
+        next_ijk[a] = f2i_clamp(floorf(p), cc[a], cc[a] + S - 1);
+        const float r = p * 0.25f;
+        next_screen = next_screen | (fabsf(r - rintf(r)) <= near_tol);
+      }
+    }
+    next_screen = next_screen | (__popc(next_stepped) > 1);
+    PROF_LEAVE(P_ADVANCE);
     {
-      uint32_t key;
-      PROF_ENTER(P_FIND);
-      const uint64_t mask = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true);
       const bool have = mask != 0;
-      PROF_LEAVE(P_FIND);
       PROF_COUNT_LANES(P_L_TRIPS, true);
       PROF_COUNT_LANES(P_L_BRICK, have);
       PROF_COUNT_LANES(P_L_EMPTY4, !have && cl_main == 2);
@@ -631,42 +671,10 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       if (COUNT) st.bricks_tested += nv[7];
     }
     PROF_LEAVE(P_SCREEN);
-    // leave the cell of size 2^cl_main that contains ijk
-    PROF_ENTER(P_ADVANCE);
-    const int S = 1 << cl_main;
-    float ta[3], tn = INFINITY;
-    int cc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      cc[a] = ijk[a] & ~(S - 1);
-      if (dd[a] != 0.0f) {
-        const float plane = (float)(dd[a] > 0.0f ? cc[a] + S : cc[a]);
-        ta[a] = (plane - oo[a]) * inv[a];
-      } else {
-        ta[a] = INFINITY;
-      }
-      tn = fminf(tn, ta[a]);
-    }
-    if (!(tn < INFINITY)) { PROF_LEAVE(P_ADVANCE); return; }
-    stepped = 0;
-    bool outside = false;
-    screen = false;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (ta[a] == tn) {
-        stepped |= 1u << a;
-        ijk[a] = dd[a] > 0.0f ? cc[a] + S : cc[a] - 1;
-        if (ijk[a] < 0 || ijk[a] >= E) outside = true;
-      } else {
-        const float p = oo[a] + dd[a] * tn;  // the next cell's entry point on an axis that does not cross a plane
-        ijk[a] = f2i_clamp(floorf(p), cc[a], cc[a] + S - 1);
-        const float r = p * 0.25f;
-        screen = screen | (fabsf(r - rintf(r)) <= near_tol);
-      }
-    }
-    screen = screen | (__popc(stepped) > 1);
-    PROF_LEAVE(P_ADVANCE);
-    if (outside) return;
+    if (stuck || outside) return;
+    ijk[0] = next_ijk[0]; ijk[1] = next_ijk[1]; ijk[2] = next_ijk[2];
+    stepped = next_stepped;
+    screen = next_screen;
     t = fmaxf(t, tn);
     if (t * (1.0f - 2e-6f) > tx_stop) return;
   }
