@@ -159,7 +159,7 @@ struct EditState {
 
 struct DustHipModel {
   DustHipContext* ctx = nullptr;
-  DeviceBuffer root, l2, mid, dense_mask, blocks, materials, palette;
+  DeviceBuffer root, l2, l2_cells, mid, dense_mask, blocks, materials, palette;
   std::vector<uint8_t> host_root;  // 640 B: mask + prefix, what the kernels stage in LDS
   dust::DevModel dev{};
   uint32_t id = 0;
@@ -642,6 +642,30 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size()));
     m->host_root.assign(root.bytes.begin(), root.bytes.begin() + dust::kN16LdsBytes);
     HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size()));
+    if (tree_extent_log2 == 12) {  // the per-cell table the DEEP kernel variants look 16-cells up in: {mid index, child mask} per cell
+      const size_t n_l2 = l2.bytes.size() / dust::kN16Bytes;
+      std::vector<dust::DevL2Cell> cells(n_l2 * 4096, dust::DevL2Cell{0xFFFFFFFFu, 0u, 0ull});
+      for (size_t i = 0; i < n_l2; ++i) {
+        const uint64_t* mask = reinterpret_cast<const uint64_t*>(l2.node(i));
+        uint32_t base;
+        std::memcpy(&base, l2.node(i) + 640, 4);
+        uint32_t run = base;  // children of a node are contiguous, in ascending bit order
+        for (uint32_t w = 0; w < 64; ++w)
+          for (uint64_t bits = mask[w]; bits; bits &= bits - 1) {
+            dust::DevL2Cell& c = cells[i * 4096 + w * 64 + uint32_t(__builtin_ctzll(bits))];
+            c.mid = run;
+            c.child_mask = (uint64_t(mid[run].mask_hi) << 32) | mid[run].mask_lo;
+            uint32_t lo[3] = {3, 3, 3}, hi[3] = {0, 0, 0};
+            for (uint64_t cm = c.child_mask; cm; cm &= cm - 1) {
+              const uint32_t b = uint32_t(__builtin_ctzll(cm)), xyz[3] = {b >> 4, (b >> 2) & 3u, b & 3u};
+              for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], xyz[k]); hi[k] = std::max(hi[k], xyz[k]); }
+            }
+            c.bounds = lo[0] | (lo[1] << 2) | (lo[2] << 4) | (hi[0] << 6) | (hi[1] << 8) | (hi[2] << 10);
+            ++run;
+          }
+      }
+      HIP_TRY(m->l2_cells.upload(cells.data(), cells.size() * sizeof(dust::DevL2Cell)));
+    }
     HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4)));
     HIP_TRY(m->dense_mask.upload(dense_mask.data(), dense_mask.size() * 8));
     HIP_TRY(m->blocks.upload(blocks, size_t(n_blocks) * sizeof(DustHipBlock)));
@@ -653,6 +677,7 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     dust::DevModel& d = m->dev;
     d.root = static_cast<const uint8_t*>(m->root.p);
     d.l2 = tree_extent_log2 == 12 ? static_cast<const uint8_t*>(m->l2.p) : nullptr;
+    d.l2_cells = tree_extent_log2 == 12 ? static_cast<const dust::DevL2Cell*>(m->l2_cells.p) : nullptr;
     d.mid = static_cast<const dust::DevN4*>(m->mid.p);
     d.dense_mask = static_cast<const uint64_t*>(m->dense_mask.p);
     d.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
@@ -961,7 +986,6 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       visits[i].pad0 = visits[i].pad1 = 0.0f;
       std::memcpy(visits[i].w2o, di[i].w2o, sizeof(visits[i].w2o));
       visits[i].m = dm[di[i].model];
-      visits[i].pad[0] = visits[i].pad[1] = 0;
     }
     HIP_TRY(s->d_visits.upload(visits.data(), visits.size() * sizeof(dust::DevVisit)));
     s->model_generation.clear();
@@ -1088,6 +1112,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.accum_count = p->accum_count;
   const Tuning& tune = p->tune;
   a.debug = tune.debug;
+  for (const DustHipModel* m : s->models) a.deep |= m->dev.n_levels == 3 ? 1u : 0u;
+  if (tune.debug & 32u) a.deep = 0;  // DUST_HIP_DEBUG bit 32: 4096^3 models through the generic lookups of the two-level kernels
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;
   uint32_t bpc = tune.blocks_per_cu;

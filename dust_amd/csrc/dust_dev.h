@@ -47,6 +47,12 @@ struct DevN4 {
   uint32_t pad;
 };
 
+struct DevL2Cell {  // one 16^3 cell of a level-2 node, laid out for ONE 16-byte load: the mid node it holds and which of its 4^3 cells hold a brick
+  uint32_t mid;         // index into mid / dense_mask, 0xFFFFFFFF = empty 16-cell
+  uint32_t bounds;      // box of the occupied 4-cells in child coordinates 0..3: lo.x | lo.y<<2 | lo.z<<4 | hi.x<<6 | hi.y<<8 | hi.z<<10
+  uint64_t child_mask;  // the mid node's 64-bit child mask
+};
+
 struct DevModel {
   DUST_RO(uint8_t) root;          // N16
   DUST_RO(uint8_t) l2;            // N16[] or null
@@ -60,6 +66,9 @@ struct DevModel {
   uint32_t n_levels;            // internal levels: 2 (root,mid) or 3 (root,l2,mid)
   uint32_t n_blocks;
   int32_t lds_slot;             // slot of the staged root in LDS, -1 = read it from HBM/L2
+  DUST_RO(DevL2Cell) l2_cells;  // 4096^3 trees: [level-2 node][4096 cells], what the DEEP kernel variants look 16-cells up in
+                                // (268 MB when every 256-cell is occupied: sized for 288 GB of HBM, and within reach of the
+                                // 256 MB Infinity Cache); null for 256^3 trees
 };
 
 struct DevInstance {
@@ -76,7 +85,6 @@ struct DevVisit {  // what a ray needs to test and enter an instance, in one rec
   float hi[3], pad1;
   float w2o[12];
   DevModel m;
-  uint32_t pad[2];
 };
 
 struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, pad, hi.xyz, pad}
@@ -163,6 +171,7 @@ struct FrameArgs {
   uint32_t accum_count;       // frames already in `accum`
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
+  uint32_t deep;              // the scene holds a 4096^3 model with its per-cell table: launch the DEEP kernel variants
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in
                               // index order instead of the packet's sorted candidate list, 8: gather / surfel rays take the
                               // wave-uniform candidate walk of the coherent ray types); 0 in production

@@ -62,6 +62,11 @@ __shared__ unsigned long long g_dbg_mask[16];  // per wave: lanes being traced v
 #else
 #define DBG_PRINT(...)
 #endif
+// Kernel variants are selected by one template integer: bit 0 = the counting build (DUST_PASS_COUNT_STATS), bit 1 = the
+// scene holds a 4096^3 model (hierarchy (4,4,2,2)): its 16-cell lookups then go through the per-cell table (DevModel::l2_cells)
+// and the walk carries the 16-cell's child mask. Scenes without such a model run MODE 0 / 1: exactly the two-level code.
+#define COUNT ((MODE & 1) != 0)
+#define DEEP ((MODE & 2) != 0)
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
        P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
@@ -362,6 +367,7 @@ struct LaneStats {
 struct MidCache {  // the 16-cell the ray was last in and its mid-node index (saves the LDS root lookup)
   int key;
   uint32_t mid;
+  uint64_t mask4;  // DEEP variants only: which 4^3 cells of that 16-cell hold a brick (all ones for two-level models)
 };
 
 // Ray against an axis-aligned box, conservative (slack on both ends). inv = 1/d per component (IEEE divide). A zero
@@ -419,9 +425,10 @@ __device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, u
 // cell_log2 = size of the cell that was found empty (2 when a brick exists), key = mid_index*64 + child bit,
 // which orders bricks exactly like the block index does (both are depth-first).
 // One dependent memory access per call: root in LDS -> mid index -> dense_mask[mid*64 + bit].
-template <bool COUNT>
+// ray (DEEP variants): the object-space ray o + t d with inv_d = 1 / d, for the occupied-box test of a 16-cell
+template <int MODE>
 __device__ __forceinline__ uint64_t find_brick(ModelRef m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
-                                               MidCache& mc, LaneStats& st, bool count) {
+                                               MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d) {
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
   if (k16 != mc.key) {
     uint32_t mid_index;
@@ -435,14 +442,38 @@ __device__ __forceinline__ uint64_t find_brick(ModelRef m, int x, int y, int z, 
       if (!n16_child(m.root, m.lds_slot, idx, l2)) { cell_log2 = 8; return 0; }
       if (COUNT && count) st.upper_descents += 1;
       uint32_t idx2 = ((uint32_t)((x >> 4) & 15) << 8) | ((uint32_t)((y >> 4) & 15) << 4) | (uint32_t)((z >> 4) & 15);
-      if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return 0; }
-      if (COUNT && count) st.upper_descents += 1;
+      if (DEEP) {
+        // one 16-byte load instead of mask word -> rank prefix + base -> (per 4-cell) brick mask: the cell's mid index and
+        // its child mask arrive together, and the walk then crosses the 16-cell's empty 4-cells without touching memory
+        const u32x4 cell = *(DUST_RO(u32x4))(m.l2_cells + ((size_t)l2 * 4096u + idx2));
+        if (cell.x == 0xFFFFFFFFu) { cell_log2 = 4; return 0; }
+        if (COUNT && count) st.upper_descents += 1;
+        // At low occupancy a 16-cell holds one or two bricks in its 64 places. If the ray misses the box of the occupied
+        // 4-cells -- grown by 0.05 voxel, far more than the walk's own tolerance delta <= 1e-2, so nothing the conservative
+        // walk or its neighbour visits could test lies outside --, the whole 16-cell is crossed in one step like an empty one.
+        {
+          const float bx = (float)(x & ~15), by = (float)(y & ~15), bz = (float)(z & ~15);
+          const float lo[3] = {bx + 4.0f * (float)(cell.y & 3u) - 0.05f, by + 4.0f * (float)((cell.y >> 2) & 3u) - 0.05f,
+                               bz + 4.0f * (float)((cell.y >> 4) & 3u) - 0.05f};
+          const float hi[3] = {bx + 4.0f * (float)(((cell.y >> 6) & 3u) + 1u) + 0.05f, by + 4.0f * (float)(((cell.y >> 8) & 3u) + 1u) + 0.05f,
+                               bz + 4.0f * (float)(((cell.y >> 10) & 3u) + 1u) + 0.05f};
+          float te, tx;
+          if (!slab_box(ray_o, ray_d, ray_inv_d, lo, hi, te, tx)) { cell_log2 = 4; return 0; }
+        }
+        mid_index = cell.x;
+        mc.mask4 = ((uint64_t)cell.w << 32) | cell.z;
+      } else {
+        if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return 0; }
+        if (COUNT && count) st.upper_descents += 1;
+      }
     }
+    if (DEEP && m.n_levels == 2) mc.mask4 = ~0ull;  // a two-level model in a scene that also holds a deep one: every step looks its cell up
     mc.key = k16; mc.mid = mid_index;
   }
   const uint32_t bit = ((uint32_t)((x >> 2) & 3) << 4) | ((uint32_t)((y >> 2) & 3) << 2) | (uint32_t)((z >> 2) & 3);
   key = mc.mid * 64u + bit;
   cell_log2 = 2;
+  if (DEEP && !((mc.mask4 >> bit) & 1ull)) return 0;  // empty 4-cell, known without a load
   const uint64_t mask = m.dense_mask[key];
   if (COUNT && count && mask != 0) st.mid_descents += 1;
   return mask;
@@ -468,7 +499,7 @@ __device__ __forceinline__ DustHipBlock load_block(DUST_RO(DustHipBlock) p) {
 
 // run the ray type's intersection routine on one brick and apply Vulkan's accept rule
 // (tmin <= t <= current tmax; equal t: lower (instance, block) wins -- see oracle/shade.c header)
-template <int RT, bool COUNT>
+template <int RT, int MODE>
 __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_t key, int bx, int by, int bz, V3 o,
                                            V3 d, V3 inv_d, float tmin, float tmax, Hit& best, LaneStats& st) {
   V3 ol = mk(o.x - (float)bx, o.y - (float)by, o.z - (float)bz);  // hit.rint:137-140
@@ -494,7 +525,7 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
 // {t, inst, block, voxel, found, mc.key, mc.mid, bricks_tested}. (Structs by value go through the stack here, and a build
 // that passed Hit that way resolved equal-t ties between overlapping instances differently from the inlined code.)
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-template <int RT, bool COUNT>
+template <int RT, int MODE>
 __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS DevModel* mp, uint32_t inst, float ox, float oy, float oz,
                                                            float dx, float dy, float dz, float ix, float iy, float iz,
                                                            float tmin, float tmax, float t, int i0, int i1, int i2, uint32_t stepped,
@@ -505,7 +536,7 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
   Hit best;
   best.t = best_t; best.inst = best_inst; best.block = best_block; best.voxel = best_voxel; best.found = best_found != 0;
   MidCache mc;
-  mc.key = mc_key; mc.mid = mc_mid;
+  mc.key = DEEP ? -1 : mc_key; mc.mid = mc_mid; mc.mask4 = 0;  // DEEP: a private cache (the caller's child mask does not cross the call)
   LaneStats st = {0, 0, 0, 0, 0, 0};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   const int ijk[3] = {i0, i1, i2};
@@ -533,13 +564,13 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
       for (int a = 0; a < 3; ++a)
         if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
       uint32_t cl2, key;
-      const uint64_t mask = find_brick<COUNT>(m, c[0], c[1], c[2], cl2, key, mc, st, false);
-      if (mask != 0) test_brick<RT, COUNT>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      const uint64_t mask = find_brick<MODE>(m, c[0], c[1], c[2], cl2, key, mc, st, false, o, d, inv_d);
+      if (mask != 0) test_brick<RT, MODE>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
     }
   }
   u32x8 out;
   out[0] = __float_as_uint(best.t); out[1] = best.inst; out[2] = best.block; out[3] = best.voxel; out[4] = best.found ? 1u : 0u;
-  out[5] = (uint32_t)mc.key; out[6] = mc.mid; out[7] = st.bricks_tested;
+  out[5] = DEEP ? (uint32_t)mc_key : (uint32_t)mc.key; out[6] = DEEP ? mc_mid : mc.mid; out[7] = st.bricks_tested;
   return out;
 }
 
@@ -549,7 +580,7 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
 // delta of a brick-grid edge or corner every brick around it is tested too (DESIGN.md "Conservative walk").
 // One loop iteration handles one cell; when its entry point lies within delta of other brick planes, the bricks across
 // those planes (one per non-empty subset of the near axes) are tested by visit_neighbours before the walk advances.
-template <int RT, bool COUNT>
+template <int RT, int MODE>
 __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                                Hit& best, LaneStats& st) {
   PROF_ENTER(P_SETUP);
@@ -593,7 +624,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
   uint32_t cl_main = 2;
   MidCache mc;
-  mc.key = -1;
+  mc.key = -1; mc.mid = 0; mc.mask4 = 0;
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
@@ -610,7 +641,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     // "test, visit neighbours, advance"; the load's latency is covered by ~100 instructions of the wave's own arithmetic.
     uint32_t key;
     PROF_ENTER(P_FIND);
-    const uint64_t mask = find_brick<COUNT>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true);
+    const uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d);
     PROF_LEAVE(P_FIND);
     // leave the cell of size 2^cl_main that contains ijk
     PROF_ENTER(P_ADVANCE);
@@ -654,7 +685,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       PROF_COUNT_LANES(P_L_EMPTY4, !have && cl_main == 2);
       PROF_COUNT_LANES(P_L_EMPTY16, !have && cl_main > 2);
       PROF_ENTER(P_BRICK);
-      if (have) test_brick<RT, COUNT>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      if (have) test_brick<RT, MODE>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
       PROF_LEAVE(P_BRICK);
     }
     // Is the entry point within delta of further brick planes? `screen` (worked out when the walk stepped into this
@@ -663,7 +694,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     PROF_ENTER(P_SCREEN);
     if (__builtin_expect(screen, 0)) {
       PROF_COUNT(P_N_NEIGHBOUR_CALLS, 1);
-      const u32x8 nv = visit_neighbours<RT, COUNT>(&m, inst, o.x, o.y, o.z, d.x, d.y, d.z, inv_d.x, inv_d.y, inv_d.z, tmin, tmax, t,
+      const u32x8 nv = visit_neighbours<RT, MODE>(&m, inst, o.x, o.y, o.z, d.x, d.y, d.z, inv_d.x, inv_d.y, inv_d.z, tmin, tmax, t,
                                                    ijk[0], ijk[1], ijk[2], stepped, best.t, best.inst, best.block, best.voxel,
                                                    best.found ? 1u : 0u, mc.key, mc.mid);
       best.t = __uint_as_float(nv[0]); best.inst = nv[1]; best.block = nv[2]; best.voxel = nv[3]; best.found = nv[4] != 0;
@@ -794,7 +825,7 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
 }
 
 // any_hit: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (the sun shadow rays)
-template <int RT, bool COUNT>
+template <int RT, int MODE>
 __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, float tmax, bool any_hit,
                           const uint32_t* cand, uint32_t ncand, Hit& best, LaneStats& st) {
   PROF_ENTER(P_TRACE_RAY);
@@ -860,7 +891,7 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
           if (COUNT) st.instances_tested += 1;
           const DUST_CONST_AS DevVisit& v = a.visits[mine];
           PROF_ENTER(P_INSTANCE);
-          trace_instance<RT, COUNT>(v.m, mine, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin, tmax, any_hit, best, st);
+          trace_instance<RT, MODE>(v.m, mine, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin, tmax, any_hit, best, st);
           PROF_LEAVE(P_INSTANCE);
         }
       }
@@ -908,7 +939,7 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
     if (go) {
       if (COUNT) st.instances_tested += 1;
       PROF_ENTER(P_INSTANCE);
-      trace_instance<RT, COUNT>(v.m, ii, oo, od, tmin, tmax, any_hit, best, st);
+      trace_instance<RT, MODE>(v.m, ii, oo, od, tmin, tmax, any_hit, best, st);
       PROF_LEAVE(P_INSTANCE);
     }
   }
@@ -1050,7 +1081,7 @@ __device__ __forceinline__ void add_stats(LaneStats& d, const LaneStats& s) {
   d.rays += s.rays; d.instances_tested += s.instances_tested; d.upper_descents += s.upper_descents;
   d.mid_descents += s.mid_descents; d.bricks_tested += s.bricks_tested; d.hits += s.hits;
 }
-template <bool COUNT>
+template <int MODE>
 __device__ __forceinline__ void flush_stats(ArgsRef a, int slot, const LaneStats& st) {
   if (!COUNT) return;
   atomicAdd((unsigned long long*)&a.stats[slot].rays, (unsigned long long)st.rays);
@@ -1082,10 +1113,10 @@ __device__ __forceinline__ V3 camera_ray_dir(ArgsRef a, uint32_t px, uint32_t py
 // passes read back from the G-buffer: the hit distance (INFINITY on a miss) and the packed normal texel.
 // store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
 // occlusion pass overwrites the texel of every hit pixel anyway.
-template <bool COUNT>
+template <int MODE>
 __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
                                               float& hitT, uint32_t& normal_packed);
-template <bool COUNT>
+template <int MODE>
 __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
@@ -1093,13 +1124,13 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
   Hit h;
   h.found = false;
-  if (!(a.debug & 1u)) trace_ray<0, COUNT>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
+  if (!(a.debug & 1u)) trace_ray<0, MODE>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
   PROF_ENTER(P_PRIMARY_SHADE);
-  primary_shade<COUNT>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
+  primary_shade<MODE>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
   PROF_LEAVE(P_PRIMARY_SHADE);
 }
-template <bool COUNT>
+template <int MODE>
 __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
                                               float& hitT, uint32_t& normal_packed) {
   hitT = INFINITY;
@@ -1153,7 +1184,7 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
 // ==================================================================== sun shadow + ambient occlusion
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.
-template <bool COUNT>
+template <int MODE>
 __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st_sun, LaneStats& st_ao,
                                           float hitT, uint32_t normal_packed, V3 payload) {
   PROF_ENTER(P_AO_SETUP);
@@ -1187,7 +1218,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
     const float tmax = k == 0 ? 10000.0f : 8.0f;
     const uint32_t ncand = cull_instances(b, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
     LaneStats cur = {0, 0, 0, 0, 0, 0};
-    trace_ray<1, COUNT>(b, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
+    trace_ray<1, MODE>(b, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
     __builtin_amdgcn_wave_barrier();
     if (k == 0 && sun_live && !h.found) {  // final_gather/nee.rmiss:11-22; sun_term = sun radiance x (1 - cos(solar radius))
@@ -1198,7 +1229,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   if (live) store_radiance(reload_args(a).g.illuminance, pix, payload, h.found ? h.t : 0.0f);
 }
 
-template <bool COUNT>
+template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
@@ -1210,13 +1241,13 @@ __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     float hitT;
     uint32_t npk;
-    primary_packet<COUNT>(a, p, cand, st, true, hitT, npk);
+    primary_packet<MODE>(a, p, cand, st, true, hitT, npk);
   }
   prof_end();
-  flush_stats<COUNT>(a0, 0, st);
+  flush_stats<MODE>(a0, 0, st);
 }
 
-template <bool COUNT>
+template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
@@ -1235,18 +1266,18 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
       float w;
       payload = load_radiance(a.g.illuminance, pix, w);
     }
-    ao_packet<COUNT>(a, p, cand, st_sun, st_ao, hitT, npk, payload);
+    ao_packet<MODE>(a, p, cand, st_sun, st_ao, hitT, npk, payload);
   }
   prof_end();
-  flush_stats<COUNT>(a0, 0, st_sun);
-  flush_stats<COUNT>(a0, 1, st_ao);
+  flush_stats<MODE>(a0, 0, st_sun);
+  flush_stats<MODE>(a0, 1, st_ao);
 }
 
 // Fused primary + ambient occlusion passes: a pixel's AO pass reads only that pixel's own primary outputs, so the
 // wave that traced a packet's primary rays goes straight on to its shadow and AO rays with depth and normal still
 // in registers (as the quantised values the separate pass would load back). One launch, one LDS staging and one
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
-template <bool COUNT>
+template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
@@ -1257,13 +1288,13 @@ __global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs) {
   while (next_packet(a0, wc, p)) {
     float hitT;
     uint32_t npk;
-    primary_packet<COUNT>(reload_args(a0), p, cand, st, false, hitT, npk);
-    ao_packet<COUNT>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
+    primary_packet<MODE>(reload_args(a0), p, cand, st, false, hitT, npk);
+    ao_packet<MODE>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
   }
   prof_end();
-  flush_stats<COUNT>(a0, 0, st);
-  flush_stats<COUNT>(a0, 1, st_sun);
-  flush_stats<COUNT>(a0, 2, st_ao);
+  flush_stats<MODE>(a0, 0, st);
+  flush_stats<MODE>(a0, 1, st_sun);
+  flush_stats<MODE>(a0, 2, st_ao);
 }
 
 // ==================================================================== spatial hash (headers/spatial_hash.glsl)
@@ -1515,7 +1546,7 @@ __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
-template <bool COUNT>
+template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
@@ -1547,7 +1578,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
 #endif
     Hit h;
     const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
-    trace_ray<2, COUNT>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
+    trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
     __builtin_amdgcn_wave_barrier();
     ArgsRef ar = reload_args(a0);
     if (!live) continue;
@@ -1576,7 +1607,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
     store_radiance(ar.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
   }
   prof_end();
-  flush_stats<COUNT>(a0, 0, st);
+  flush_stats<MODE>(a0, 0, st);
 }
 
 // the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
@@ -1664,7 +1695,7 @@ __global__ void k_surfel_keys(const FrameArgs) {
 
 // ==================================================================== surfel pass, phase 1: trace + read the hash
 // surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
-template <bool COUNT>
+template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
@@ -1710,7 +1741,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
       const Range3 orgs = wave_range(live, org);
       const uint32_t ncand = cull_instances(a, __any(act), orgs, sun_item ? point_range(sd) : wave_range(live, dir), 10000.0f, cand);
       LaneStats cur = {0, 0, 0, 0, 0, 0};
-      trace_ray<3, COUNT>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
+      trace_ray<3, MODE>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
       if (COUNT) add_stats(sun_item ? st_sun : st_cos, cur);
       __builtin_amdgcn_wave_barrier();
     }
@@ -1761,8 +1792,8 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
     }
   }
   prof_end();
-  flush_stats<COUNT>(a0, 0, st_sun);
-  flush_stats<COUNT>(a0, 1, st_cos);
+  flush_stats<MODE>(a0, 0, st_sun);
+  flush_stats<MODE>(a0, 1, st_cos);
 }
 
 // ==================================================================== surfel pass, phase 2: apply in surfel order
@@ -2137,26 +2168,33 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
 
 // ==================================================================== launchers (called from capi.cpp)
 // `a` is the launch descriptor, passed to the kernels by value.
+// kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model)
+#define DUST_LAUNCH_MODE(kernel, count, a)                                                          \
+  do {                                                                                              \
+    switch (((count) ? 1 : 0) | ((a).deep ? 2 : 0)) {                                               \
+      case 0: hipLaunchKernelGGL(kernel<0>, dim3(grid), dim3(block), lds, s, a); break;             \
+      case 1: hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(block), lds, s, a); break;             \
+      case 2: hipLaunchKernelGGL(kernel<2>, dim3(grid), dim3(block), lds, s, a); break;             \
+      default: hipLaunchKernelGGL(kernel<3>, dim3(grid), dim3(block), lds, s, a); break;            \
+    }                                                                                               \
+  } while (0)
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
   return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 8u + 16u;  // roots, candidate lists, tile queue
 }
 
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(block), lds, s, a);
+  DUST_LAUNCH_MODE(k_primary, count, a);
   return hipGetLastError();
 }
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_primary_ao<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_primary_ao<false>, dim3(grid), dim3(block), lds, s, a);
+  DUST_LAUNCH_MODE(k_primary_ao, count, a);
   return hipGetLastError();
 }
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_ambient_occlusion<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_ambient_occlusion<false>, dim3(grid), dim3(block), lds, s, a);
+  DUST_LAUNCH_MODE(k_ambient_occlusion, count, a);
   return hipGetLastError();
 }
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t s) {
@@ -2173,8 +2211,7 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
 }
 hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_final_gather<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_final_gather<false>, dim3(grid), dim3(block), lds, s, a);
+  DUST_LAUNCH_MODE(k_final_gather, count, a);
   if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
@@ -2184,8 +2221,7 @@ hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {
 }
 hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a, block);
-  if (count) hipLaunchKernelGGL(k_surfel_trace<true>, dim3(grid), dim3(block), lds, s, a);
-  else hipLaunchKernelGGL(k_surfel_trace<false>, dim3(grid), dim3(block), lds, s, a);
+  DUST_LAUNCH_MODE(k_surfel_trace, count, a);
   return hipGetLastError();
 }
 // mode 0: concurrent (racy, as the reference); 1: serial in surfel order (one wavefront); 2: keys for the clustered apply;
@@ -2209,11 +2245,12 @@ hipError_t configure_kernels(size_t max_lds) {
 #ifdef DUST_TRACE_DEBUG
   max_lds -= 1024;
 #endif
-  const void* fns[] = {(const void*)k_primary<false>, (const void*)k_primary<true>,
-                       (const void*)k_ambient_occlusion<false>, (const void*)k_ambient_occlusion<true>,
-                       (const void*)k_primary_ao<false>, (const void*)k_primary_ao<true>,
-                       (const void*)k_final_gather<false>, (const void*)k_final_gather<true>,
-                       (const void*)k_surfel_trace<false>, (const void*)k_surfel_trace<true>};
+  const void* fns[] = {
+      (const void*)k_primary<0>, (const void*)k_primary<1>, (const void*)k_primary<2>, (const void*)k_primary<3>,
+      (const void*)k_ambient_occlusion<0>, (const void*)k_ambient_occlusion<1>, (const void*)k_ambient_occlusion<2>, (const void*)k_ambient_occlusion<3>,
+      (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>,
+      (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
+      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>};
   for (const void* f : fns) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;
