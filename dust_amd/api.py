@@ -400,6 +400,16 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_pipeline_read_plane(self._h, plane, _ptr(out), out.nbytes))
         return out
 
+    def tile_costs(self, pass_kind=0):
+        """cycles per tile of the pass's last launch, shape (tiles_y, tiles_x); None before the first launch"""
+        tx, ty = C.c_uint32(), C.c_uint32()
+        L.check(self._lib.dust_hip_pipeline_tile_costs(self._h, pass_kind, None, 0, C.byref(tx), C.byref(ty)))
+        if tx.value == 0:
+            return None
+        out = np.zeros((ty.value, tx.value), np.uint32)
+        L.check(self._lib.dust_hip_pipeline_tile_costs(self._h, pass_kind, _ptr(out), out.size, C.byref(tx), C.byref(ty)))
+        return out
+
     def plane_device_ptr(self, plane):
         p, n = C.c_void_p(), C.c_size_t()
         L.check(self._lib.dust_hip_pipeline_plane_device_ptr(self._h, plane, C.byref(p), C.byref(n)))

@@ -39,6 +39,7 @@ hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s);
 hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s);
 }  // namespace dust
 
@@ -195,6 +196,7 @@ struct Tuning {
   bool no_fuse = false;         // DUST_HIP_NO_FUSE: primary and AO passes as two launches (the reference's shape)
   bool no_gather_order = false; // DUST_HIP_NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
+  bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
   static uint32_t num(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
@@ -208,6 +210,7 @@ struct Tuning {
     t.no_fuse = std::getenv("DUST_HIP_NO_FUSE") != nullptr;
     t.no_gather_order = std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
+    t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
     return t;
   }
 };
@@ -221,6 +224,9 @@ struct DustHipPipeline {
   void* plane(int i) const { return bound[i] ? bound[i] : planes[i].p; }
   DeviceBuffer noise0, noise5, counters, stats;
   uint32_t counter_parity[4] = {0, 0, 0, 0};  // per pass kind: which of its two counter sets the next launch uses
+  // per pass kind: cycles each tile took in the pass's last launch and the hand-out order made from them (k_tile_order);
+  // valid for the tile grid they were recorded on
+  struct TileHistory { DeviceBuffer cost, order; uint32_t tiles_x = 0, tiles_y = 0, capacity = 0; bool recorded = false; } tile_history[4];
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
@@ -600,7 +606,7 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   if (const char* env = std::getenv("DUST_HIP_LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));
   // what a 512-thread workgroup needs besides the staged roots: 8 candidate lists, the tile queue, and the static
   // buckets of the profiling / debug builds (kernels.hip lds_bytes(), configure_kernels())
-  const size_t reserve = size_t(8) * dust::kMaxCand * 8 + 16 + 4096;
+  const size_t reserve = size_t(8) * (dust::kMaxCand * 8 + 8) + 16 + 4096;
   const size_t cap = c->max_lds > reserve ? c->max_lds - reserve : 0;
   if (c->lds_root_bytes > cap) c->lds_root_bytes = uint32_t(cap);
   HIP_TRY(dust::configure_kernels(c->max_lds));
@@ -1040,6 +1046,28 @@ extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_
 
 // Work counters without a memset per launch: every pass kind owns two sets; a launch pulls tiles from one and its
 // first workgroup zeroes the other, which is the set the next launch of that kind (stream-ordered behind it) will use.
+// Cost-ordered hand-out for the launch about to be made (kernels.hip, k_tile_order): orders the tiles by what the pass's
+// previous launch measured, if that was on the same tile grid, and has this launch measure again.
+static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a, hipStream_t st) {
+  a.tile_order = nullptr; a.tile_cost = nullptr;
+  if (p->tune.no_tile_order) return DUST_OK;
+  DustHipPipeline::TileHistory& h = p->tile_history[kind];
+  const uint32_t total = a.tiles_x * a.tiles_y;
+  if (total > h.capacity) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(h.cost.alloc(size_t(total) * 4)); HIP_TRY(h.order.alloc(size_t(total) * 4));
+    h.capacity = total; h.recorded = false;
+  }
+  if (h.recorded && h.tiles_x == a.tiles_x && h.tiles_y == a.tiles_y) {  // (k_tile_order also clears the costs it has read)
+    HIP_TRY(dust::launch_tile_order(static_cast<uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p), total, (total + dust::kRegions - 1) / dust::kRegions, st));
+    a.tile_order = static_cast<const uint32_t*>(h.order.p);
+  } else {
+    HIP_TRY(hipMemsetAsync(h.cost.p, 0, size_t(total) * 4, st));
+  }
+  a.tile_cost = static_cast<uint32_t*>(h.cost.p);
+  h.tiles_x = a.tiles_x; h.tiles_y = a.tiles_y; h.recorded = true;
+  return DUST_OK;
+}
 static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a) {
   uint32_t* base = static_cast<uint32_t*>(p->counters.p) + size_t(kind) * 2 * dust::kRegions * dust::kCounterStride;
   const uint32_t par = p->counter_parity[kind];
@@ -1117,7 +1145,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;
   uint32_t bpc = tune.blocks_per_cu;
-  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * dust::kMaxCand * 8 + 16;
+  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * (dust::kMaxCand * 8 + 8) + 16;
   if (lds > ctx->max_lds) return fail(DUST_ERR_INVALID_ARGUMENT, "staged roots and candidate lists exceed the device's LDS");
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
@@ -1144,6 +1172,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   p->fused_last = fuse;
   if (fuse) {
     take_counters(p, 0, a);
+    { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     HIP_TRY(dust::launch_primary_ao(a, grid, block, count, st));
@@ -1151,6 +1180,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     take_counters(p, 0, a);
+    { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
     HIP_TRY(dust::launch_primary(a, grid, block, count, st));
@@ -1158,6 +1188,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
     take_counters(p, 1, a);
+    { DustStatus os = order_tiles(p, 1, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
@@ -1184,6 +1215,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
     take_counters(p, 2, g);
+    { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
   }
@@ -1192,6 +1224,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
     b.tiles_y = 1;
     take_counters(p, 3, b);
+    { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
     uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
     uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
@@ -1455,6 +1488,18 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
   HIP_TRY(dust::launch_device_eval(fn, static_cast<const uint32_t*>(din.p), in_words, static_cast<uint32_t*>(dout.p), out_words, n, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out, dout.p, size_t(n) * out_words * 4, hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, uint32_t* cycles, uint32_t capacity, uint32_t* tiles_x, uint32_t* tiles_y) {
+  if (!p || pass_kind > 3) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass kind");
+  const DustHipPipeline::TileHistory& h = p->tile_history[pass_kind];
+  if (tiles_x) *tiles_x = h.recorded ? h.tiles_x : 0;
+  if (tiles_y) *tiles_y = h.recorded ? h.tiles_y : 0;
+  if (!cycles || !h.recorded) return DUST_OK;
+  if (capacity < h.tiles_x * h.tiles_y) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(hipMemcpy(cycles, h.cost.p, size_t(h.tiles_x) * h.tiles_y * 4, hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_set_denoiser(DustHipPipeline* p, const DustHipDenoiseParams* dp) {

@@ -162,6 +162,11 @@ struct FrameArgs {
   float inv_width, inv_height, aspect;  // RN(1 / width), RN(1 / height), RN(width / height): camera.glsl's divisions, done once
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
+  // Cost-ordered work distribution: every wave records the cycles it spent on each tile (tile_cost); before the next launch
+  // of the same pass k_tile_order turns that into tile_order -- per XCD band, most expensive first --, which maps ticket ->
+  // tile. Both null on the first frame of a pass (identity order) or when switched off.
+  DUST_RO(uint32_t) tile_order;
+  DUST_RW(uint32_t) tile_cost;
   DUST_RW(uint32_t) work_counters;    // 8 per-band tile counters, kCounterStride apart, zero at launch
   DUST_RW(uint32_t) next_work_counters;  // the set the next launch of this pass kind uses: this launch zeroes it
   DUST_RO(uint8_t) noise0;     // 128*128 R8 slice for this frame, or null

@@ -983,8 +983,21 @@ constexpr uint32_t kQueueDone = 0x80000000u;  // {end = 0, next >= kQueueDone}: 
 __device__ __forceinline__ unsigned long long* block_queue(ArgsRef a) {  // behind the per-wave candidate lists, zeroed by stage_roots
   return reinterpret_cast<unsigned long long*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u));
 }
+// The tile a wave is working on and when it started, in the wave's LDS slot behind the workgroup's queue: next_packet closes
+// the previous tile's account (cycles -> a.tile_cost) when the wave comes back for more. No register is carried for it.
+__device__ __forceinline__ void account_tile(ArgsRef a, uint32_t next_tile) {
+  if (!a.tile_cost) return;
+  if ((threadIdx.x & 63u) == 0) {
+    uint32_t* slot = reinterpret_cast<uint32_t*>(block_queue(a) + 2) + (threadIdx.x >> 6) * 2u;
+    const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime(), prev = slot[0];
+    if (prev != 0xFFFFFFFFu) a.tile_cost[prev] = now - slot[1];
+    slot[0] = next_tile; slot[1] = now;
+  }
+}
 __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t tile, Packet& p) {
   const uint32_t lane = threadIdx.x & 63u;
+  if (a.tile_order) tile = a.tile_order[tile];  // ticket -> tile, most expensive tiles of the band first
+  account_tile(a, tile);
   const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
   p.px = tx * 8u + (lane & 7u);
   p.py = a.row_begin + ty * 8u + (lane >> 3);
@@ -1010,13 +1023,14 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
     const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
     if (next < end) { packet_of_tile(a, next, p); PROF_LEAVE(P_GRAB); return true; }
-    if (end == 0u && next >= kQueueDone) { PROF_LEAVE(P_GRAB); return false; }
+    if (end == 0u && next >= kQueueDone) { account_tile(a, 0xFFFFFFFFu); PROF_LEAVE(P_GRAB); return false; }
     if (next != end) { __builtin_amdgcn_s_sleep(4); continue; }  // another wave is refilling
     // exactly empty: this wave refills. Own band first, then the others' (a band stays in one XCD's L2 while it lasts).
     uint32_t bt = (uint32_t)__builtin_amdgcn_readfirstlane((int)*band_try);
     for (;;) {
       if (bt >= kRegions) {
         if (lane == 0) *qv = (unsigned long long)kQueueDone;
+        account_tile(a, 0xFFFFFFFFu);
         PROF_LEAVE(P_GRAB);
         return false;
       }
@@ -1065,6 +1079,7 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
 #endif
   if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
   if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(block_queue(a))[threadIdx.x] = 0u;  // {next, end} = {0, 0}: empty; band_try = 0
+  if (threadIdx.x < (blockDim.x >> 6) * 2u) reinterpret_cast<uint32_t*>(block_queue(a) + 2)[threadIdx.x] = 0xFFFFFFFFu;  // per-wave tile accounts: none open
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
   const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
@@ -2168,6 +2183,74 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
 
 // ==================================================================== launchers (called from capi.cpp)
 // `a` is the launch descriptor, passed to the kernels by value.
+// ==================================================================== cost-ordered work distribution
+// A persistent launch ends when its LAST tile does, and tile costs are far from equal (a packet whose rays graze a dozen
+// instances takes several times the median): with tiles handed out in screen order the expensive ones that happen to be drawn
+// late leave most of the GPU idle while a few waves finish them -- a quarter of the fused kernel's time on the castle. Costs
+// barely change from one frame to the next (same view, or a slowly moving one), so each launch records per-tile cycles and the
+// next launch of the same pass hands its tiles out longest first: per band (the XCD affinity stays), a stable counting sort of
+// the band's tiles into 32 cost classes a quarter octave apart, most expensive class first. One workgroup per band, wave
+// ballots for the ranks (as radix.hip), ~5 us. The order only decides which wave traces which tile when -- never a result.
+__global__ void __launch_bounds__(1024) k_tile_order(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t total, uint32_t per) {
+  __shared__ uint32_t cnt[16][32];
+  __shared__ uint32_t wave_max[16];
+  const uint32_t lo = blockIdx.x * per < total ? blockIdx.x * per : total, hi = lo + per < total ? lo + per : total;
+  const uint32_t n = hi - lo, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  uint32_t mx = 1;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024u) mx = max(mx, cost[lo + i]);
+#pragma unroll
+  for (uint32_t d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, (int)d));
+  if (lane == 0) wave_max[wave] = mx;
+  if (threadIdx.x < 512) (&cnt[0][0])[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t w = 0; w < 16; ++w) mx = max(mx, wave_max[w]);
+  const float inv_max = 1.0f / (float)mx;
+  const uint32_t chunk = ((n + 15u) / 16u + 63u) & ~63u;  // a wave owns a contiguous run: (wave, round, lane) order is index order
+  const uint32_t begin = wave * chunk;
+  const uint64_t lower = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0 counts, pass 1 places
+    for (uint32_t r = 0; r < chunk; r += 64u) {
+      const uint32_t i = begin + r + lane;
+      const bool valid = i < n;
+      const uint32_t c = valid ? cost[lo + i] : 0u;
+      // class 0 = within a quarter octave of the band's most expensive tile, ..., 31 = 1/256 of it or less (or never timed)
+      const float cls = c ? -4.0f * __log2f((float)c * inv_max) : 31.0f;
+      const uint32_t digit = cls >= 31.0f ? 31u : (cls > 0.0f ? (uint32_t)cls : 0u);
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const uint32_t before = cnt[wave][digit];
+      const uint32_t rank = before + (uint32_t)__popcll(peers & lower);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (peers & lower) == 0) cnt[wave][digit] = before + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (pass == 1 && valid) {
+        order[lo + rank] = lo + i;
+        cost[lo + i] = 0u;  // the launch that follows measures afresh; a tile nobody times then counts as free
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      if (threadIdx.x == 0) {  // 512 counters: class-major, wave-minor exclusive prefix
+        uint32_t run = 0;
+        for (uint32_t d = 0; d < 32; ++d)
+          for (uint32_t w = 0; w < 16; ++w) { const uint32_t c = cnt[w][d]; cnt[w][d] = run; run += c; }
+      }
+      __syncthreads();
+    }
+  }
+}
+hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s) {
+  hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, total, per);
+  return hipGetLastError();
+}
+
 // kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model)
 #define DUST_LAUNCH_MODE(kernel, count, a)                                                          \
   do {                                                                                              \
@@ -2179,7 +2262,7 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
     }                                                                                               \
   } while (0)
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
-  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * kMaxCand * 8u + 16u;  // roots, candidate lists, tile queue
+  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * (kMaxCand * 8u + 8u) + 16u;  // roots, candidate lists + tile accounts, tile queue
 }
 
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
