@@ -39,7 +39,8 @@ hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s);
+constexpr uint32_t kTileOrderMaxBand = 65536;  // (kernels.hip)
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s);
 hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s);
 }  // namespace dust
 
@@ -184,6 +185,7 @@ struct DustHipScene {
   std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
   uint32_t n_lds_models = 0;
+  uint64_t revision = 0;  // bumped by every add / set_transform / commit (what the cost-ordered hand-out keys its view on)
   bool committed = false;
 };
 
@@ -226,7 +228,15 @@ struct DustHipPipeline {
   uint32_t counter_parity[4] = {0, 0, 0, 0};  // per pass kind: which of its two counter sets the next launch uses
   // per pass kind: cycles each tile took in the pass's last launch and the hand-out order made from them (k_tile_order);
   // valid for the tile grid they were recorded on
-  struct TileHistory { DeviceBuffer cost, order; uint32_t tiles_x = 0, tiles_y = 0, capacity = 0; bool recorded = false; } tile_history[4];
+  struct TileHistory {
+    DeviceBuffer cost, order;
+    uint32_t tiles_x = 0, tiles_y = 0, capacity = 0, age = 0;
+    uint64_t view = 0;       // view_key() of the launch the costs / the order were taken under
+    bool recorded = false;   // cost[] holds the previous launch's measurements
+    bool ordered = false;    // order[] is a valid permutation of this tile grid
+    bool measured = false;   // cost[] holds a launch's measurements (maybe not the last launch's)
+  } tile_history[4];
+  uint64_t view_key = 0;     // this frame's camera + scene revision + sun + row band
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
@@ -936,6 +946,7 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
   if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(s->ctx->device));
+    ++s->revision;
     s->models.clear();
     std::vector<dust::DevInstance> di(s->instances.size());
     for (size_t i = 0; i < s->instances.size(); ++i) {
@@ -1048,24 +1059,39 @@ extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_
 // first workgroup zeroes the other, which is the set the next launch of that kind (stream-ordered behind it) will use.
 // Cost-ordered hand-out for the launch about to be made (kernels.hip, k_tile_order): orders the tiles by what the pass's
 // previous launch measured, if that was on the same tile grid, and has this launch measure again.
+// While the view stands still (same camera, scene revision, sun and rows) the costs do too: the order is kept and re-measured
+// only every kOrderRefresh launches, which takes k_tile_order (~8 us) and the cost recording out of most frames; a moving view
+// measures and re-orders on every launch.
+constexpr uint32_t kOrderRefresh = 8;
 static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a, hipStream_t st) {
   a.tile_order = nullptr; a.tile_cost = nullptr;
   if (p->tune.no_tile_order) return DUST_OK;
   DustHipPipeline::TileHistory& h = p->tile_history[kind];
   const uint32_t total = a.tiles_x * a.tiles_y;
+  const uint32_t per_band = (total + dust::kRegions - 1) / dust::kRegions;
+  if (per_band > dust::kTileOrderMaxBand) return DUST_OK;  // beyond 8K: screen order
   if (total > h.capacity) {
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(h.cost.alloc(size_t(total) * 4)); HIP_TRY(h.order.alloc(size_t(total) * 4));
-    h.capacity = total; h.recorded = false;
+    h.capacity = total; h.tiles_x = h.tiles_y = 0;
   }
-  if (h.recorded && h.tiles_x == a.tiles_x && h.tiles_y == a.tiles_y) {  // (k_tile_order also clears the costs it has read)
-    HIP_TRY(dust::launch_tile_order(static_cast<uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p), total, (total + dust::kRegions - 1) / dust::kRegions, st));
-    a.tile_order = static_cast<const uint32_t*>(h.order.p);
-  } else {
+  if (h.tiles_x != a.tiles_x || h.tiles_y != a.tiles_y) {  // a new grid: tiles nobody has timed count as free
+    h.recorded = false; h.ordered = false; h.measured = false; h.tiles_x = a.tiles_x; h.tiles_y = a.tiles_y;
     HIP_TRY(hipMemsetAsync(h.cost.p, 0, size_t(total) * 4, st));
   }
-  a.tile_cost = static_cast<uint32_t*>(h.cost.p);
-  h.tiles_x = a.tiles_x; h.tiles_y = a.tiles_y; h.recorded = true;
+  if (h.recorded) {
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p), total, per_band, st));
+    h.recorded = false; h.ordered = true; h.age = 0;
+  } else if (h.ordered) {
+    ++h.age;
+  }
+  if (h.ordered) a.tile_order = static_cast<const uint32_t*>(h.order.p);
+  const bool still = h.ordered && h.view == p->view_key;
+  if (!still || h.age + 1 >= kOrderRefresh) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
+    a.tile_cost = static_cast<uint32_t*>(h.cost.p);
+    h.recorded = true; h.measured = true;
+  }
+  h.view = p->view_key;
   return DUST_OK;
 }
 static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a) {
@@ -1157,6 +1183,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
+  {  // FNV-1a over what decides a tile's cost
+    uint64_t k = 1469598103934665603ull;
+    auto mix = [&k](const void* data, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(data); for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
+    mix(cam, sizeof *cam); mix(&s, sizeof s); mix(&s->revision, sizeof s->revision); mix(sky->state, sizeof sky->state);
+    mix(&a.row_begin, sizeof a.row_begin); mix(&a.row_end, sizeof a.row_end);
+    p->view_key = k;
+  }
   a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);
   a.gi.hash_capacity = p->gi_capacity;
   a.gi.pool = static_cast<dust::DevSurfel*>(p->gi_pool.p);
@@ -1493,9 +1526,9 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
 DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, uint32_t* cycles, uint32_t capacity, uint32_t* tiles_x, uint32_t* tiles_y) {
   if (!p || pass_kind > 3) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass kind");
   const DustHipPipeline::TileHistory& h = p->tile_history[pass_kind];
-  if (tiles_x) *tiles_x = h.recorded ? h.tiles_x : 0;
-  if (tiles_y) *tiles_y = h.recorded ? h.tiles_y : 0;
-  if (!cycles || !h.recorded) return DUST_OK;
+  if (tiles_x) *tiles_x = h.measured ? h.tiles_x : 0;
+  if (tiles_y) *tiles_y = h.measured ? h.tiles_y : 0;
+  if (!cycles || !h.measured) return DUST_OK;
   if (capacity < h.tiles_x * h.tiles_y) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));

@@ -2191,20 +2191,27 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
 // next launch of the same pass hands its tiles out longest first: per band (the XCD affinity stays), a stable counting sort of
 // the band's tiles into 32 cost classes a quarter octave apart, most expensive class first. One workgroup per band, wave
 // ballots for the ranks (as radix.hip), ~5 us. The order only decides which wave traces which tile when -- never a result.
-__global__ void __launch_bounds__(1024) k_tile_order(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t total, uint32_t per) {
+constexpr uint32_t kTileOrderMaxBand = 65536;  // tiles per band the sorter stages in LDS (an 8K frame has 64 800)
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t total, uint32_t per) {
   __shared__ uint32_t cnt[16][32];
-  __shared__ uint32_t wave_max[16];
+  __shared__ uint32_t wave_part[16];
+  __shared__ uint8_t octave[kTileOrderMaxBand];  // quarter octaves of each tile's cost: the only pass over global memory
   const uint32_t lo = blockIdx.x * per < total ? blockIdx.x * per : total, hi = lo + per < total ? lo + per : total;
   const uint32_t n = hi - lo, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  uint32_t mx = 1;
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) mx = max(mx, cost[lo + i]);
+  uint32_t top = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
+    const uint32_t c = cost[lo + i];  // (stays: a launch that measures overwrites the tiles it traces, and the map can be read back)
+    const uint32_t q = c ? 1u + (uint32_t)(4.0f * __log2f((float)c)) : 0u;  // 0 = never timed, else 1 + floor(4 log2 c) <= 129
+    octave[i] = (uint8_t)q;
+    top = max(top, q);
+  }
 #pragma unroll
-  for (uint32_t d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, (int)d));
-  if (lane == 0) wave_max[wave] = mx;
+  for (uint32_t d = 32; d > 0; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, (int)d));
+  if (lane == 0) wave_part[wave] = top;
   if (threadIdx.x < 512) (&cnt[0][0])[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t w = 0; w < 16; ++w) mx = max(mx, wave_max[w]);
-  const float inv_max = 1.0f / (float)mx;
+  for (uint32_t w = 0; w < 16; ++w) top = max(top, wave_part[w]);
+  __syncthreads();
   const uint32_t chunk = ((n + 15u) / 16u + 63u) & ~63u;  // a wave owns a contiguous run: (wave, round, lane) order is index order
   const uint32_t begin = wave * chunk;
   const uint64_t lower = (1ull << lane) - 1ull;
@@ -2212,10 +2219,9 @@ __global__ void __launch_bounds__(1024) k_tile_order(uint32_t* __restrict__ cost
     for (uint32_t r = 0; r < chunk; r += 64u) {
       const uint32_t i = begin + r + lane;
       const bool valid = i < n;
-      const uint32_t c = valid ? cost[lo + i] : 0u;
+      const uint32_t q = valid ? octave[i] : 0u;
       // class 0 = within a quarter octave of the band's most expensive tile, ..., 31 = 1/256 of it or less (or never timed)
-      const float cls = c ? -4.0f * __log2f((float)c * inv_max) : 31.0f;
-      const uint32_t digit = cls >= 31.0f ? 31u : (cls > 0.0f ? (uint32_t)cls : 0u);
+      const uint32_t digit = q ? min(top - q, 31u) : 31u;
       uint64_t peers = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
@@ -2230,23 +2236,33 @@ __global__ void __launch_bounds__(1024) k_tile_order(uint32_t* __restrict__ cost
       if (valid && (peers & lower) == 0) cnt[wave][digit] = before + (uint32_t)__popcll(peers);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (pass == 1 && valid) {
-        order[lo + rank] = lo + i;
-        cost[lo + i] = 0u;  // the launch that follows measures afresh; a tile nobody times then counts as free
-      }
+      if (pass == 1 && valid) order[lo + rank] = lo + i;
     }
     __syncthreads();
-    if (pass == 0) {
-      if (threadIdx.x == 0) {  // 512 counters: class-major, wave-minor exclusive prefix
-        uint32_t run = 0;
-        for (uint32_t d = 0; d < 32; ++d)
-          for (uint32_t w = 0; w < 16; ++w) { const uint32_t c = cnt[w][d]; cnt[w][d] = run; run += c; }
+    if (pass == 0) {  // 512 counters -> exclusive prefix in class-major, wave-minor order: shuffles inside a wave, wave sums through LDS
+      uint32_t v = 0, inc = 0;
+      if (threadIdx.x < 512) {
+        v = cnt[threadIdx.x & 15u][threadIdx.x >> 4];
+        inc = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)inc, (int)d);
+          if (lane >= d) inc += up;
+        }
+        if (lane == 63) wave_part[wave] = inc;
+      }
+      __syncthreads();
+      if (threadIdx.x < 512) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_part[w];
+        cnt[threadIdx.x & 15u][threadIdx.x >> 4] = before + inc - v;
       }
       __syncthreads();
     }
   }
 }
-hipError_t launch_tile_order(uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s) {
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s) {
+  if (per > kTileOrderMaxBand) return hipErrorInvalidValue;  // (the caller keeps screen order for frames beyond 8K)
   hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, total, per);
   return hipGetLastError();
 }

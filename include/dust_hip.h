@@ -288,9 +288,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const Du
  * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
 /* Work distribution feedback. The traversal kernels are persistent launches whose tiles (8 x 8 pixel packets; 64-entry chunks of
- * the regrouped gather and surfel lists) cost very different amounts; every launch records the shader-clock cycles each tile took,
+ * the regrouped gather and surfel lists) cost very different amounts; a launch records the shader-clock cycles each tile took,
  * and the next launch of the same pass hands its tiles out most expensive first (per XCD band), so that the launch does not end on a
- * few late, slow tiles. The order never changes a result. This reads the map of the pass's last launch (a profiling heat map):
+ * few late, slow tiles. While camera, scene, sun and row band stay as they were the order is kept and re-measured every 8th launch
+ * only. The order never changes a result. This reads the map of the pass's last MEASURED launch (a profiling heat map):
  * pass_kind 0 primary (or fused primary + AO), 1 AO, 2 final gather, 3 surfel trace; cycles may be NULL to query the grid only
  * (tiles_x x tiles_y, 0 x 0 before the first launch). DUST_HIP_NO_TILE_ORDER=1 switches the feedback off. */
 DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline*, uint32_t pass_kind, uint32_t* cycles, uint32_t capacity, uint32_t* tiles_x,

@@ -7,6 +7,8 @@
 //   dust::VoxLoader::load      VoxLoader::load                      crates/vox/src/loader.rs:322-415
 //   dust::VoxGeometry          VoxGeometry (+ PaletteMaterial)      crates/vox/src/geometry.rs:30-179, material.rs:9-120
 //   dust::PinholeProjection    PinholeProjection                    crates/render/src/projection.rs:3-29
+//   dust::Sunlight             Sunlight + bake()                    crates/render/src/pipeline/sky.rs:6-23,90-132
+//   dust::ReblurSettings       ReblurSettings (the knobs this filter has)   crates/render/src/pipeline/nrd.rs:693-785
 //   dust::RenderContext        what RenderPlugin::build sets up     crates/render/src/lib.rs:58-134
 //   dust::Scene                TLASStore + instance vec             crates/render/src/accel_struct/tlas.rs:28-180
 //   dust::StandardPipeline     StandardPipeline + GBuffer           crates/render/src/pipeline/standard.rs:51-60,222-240,881-917
@@ -123,6 +125,26 @@ class VoxGeometry {
   ~VoxGeometry() { dust_hip_model_destroy(h_); }
   VoxGeometry(const VoxGeometry&) = delete;
   DustHipModel* raw() const { return h_; }
+  // VoxGeometry::set / get (geometry.rs:180-185) -- on the device copy, batched; Some(true) carries the palette index the
+  // voxel is shaded with (the reference's call edits the CPU tree only and has no material to give). Scenes that instance the
+  // geometry must commit() again before they render.
+  void set(const std::vector<UVec3>& coords, const std::vector<std::optional<uint8_t>>& palette_index) {
+    std::vector<uint32_t> xyz;
+    std::vector<int32_t> val;
+    for (size_t i = 0; i < coords.size(); ++i) {
+      xyz.insert(xyz.end(), coords[i].begin(), coords[i].end());
+      val.push_back(palette_index[i] ? int32_t(*palette_index[i]) : -1);
+    }
+    check(dust_hip_model_set_voxels(h_, xyz.data(), val.data(), uint32_t(val.size())));
+    uint64_t nm = 0;
+    check(dust_hip_model_info(h_, &num_blocks, &nm));
+  }
+  void set(UVec3 c, std::optional<uint8_t> palette_index) { set(std::vector<UVec3>{c}, {palette_index}); }
+  std::optional<uint8_t> get(UVec3 c) {
+    int32_t v = -1;
+    check(dust_hip_model_get_voxels(h_, c.data(), &v, 1));
+    return v < 0 ? std::nullopt : std::optional<uint8_t>(uint8_t(v));
+  }
   uint32_t num_blocks;
  private:
   DustHipModel* h_ = nullptr;
@@ -157,9 +179,11 @@ class VoxLoader {
   explicit VoxLoader(RenderContext& ctx) : ctx_(ctx) {}
   static std::vector<std::string> extensions() { return {"vox"}; }  // loader.rs:417-419
   // throws dust::Error{DUST_ERR_PARSE | DUST_ERR_UNSUPPORTED} like VoxLoadingError / unimplemented!()
-  VoxScene load(const uint8_t* bytes, size_t n) {
+  // frame: the animation frame MagicaVoxel keyframes (multi-frame nTRN, multi-model nSHP) are instantiated at; the reference
+  // stops at unimplemented!() for those files (loader.rs:103-105,149-151)
+  VoxScene load(const uint8_t* bytes, size_t n, uint32_t frame = 0) {
     DustVoxScene* s = nullptr;
-    check(dust_vox_load(bytes, n, &s));
+    check(dust_vox_load_frame(bytes, n, frame, &s));
     struct Guard { DustVoxScene* s; ~Guard() { dust_vox_scene_destroy(s); } } g{s};
     VoxScene out;
     uint32_t nm = 0, ni = 0;
@@ -238,6 +262,34 @@ inline DustHipCamera make_camera(const float eye[3], const std::array<float, 9>&
   return c;
 }
 
+// ----------------------------------------------------------------------------- Sunlight
+// The Hosek-Wilkie tables Sunlight::bake reads, as the bytes of the reference's dataset.bin / datasetSolar.bin (sky.rs:34-63)
+class SkyDataset {
+ public:
+  SkyDataset(const uint8_t* dataset_bin, size_t n, const uint8_t* dataset_solar_bin, size_t m) { check(dust_sky_dataset_create(dataset_bin, n, dataset_solar_bin, m, &h_)); }
+  ~SkyDataset() { dust_sky_dataset_destroy(h_); }
+  SkyDataset(const SkyDataset&) = delete;
+  const DustSkyDataset* raw() const { return h_; }
+ private:
+  DustSkyDataset* h_ = nullptr;
+};
+struct Sunlight {  // sky.rs:6-23
+  float turbidity = 1.0f;
+  std::array<float, 3> albedo{0.2f, 0.2f, 0.2f};
+  std::array<float, 3> direction{0.0f, 0.80114365f, -0.5984721f};
+  DustHipSky bake(const SkyDataset& d) const {  // sky.rs:90-132
+    DustHipSky s{};
+    check(dust_sky_bake(d.raw(), turbidity, albedo.data(), direction.data(), &s));
+    return s;
+  }
+};
+struct ReblurSettings {  // nrd.rs:768-785 + NRD defaults, as far as DUST_PASS_DENOISE has the knob
+  uint32_t max_accumulated_frame_num = 30;
+  float disocclusion_threshold = 0.01f;
+  float luminance_sigma_scale = 2.0f, luminance_antilag_power = 0.8f;
+  float blur_radius = 15.0f;
+};
+
 // ----------------------------------------------------------------------------- StandardPipeline
 class StandardPipeline {
  public:
@@ -267,6 +319,13 @@ class StandardPipeline {
     check(s);
     return true;
   }
+  // NRDPipeline settings / DenoiserEvent::Restart for DUST_PASS_DENOISE
+  void set_denoiser(const ReblurSettings& r) {
+    DustHipDenoiseParams dp{sizeof(DustHipDenoiseParams), r.max_accumulated_frame_num, r.disocclusion_threshold, r.luminance_sigma_scale,
+                            r.luminance_antilag_power, r.blur_radius};
+    check(dust_hip_pipeline_set_denoiser(h_, &dp));
+  }
+  void restart_denoiser() { check(dust_hip_pipeline_restart_denoiser(h_)); }
   void bind_plane(DustHipPlane plane, void* device_ptr, size_t bytes) { check(dust_hip_pipeline_bind_plane(h_, plane, device_ptr, bytes)); }
   template <class T>
   std::vector<T> read_plane(DustHipPlane plane) {

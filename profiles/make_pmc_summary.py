@@ -8,17 +8,20 @@ import re
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KEYS = {"k_primary_ao<false>": "primary_ao", "k_final_gather<false>": "final_gather", "k_surfel_trace<false>": "surfel_trace",
-        "k_primary<false>": "primary", "k_ambient_occlusion<false>": "ambient_occlusion"}
+# kernel<MODE>: MODE 0 = the timed two-level build, 2 = the DEEP build (4096^3 scenes); 1 / 3 are the counting builds
+KEYS = {"k_primary_ao<0>": "primary_ao", "k_final_gather<0>": "final_gather", "k_surfel_trace<0>": "surfel_trace",
+        "k_primary<0>": "primary", "k_ambient_occlusion<0>": "ambient_occlusion"}
+DEEP_KEYS = {"k_primary_ao<2>": "primary_ao", "k_final_gather<2>": "final_gather", "k_surfel_trace<2>": "surfel_trace"}
 
 
-def parse(path):
+def parse(path, keys=None):
+    keys = keys or KEYS
     out = {}
     for line in open(path):
         m = re.match(r"(.*?)\s+(\w+)\s+n=(\d+)\s+mean=\s*([\d.]+)", line)
         if not m:
             continue
-        for k, short in KEYS.items():
+        for k, short in keys.items():
             if k in m.group(1):
                 out.setdefault(short, {})[m.group(2)] = float(m.group(4))
     return out
@@ -50,5 +53,11 @@ if __name__ == "__main__":
         s["hbm_bytes_per_launch"][k] = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
         s["tcc_hit"][k] = int(v.get("TCC_HIT_sum", 0))
         s["tcc_miss"][k] = int(v.get("TCC_MISS_sum", 0))
+    deep = os.path.join(HERE, f"{tag}_pmc_deep.txt")
+    if os.path.exists(deep):
+        s["deep"] = {"workload": "procedural 4096^3, 1 % brick occupancy", "hbm_bytes_per_launch": {}}
+        for k, v in parse(deep, DEEP_KEYS).items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                s["deep"]["hbm_bytes_per_launch"][k] = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     json.dump(s, open(os.path.join(HERE, "pmc_summary.json"), "w"), indent=1)
     print(json.dumps(s["hbm_bytes_per_launch"]))

@@ -61,6 +61,21 @@ static int cpu_tests() {
     try { (void)dust::PngLoader::load(junk, sizeof(junk)); } catch (const dust::Error& e) { threw = e.status == DUST_ERR_PARSE; }
     EXPECT(threw);
   }
+  {  // Sunlight::bake needs the model's tables: sizes other than the reference's files are refused, not read out of bounds
+    bool threw = false;
+    std::vector<uint8_t> tiny(100);
+    try { dust::SkyDataset d(tiny.data(), tiny.size(), tiny.data(), tiny.size()); } catch (const dust::Error& e) { threw = e.status == DUST_ERR_INVALID_ARGUMENT; }
+    EXPECT(threw);
+    std::vector<float> ds(1200 * 3, 0.5f), sol(1806 * 3, 100.0f);
+    dust::SkyDataset d(reinterpret_cast<const uint8_t*>(ds.data()), ds.size() * 4, reinterpret_cast<const uint8_t*>(sol.data()), sol.size() * 4);
+    const DustHipSky sky = dust::Sunlight{}.bake(d);
+    EXPECT(sky.state[49] == 0.80114365f && sky.state[51] == 0.0f && sky.state[55] > 0.004f && sky.state[55] < 0.005f);
+    dust::Sunlight below;
+    below.direction = {0.0f, -0.5f, 0.8660254f};
+    threw = false;
+    try { (void)below.bake(d); } catch (const dust::Error&) { threw = true; }
+    EXPECT(threw);
+  }
   std::puts("cpu ok");
   return 0;
 }

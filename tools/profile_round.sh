@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ keeps for a round:
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r01'
+#   python tools/kernel_sections.py --build && gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
 # writes gpurun_out/<tag>_{gpu_tests.log,bench.log,bench_gi.log,kernel_stats.{txt,json},pmc.txt}.
 # Counter passes run separately from the kernel-trace/stats pass (one counter group per run).
 tag=${1:-r01}
@@ -17,6 +17,11 @@ python bench.py > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench.log" | cut -c1-600
 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_gi.log" | cut -c1-600
+python bench.py --workload deep --steps 30 > "$out/${tag}_bench_deep.log" 2>> "$out/${tag}_bench.err"
+tail -1 "$out/${tag}_bench_deep.log" | cut -c1-600
+python bench.py --shard bands > "$out/${tag}_bench_bands.log" 2>> "$out/${tag}_bench.err"
+python bench.py --workload gi --shard bands --no-cpu-baseline > "$out/${tag}_bench_gi_bands.log" 2>> "$out/${tag}_bench.err"
+python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
 
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
@@ -24,6 +29,10 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench -- \
     python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi -- \
     python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_prof.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_deep -- \
+    python "$R/bench.py" --workload deep --steps 10 --warmup 2 --no-cpu-baseline > "$out/${tag}_bench_deep_prof.log" 2>&1
+python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_deep_results.db') \
+    --json "$out/${tag}_kernel_stats_deep.json" > "$out/${tag}_kernel_stats_deep.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_results.db') \
     --json "$out/${tag}_kernel_stats.json" > "$out/${tag}_kernel_stats.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_gi_results.db') \
@@ -33,14 +42,18 @@ head -12 "$out/${tag}_kernel_stats.txt"
 groups=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"
         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY"
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE")
-for wl in primary_ao gi; do
+for wl in primary_ao gi deep; do
   for c in "${groups[@]}"; do
     n=$(echo $c | cut -d' ' -f1)
+    if [ $wl = deep ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ]; then continue; fi
     rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$tag" -o ${wl}_$n -- \
-        python "$R/bench.py" --workload $wl --steps 4 --warmup 1 --no-cpu-baseline > "$out/pmc_${wl}_$n.log" 2>&1
+        python "$R/bench.py" --workload $wl --steps 4 --warmup 2 --no-cpu-baseline > "$out/pmc_${wl}_$n.log" 2>&1
   done
 done
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'primary_ao_*_results.db' | sort) > "$out/${tag}_pmc.txt" 2>&1
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'gi_*_results.db' | sort) > "$out/${tag}_pmc_gi.txt" 2>&1
+python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'deep_*_results.db' | sort) > "$out/${tag}_pmc_deep.txt" 2>&1
+python "$R/tools/kernel_sections.py" > "$out/${tag}_sections.txt" 2>&1
+python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
