@@ -145,6 +145,38 @@ def test_fused_and_separate_launches_agree(ctx, noise5, monkeypatch):
         assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
 
 
+def test_tile_order_does_not_change_results(ctx, noise5, monkeypatch):
+    """Cost-ordered hand-out (k_tile_order): frames rendered with the measured order -- first launch in screen order, then
+    ordered, re-measured, kept on a still view, and again after the camera moves -- are bit-identical to screen-order
+    launches (DUST_HIP_NO_TILE_ORDER), and the heat map covers the tile grid."""
+    desc = P.small_scene(seed=13)
+    sky = P.sky_state()
+    cams = [P.camera_for((60.0, 90.0, 100.0)), P.camera_for((-40.0, 70.0, 120.0))]
+    scene = P.hip_scene(ctx, desc)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DUST_HIP_NO_TILE_ORDER", "1")
+        else:
+            monkeypatch.delenv("DUST_HIP_NO_TILE_ORDER", raising=False)
+        pipe = api.StandardPipeline(ctx, 203, 131)
+        pipe.set_noise(5, noise5)
+        frames = []
+        for f in range(12):  # 10 frames on one view (crosses the re-measure interval), then a moved camera
+            pipe.render(scene, cams[0 if f < 10 else 1], sky, passes, frame_index=f + 1, rand=7 + f)
+            if f in (0, 1, 2, 9, 10, 11):
+                frames.append(P.read_hip_gbuffer(pipe))
+        if not off:
+            costs = pipe.tile_costs(0)
+            assert costs.shape == ((131 + 7) // 8, (203 + 7) // 8) and costs.max() > 0
+        runs.append(frames)
+    monkeypatch.delenv("DUST_HIP_NO_TILE_ORDER", raising=False)
+    for a, b in zip(*runs):
+        for k in a:
+            assert a[k].tobytes() == b[k].tobytes(), k
+
+
 def test_repeatable(ctx, noise5):
     desc = P.small_scene(seed=8)
     sky = P.sky_state()
