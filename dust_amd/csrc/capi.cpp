@@ -199,6 +199,7 @@ struct Tuning {
   bool no_gather_order = false; // DUST_HIP_NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
+  bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
   static uint32_t num(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
@@ -213,6 +214,7 @@ struct Tuning {
     t.no_gather_order = std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
+    t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
     return t;
   }
 };
@@ -1171,8 +1173,14 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;
   uint32_t bpc = tune.blocks_per_cu;
-  const size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * (dust::kMaxCand * 8 + 8) + 16;
+  size_t lds = size_t(a.n_lds_models) * dust::kN16LdsBytes + (block / 64) * (dust::kMaxCand * 8 + 8) + 16;
   if (lds > ctx->max_lds) return fail(DUST_ERR_INVALID_ARGUMENT, "staged roots and candidate lists exceed the device's LDS");
+  // the instance boxes ride along when the workgroups of a CU still fit side by side (the packet cull reads all of them, per packet)
+  a.n_lds_boxes = 0;
+  if (!tune.no_lds_boxes && (lds + size_t(a.n_instances) * 32) * bpc <= 160 * 1024 && lds + size_t(a.n_instances) * 32 <= ctx->max_lds) {
+    a.n_lds_boxes = a.n_instances;
+    lds += size_t(a.n_instances) * 32;
+  }
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;
   // Workgroups per persistent launch: every slot of every CU, minus what the caller asks to be left free. The traversal

@@ -148,6 +148,7 @@ struct FrameArgs {
   DUST_RO(DevInstance) instances;
   uint32_t n_models, n_instances;
   uint32_t n_lds_models;      // roots staged in LDS: models[i].lds_slot == i for i < n_lds_models
+  uint32_t n_lds_boxes;       // n_instances if the instance boxes are staged in LDS too (32 B each, behind the queue), else 0
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}

@@ -774,11 +774,15 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n_inst = a.n_instances;
+  const bool in_lds = a.n_lds_boxes != 0;
+  const f32x4* lbox = reinterpret_cast<const f32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
   uint32_t n = 0;
   for (uint32_t base = 0; base < n_inst; base += 64) {
     const uint32_t i = base + lane;
     const uint32_t ic = i < n_inst ? i : n_inst - 1u;  // clamp instead of branching around the loads
-    const f32x4 blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]), bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]);
+    f32x4 blo, bhi;
+    if (in_lds) { blo = lbox[ic * 2u]; bhi = lbox[ic * 2u + 1u]; }
+    else { blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]); }
     const float wlo[3] = {blo.x, blo.y, blo.z}, whi[3] = {bhi.x, bhi.y, bhi.z};
     float t_lo = 0.0f, t_hi = tmax;
     bool pass = i < n_inst;
@@ -1055,6 +1059,9 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
   }
 }
 
+__device__ __forceinline__ u32x4* lds_boxes(ArgsRef a) {  // behind the queue and the per-wave tile accounts (16-byte aligned: every part before it is)
+  return reinterpret_cast<u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
+}
 __device__ __forceinline__ void prof_begin() {
 #ifdef DUST_PROFILE
   if ((threadIdx.x & 63u) == 0)
@@ -1085,6 +1092,11 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
   DUST_RO(u32x4) src = (DUST_RO(u32x4))a.root_table;
   for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<u32x4*>(g_lds)[i] = src[i];
+  {  // the instance boxes the packet cull streams through, when they fit as well
+    DUST_RO(u32x4) bsrc = (DUST_RO(u32x4))a.boxes;
+    u32x4* bdst = lds_boxes(a);
+    for (uint32_t i = threadIdx.x; i < a.n_lds_boxes * 2u; i += blockDim.x) bdst[i] = bsrc[i];
+  }
   __syncthreads();
   PROF_LEAVE(P_STAGE);
 }
@@ -2278,7 +2290,7 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t tot
     }                                                                                               \
   } while (0)
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
-  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * (kMaxCand * 8u + 8u) + 16u;  // roots, candidate lists + tile accounts, tile queue
+  return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * (kMaxCand * 8u + 8u) + 16u + (size_t)a.n_lds_boxes * 32u;  // roots, candidate lists + tile accounts, tile queue, boxes
 }
 
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
