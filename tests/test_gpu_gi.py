@@ -115,6 +115,10 @@ def test_surfel_position_sort_only_regroups(monkeypatch):
         assert np.array_equal(x, y)
 
 
+_SWITCHES = ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
+             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU")
+
+
 def _castle_gi_states(monkeypatch, settings, frames=3):
     """GI state + radiance plane after `frames` frames of the small castle (overlapping, lattice-aligned instances:
     equal-t ties between bricks of different instances are the rule there, not the exception)."""
@@ -128,7 +132,7 @@ def _castle_gi_states(monkeypatch, settings, frames=3):
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
     out = []
     for env in settings:
-        for k in ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT"):
+        for k in _SWITCHES:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -140,7 +144,7 @@ def _castle_gi_states(monkeypatch, settings, frames=3):
             pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(7, f))
         h, sp = pipe.read_gi()
         out.append((h, sp.view(np.uint32).copy(), pipe.read_plane(L.PLANE_ILLUMINANCE)))
-    for k in ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT"):
+    for k in _SWITCHES:
         monkeypatch.delenv(k, raising=False)
     return desc, cam, sky, n0, n5, out
 
@@ -149,10 +153,13 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     """Closest hit with the lower (instance, block) on equal t is a property of the ray, not of the order instances are
     visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4; every lane on its own instance vs the whole
     wave on one, bit 8) nor of which rays share a wavefront
-    (octant-ordered gather packets, position-ordered surfels). Caught a build whose out-of-line neighbour visit passed the
+    (octant-ordered gather packets, position-ordered surfels), which wave traces which tile when (cost-ordered hand-out), where
+    the cull reads its boxes from, or the launch shape. Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
     _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
-                                                       {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"}])
+                                                       {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
+                                                       {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
+                                                       {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"}])
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:
         for x, y in zip(st[0], other):
