@@ -249,11 +249,12 @@ struct DustHipPipeline {
   uint32_t gi_capacity = 0, gi_pool_size = 0;
   uint32_t noise0_layers = 0, noise5_layers = 0;
   uint32_t accum_count = 0;
-  // DUST_PASS_DENOISE: two history sets used in turn {rgb + frame count (16 B), depth, normal, instance (4 B each)}, the camera
+  // DUST_PASS_DENOISE: two history sets used in turn {rgb + frame count (16 B); depth, normal, instance as one 16 B record}, the camera
   // of the frame that wrote the current one, and the filter's settings
-  DeviceBuffer hist_accum[2], hist_depth[2], hist_normal[2], hist_id[2];
+  DeviceBuffer hist_accum[2], hist_geo[2];
   uint32_t hist_parity = 0;
   bool have_history = false;
+  bool hist_traded = true;  // the radiance history is DUST_PLANE_ACCUM's own buffer (not a caller-bound one)
   dust::DevCamera prev_cam{};
   DustHipDenoiseParams denoise{sizeof(DustHipDenoiseParams), 30, 0.01f, 2.0f, 0.8f, 15.0f};
   hipEvent_t ev[8] = {};
@@ -1300,6 +1301,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
+    if (fp->passes & DUST_PASS_DENOISE)
+      return fail(DUST_ERR_INVALID_ARGUMENT, "DUST_PASS_ACCUMULATE and DUST_PASS_DENOISE both keep their running result in DUST_PLANE_ACCUM: one per frame");
+    p->have_history = false;  // the plane now holds an N-frame mean, not the denoiser's history
     HIP_TRY(dust::launch_accumulate(a, st));
     p->accum_count += 1;
   }
@@ -1309,8 +1313,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     const size_t px = size_t(p->width) * p->height;
     if (!p->hist_accum[0].p) {
       for (int k = 0; k < 2; ++k) {
-        HIP_TRY(p->hist_accum[k].alloc(px * 16)); HIP_TRY(p->hist_depth[k].alloc(px * 4));
-        HIP_TRY(p->hist_normal[k].alloc(px * 4)); HIP_TRY(p->hist_id[k].alloc(px * 4));
+        HIP_TRY(p->hist_accum[k].alloc(px * 16)); HIP_TRY(p->hist_geo[k].alloc(px * 16));
       }
       p->have_history = false;
     }
@@ -1318,10 +1321,16 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     d.illuminance = a.g.illuminance; d.denoised = a.g.denoised; d.normal = a.g.normal; d.depth = a.g.depth;
     d.motion = a.g.motion; d.voxel_id = a.g.voxel_id;
     const uint32_t in = p->hist_parity, out = in ^ 1u;
-    d.hist_in_accum = static_cast<const float*>(p->hist_accum[in].p); d.hist_in_depth = static_cast<const float*>(p->hist_depth[in].p);
-    d.hist_in_normal = static_cast<const uint32_t*>(p->hist_normal[in].p); d.hist_in_id = static_cast<const uint32_t*>(p->hist_id[in].p);
-    d.hist_out_accum = static_cast<float*>(p->hist_accum[out].p); d.hist_out_depth = static_cast<float*>(p->hist_depth[out].p);
-    d.hist_out_normal = static_cast<uint32_t*>(p->hist_normal[out].p); d.hist_out_id = static_cast<uint32_t*>(p->hist_id[out].p);
+    // The radiance history lives in DUST_PLANE_ACCUM itself (it is what that plane shows while the denoiser runs): this frame
+    // reads the plane's buffer and writes the spare one, and the two then trade places -- no copy. A caller-bound plane cannot
+    // trade: it takes part as one side of an ordinary pair and receives a copy.
+    const bool trade = p->bound[DUST_PLANE_ACCUM] == nullptr;
+    d.hist_in_accum = static_cast<const float*>(trade ? p->planes[DUST_PLANE_ACCUM].p : p->hist_accum[in].p);
+    d.hist_out_accum = static_cast<float*>(trade ? p->hist_accum[0].p : p->hist_accum[out].p);
+    d.hist_in_geo = static_cast<const uint32_t*>(p->hist_geo[in].p);
+    d.hist_out_geo = static_cast<uint32_t*>(p->hist_geo[out].p);
+    if (trade != p->hist_traded) p->have_history = false;  // the plane was bound or released since the last frame: start over
+    p->hist_traded = trade;
     d.cam = a.cam; d.prev = p->prev_cam;
     d.have_history = p->have_history ? 1u : 0u;
     d.width = p->width; d.height = p->height; d.frame_index = fp->frame_index;
@@ -1333,7 +1342,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     d.max_radius = p->denoise.max_blur_radius;
     HIP_TRY(dust::launch_denoise(d, st));
     // DUST_PLANE_ACCUM shows the temporal accumulation (rgb + frame count) of the frame just filtered
-    HIP_TRY(hipMemcpyAsync(p->plane(DUST_PLANE_ACCUM), d.hist_out_accum, px * 16, hipMemcpyDeviceToDevice, st));
+    if (trade) { std::swap(p->planes[DUST_PLANE_ACCUM].p, p->hist_accum[0].p); std::swap(p->planes[DUST_PLANE_ACCUM].bytes, p->hist_accum[0].bytes); }
+    else HIP_TRY(hipMemcpyAsync(p->plane(DUST_PLANE_ACCUM), d.hist_out_accum, px * 16, hipMemcpyDeviceToDevice, st));
     p->hist_parity = out;
     p->have_history = true;
     p->prev_cam = a.cam;

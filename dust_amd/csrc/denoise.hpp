@@ -17,14 +17,10 @@ struct DenoiseArgs {
   const uint16_t* motion;       // IN_MV, world space (nrd.rs:763)
   const uint32_t* voxel_id;     // low 16 bits: instance
   // history: previous frame in, this frame out (two sets used in turn)
-  const float* hist_in_accum;   // rgb radiance + accumulated frame count
-  const float* hist_in_depth;
-  const uint32_t* hist_in_normal;
-  const uint32_t* hist_in_id;
+  const float* hist_in_accum;   // rgb radiance + accumulated frame count (16 B / px)
+  const uint32_t* hist_in_geo;  // what the taps are tested against, ONE 16-byte record / px: {depth bits, packed normal, instance, 0}
   float* hist_out_accum;
-  float* hist_out_depth;
-  uint32_t* hist_out_normal;
-  uint32_t* hist_out_id;
+  uint32_t* hist_out_geo;
   DevCamera cam, prev;
   uint32_t have_history, width, height, frame_index;
   float aspect;

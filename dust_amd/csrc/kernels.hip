@@ -22,6 +22,7 @@
 
 #define DUST_DEVICE_ADDRESS_SPACES 1
 #include "dust_dev.h"
+#include "exact_div.hpp"
 
 namespace dust {
 
@@ -102,26 +103,6 @@ __device__ __forceinline__ float gsign(float x) { return (float)((x > 0.0f) - (x
 __device__ __forceinline__ float gstep(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 __device__ __forceinline__ float gclamp(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-// a / b, correctly rounded, given y = RN(1 / b) (an IEEE division done once per instance and axis): Markstein's
-// sequence q0 = RN(a y), r = a - b q0 (exact in an FMA), q = RN(q0 + r y) yields RN(a / b) whenever nothing under- or
-// overflows. b == 0 (y infinite) takes q0 = a * (+-inf), which is what a / (+-0) is, NaN for a == 0 included.
-// Four instructions against the ten of the hardware division sequence, bit for bit the same quotient; direction
-// components in the denormal range (1 / b overflowing) are the one input class where it would differ.
-__device__ __forceinline__ float div_by(float a, float b, float y, bool y_inf) {
-  const float q0 = a * y;
-  const float r = __builtin_fmaf(-b, q0, a);
-  const float q = __builtin_fmaf(r, y, q0);
-  return y_inf ? q0 : q;
-}
-// The same sequence wherever the shaders divide: by a constant (y folds at compile time), or several numerators by one
-// divisor (one IEEE reciprocal instead of a division each). y zero, infinite or NaN (a divisor that is infinite, zero
-// or NaN) takes a * y, which is a / b in those cases too.
-__device__ __forceinline__ float div_const(float a, float c) {  // c: a literal
-  const float y = 1.0f / c;
-  const float q0 = a * y;
-  return __builtin_fmaf(__builtin_fmaf(-c, q0, a), y, q0);
-}
-__device__ __forceinline__ bool recip_special(float y) { return __builtin_amdgcn_classf(y, 0x267); }  // NaN, +-inf, +-0
 __device__ __forceinline__ V3 div3(V3 v, float b) {  // v / b
   const float y = 1.0f / b;
   const bool sp = recip_special(y);

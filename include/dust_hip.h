@@ -233,7 +233,9 @@ typedef enum DustHipPlane {
   DUST_PLANE_MOTION = 5,      /* RGBA16F, 8 B/px */
   DUST_PLANE_VOXEL_ID = 6,    /* R32UI, 4 B/px */
   DUST_PLANE_ACCUM = 7,       /* RGBA32F, 16 B/px: accumulated unpacked illuminance + frame count (DUST_PASS_ACCUMULATE: plain
-                                 N-frame mean; DUST_PASS_DENOISE: the reprojected temporal accumulation) */
+                                 N-frame mean; DUST_PASS_DENOISE: the reprojected temporal accumulation, which IS the filter's history:
+                                 the plane's device pointer then alternates between two buffers from frame to frame -- query it
+                                 per frame, or bind the plane -- and a frame may ask for one of the two passes, not both) */
   DUST_PLANE_OUTPUT = 8,      /* RGBA16F, 8 B/px: tone-mapped display image (ToneMappingPipeline's dst) */
   DUST_PLANE_COUNT = 9
 } DustHipPlane;
