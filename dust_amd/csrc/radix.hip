@@ -22,8 +22,9 @@
 namespace dust {
 namespace {
 
-constexpr uint32_t kThreads = 512, kWaves = kThreads / 64, kRounds = 16, kTile = kThreads * kRounds;  // 8192 items per workgroup: the
-// pool's 345 600 items are 43 tiles, so the [tile][digit] table every workgroup sums over stays a few thousand loads
+constexpr uint32_t kThreads = 512, kWaves = kThreads / 64, kRounds = 8, kTile = kThreads * kRounds;  // 4096 items per workgroup: the
+// pool's 345 600 items are 85 tiles (8192-item tiles, 43 workgroups, left most CUs idle: surfel pass +2 %; 2048-item tiles make the
+// [tile][digit] table every workgroup sums over four times as long: +2 %)
 
 struct PassArgs {
   const uint32_t* keys_in;
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
   }
   __syncthreads();
   // (b) ranks
-  const uint32_t base = blockIdx.x * kTile + wave * (kRounds * 64u);  // a wave owns 1024 consecutive items
+  const uint32_t base = blockIdx.x * kTile + wave * (kRounds * 64u);  // a wave owns kRounds * 64 consecutive items
   const uint64_t lower = (1ull << lane) - 1ull;
   uint32_t key[kRounds], val[kRounds], rank[kRounds];
 #pragma unroll
