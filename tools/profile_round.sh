@@ -53,6 +53,9 @@ done
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'primary_ao_*_results.db' | sort) > "$out/${tag}_pmc.txt" 2>&1
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'gi_*_results.db' | sort) > "$out/${tag}_pmc_gi.txt" 2>&1
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'deep_*_results.db' | sort) > "$out/${tag}_pmc_deep.txt" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o denoise -- \
+    python "$R/tools/denoise_timing.py" > "$out/${tag}_denoise_timing.log" 2>&1
+{ grep "GI frame" "$out/${tag}_denoise_timing.log"; python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'denoise_results.db') | grep -i "denoise\|kernel  "; } > "$out/${tag}_denoise_kernels.txt" 2>&1
 python "$R/tools/kernel_sections.py" > "$out/${tag}_sections.txt" 2>&1
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
