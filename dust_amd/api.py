@@ -400,6 +400,12 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_pipeline_read_plane(self._h, plane, _ptr(out), out.nbytes))
         return out
 
+    def kernel_times(self, mark=True):
+        """(ms_sum[4], launches[4]) per pass kind (primary/fused, AO, final gather, surfel pass) since the last mark"""
+        ms, n = (C.c_float * 4)(), (C.c_uint32 * 4)()
+        L.check(self._lib.dust_hip_pipeline_kernel_times(self._h, 1 if mark else 0, ms, n))
+        return list(ms), list(n)
+
     def tile_costs(self, pass_kind=0):
         """cycles per tile of the pass's last launch, shape (tiles_y, tiles_x); None before the first launch"""
         tx, ty = C.c_uint32(), C.c_uint32()

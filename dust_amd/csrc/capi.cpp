@@ -257,7 +257,13 @@ struct DustHipPipeline {
   bool hist_traded = true;  // the radiance history is DUST_PLANE_ACCUM's own buffer (not a caller-bound one)
   dust::DevCamera prev_cam{};
   DustHipDenoiseParams denoise{sizeof(DustHipDenoiseParams), 30, 0.01f, 2.0f, 0.8f, 15.0f};
-  hipEvent_t ev[8] = {};
+  // HIP-event pairs around the launches of the four pass kinds (primary or fused, AO, final gather, surfel pass), a ring per kind:
+  // the last pair is what dust_hip_pipeline_pass_stats reports, the pairs since the last mark what dust_hip_pipeline_kernel_times sums
+  static constexpr uint32_t kEvRing = 256;
+  std::vector<hipEvent_t> ev_ring[4][2];
+  uint32_t ev_head[4] = {0, 0, 0, 0}, ev_mark[4] = {0, 0, 0, 0};
+  hipEvent_t ev_begin(int kind) { return ev_ring[kind][0][ev_head[kind]++ % kEvRing]; }
+  hipEvent_t ev_end(int kind) { return ev_ring[kind][1][(ev_head[kind] - 1u) % kEvRing]; }
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
   bool stats_valid = false;
   bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
@@ -1035,14 +1041,21 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
     HIP_TRY(p->exposure.alloc(257 * 4));
     HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
     // timing only (nothing waits on them for visibility): without the system-scope fence a record does not flush L2 between passes
-    for (auto& e : p->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+    if (ctx->timing)
+      for (auto& kind : p->ev_ring)
+        for (auto& side : kind) {
+          side.assign(DustHipPipeline::kEvRing, nullptr);
+          for (auto& e : side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+        }
     *out = p.release();
     return DUST_OK;
   });
 }
 void dust_hip_pipeline_destroy(DustHipPipeline* p) {
   if (!p) return;
-  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& kind : p->ev_ring)
+    for (auto& side : kind)
+      for (auto& e : side) if (e) (void)hipEventDestroy(e);
   delete p;
 }
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
@@ -1216,25 +1229,25 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
     HIP_TRY(dust::launch_primary_ao(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[0], st));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
     HIP_TRY(dust::launch_primary(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[1], st)); p->ev_valid[0] = true; }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
     take_counters(p, 1, a);
     { DustStatus os = order_tiles(p, 1, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[2], st));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(1), st));
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[3], st)); p->ev_valid[1] = true; }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
     if (sharded) {  // pixels that stamp nothing must read 0 after the all-gather
@@ -1243,7 +1256,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[4], st));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
     dust::FrameArgs g = a;
     uint32_t ggrid = grid;
     if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
@@ -1259,7 +1272,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[5], st)); p->ev_valid[2] = true; }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
     dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
@@ -1272,7 +1285,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
     b.gi.sort_keys = sk[0];
     b.gi.sort_vals = sv[0];
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev[6], st));
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
     if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
       HIP_TRY(dust::launch_surfel_keys(b, st));
       bool in_b = false;
@@ -1298,7 +1311,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       b.gi.apply_vals = sv[in_b ? 1 : 0];
       HIP_TRY(dust::launch_surfel_apply(b, 3, st));
     }
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev[7], st)); p->ev_valid[3] = true; }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
     if (fp->passes & DUST_PASS_DENOISE)
@@ -1364,13 +1377,38 @@ DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustH
   const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : (pass == 3 ? 2 : 3));
   if (kernel >= 0 && p->ctx->timing && p->ev_valid[kernel]) {
     float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, p->ev[kernel * 2], p->ev[kernel * 2 + 1]));
+    const uint32_t slot = (p->ev_head[kernel] - 1u) % DustHipPipeline::kEvRing;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev_ring[kernel][0][slot], p->ev_ring[kernel][1][slot]));
     out->ms = ms;
   }
   if (p->stats_valid) {
     const dust::DevStats& s = p->host_stats[pass];
     out->rays = s.rays; out->instances_tested = s.instances_tested; out->upper_descents = s.upper_descents;
     out->mid_descents = s.mid_descents; out->bricks_tested = s.bricks_tested; out->hits = s.hits;
+  }
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline* p, int mark, float ms_sum[4], uint32_t launches[4]) {
+  if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  for (int k = 0; k < 4; ++k) {
+    double sum = 0.0;
+    uint32_t n = 0;
+    if (p->ctx->timing) {
+      const uint32_t head = p->ev_head[k];
+      uint32_t from = p->ev_mark[k];
+      if (head - from > DustHipPipeline::kEvRing) from = head - DustHipPipeline::kEvRing;  // older pairs have been recorded over
+      for (uint32_t i = from; i != head; ++i) {
+        const uint32_t slot = i % DustHipPipeline::kEvRing;
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev_ring[k][0][slot], p->ev_ring[k][1][slot]));
+        sum += ms; ++n;
+      }
+      if (mark) p->ev_mark[k] = head;
+    }
+    if (ms_sum) ms_sum[k] = float(sum);
+    if (launches) launches[k] = n;
   }
   return DUST_OK;
 }

@@ -289,6 +289,11 @@ DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const Du
  * When primary and AO passes are requested together they run as ONE fused kernel: its time is reported under
  * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
+/* Kernel time over a run of frames (DUST_HIP_CONTEXT_TIMING): per pass kind -- 0 primary (or the fused primary + AO kernel), 1 AO,
+ * 2 final gather (+ regroup, commit), 3 surfel pass (keys, sort, trace, apply) -- the summed HIP-event durations of its launches
+ * since the last call with mark != 0 (at most the 256 most recent ones), and how many launches that was. Waits for the stream.
+ * Nothing is synchronised per frame: the pairs are recorded into a ring on the launch stream and read here. */
+DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline*, int mark, float ms_sum[4], uint32_t launches[4]);
 /* Work distribution feedback. The traversal kernels are persistent launches whose tiles (8 x 8 pixel packets; 64-entry chunks of
  * the regrouped gather and surfel lists) cost very different amounts; a launch records the shader-clock cycles each tile took,
  * and the next launch of the same pass hands its tiles out most expensive first (per XCD band), so that the launch does not end on a
