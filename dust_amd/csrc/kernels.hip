@@ -511,29 +511,35 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
                                                            float dx, float dy, float dz, float ix, float iy, float iz,
                                                            float tmin, float tmax, float t, int i0, int i1, int i2, uint32_t stepped,
                                                            float best_t, uint32_t best_inst, uint32_t best_block, uint32_t best_voxel,
-                                                           uint32_t best_found, int mc_key, uint32_t mc_mid) {
+                                                           uint32_t best_found, int mc_key, uint32_t mc_mid, uint32_t cell_log2,
+                                                           uint32_t mc_mask_lo, uint32_t mc_mask_hi) {
   ModelRef m = *mp;
   const V3 o = mk(ox, oy, oz), d = mk(dx, dy, dz), inv_d = mk(ix, iy, iz);
   Hit best;
   best.t = best_t; best.inst = best_inst; best.block = best_block; best.voxel = best_voxel; best.found = best_found != 0;
   MidCache mc;
-  mc.key = DEEP ? -1 : mc_key; mc.mid = mc_mid; mc.mask4 = 0;  // DEEP: a private cache (the caller's child mask does not cross the call)
+  // DEEP: the caller's 16-cell comes along with its child mask, so a neighbour inside the same 16-cell (three brick planes in
+  // four are) is known to be empty without a lookup; the caller keeps its own cache whatever this call moves on to
+  mc.key = mc_key; mc.mid = mc_mid; mc.mask4 = DEEP ? ((uint64_t)mc_mask_hi << 32) | mc_mask_lo : 0ull;
   LaneStats st = {0, 0, 0, 0, 0, 0};
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   const int ijk[3] = {i0, i1, i2};
-  uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the brick's low / high plane on axis a
+  uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the cell's low / high plane on axis a
   uint32_t unstepped_near = 0;
+  const int G = DEEP && cell_log2 >= 4u ? 16 : 4;  // (the two-level kernels keep the constant: the refinement below is the DEEP variants')
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int blo = (int)m.bmin[a], bhi = (int)m.bmax[a] - 1;  // voxel range that holds bricks (tight bounds, multiples of 4)
     const float p = oo[a] + dd[a] * t;
     const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
-    const int b0 = ijk[a] & ~3;
+    // The cell the walk is in: a brick cell, or an empty 16-cell (or a larger one, or a 16-cell whose bricks the ray misses
+    // by more than any delta: DEEP) -- nothing inside THAT can be hit, so only its own faces have bricks behind them.
+    const int b0 = ijk[a] & ~(G - 1);
     const float q = p - (float)b0;
     // a plane only matters if bricks can exist on its far side
-    if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo) near_neg |= 1u << a; } else if (b0 + 4 <= bhi) near_pos |= 1u << a; }
+    if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo) near_neg |= 1u << a; } else if (b0 + G <= bhi) near_pos |= 1u << a; }
     else if (q <= delta) { if (b0 - 1 >= blo) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
-    else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+    else if (q >= (float)G - delta) { if (b0 + G <= bhi) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
   }
   const uint32_t nearm = near_neg | near_pos;
   if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
@@ -543,7 +549,7 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
       int c[3] = {ijk[0], ijk[1], ijk[2]};
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-        if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
+        if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~(G - 1)) - 1 : (ijk[a] & ~(G - 1)) + G;
       uint32_t cl2, key;
       const uint64_t mask = find_brick<MODE>(m, c[0], c[1], c[2], cl2, key, mc, st, false, o, d, inv_d);
       if (mask != 0) test_brick<RT, MODE>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
@@ -624,6 +630,21 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     PROF_ENTER(P_FIND);
     const uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d);
     PROF_LEAVE(P_FIND);
+    // The screen was raised for brick planes (multiples of 4). If the cell turns out to be an empty 16-cell or larger -- or, DEEP,
+    // a 16-cell whose occupied box the ray misses by 0.05 voxel, five times the largest delta -- nothing inside it can be hit,
+    // and only planes that are ITS faces (multiples of 16) can have bricks behind them: look again at that granularity.
+    // (On the 4096^3 stress tree three quarters of the steps cross such cells and one wave trip in seven made the call; in the
+    // two-level kernels the call is rare and the extra test cost the surfel pass 3 %: DEEP variants only.)
+    if (DEEP && __builtin_expect(screen, 0) && cl_main >= 4u) {
+      bool s16 = __popc(stepped) > 1;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (!(stepped & (1u << a))) {
+          const float r = (oo[a] + dd[a] * t) * 0.0625f;
+          s16 = s16 | (fabsf(r - rintf(r)) <= near_tol * 0.25f);
+        }
+      screen = s16;
+    }
     // leave the cell of size 2^cl_main that contains ijk
     PROF_ENTER(P_ADVANCE);
     const int S = 1 << cl_main;
@@ -677,7 +698,8 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       PROF_COUNT(P_N_NEIGHBOUR_CALLS, 1);
       const u32x8 nv = visit_neighbours<RT, MODE>(&m, inst, o.x, o.y, o.z, d.x, d.y, d.z, inv_d.x, inv_d.y, inv_d.z, tmin, tmax, t,
                                                    ijk[0], ijk[1], ijk[2], stepped, best.t, best.inst, best.block, best.voxel,
-                                                   best.found ? 1u : 0u, mc.key, mc.mid);
+                                                   best.found ? 1u : 0u, mc.key, mc.mid, cl_main,
+                                                   DEEP ? (uint32_t)mc.mask4 : 0u, DEEP ? (uint32_t)(mc.mask4 >> 32) : 0u);
       best.t = __uint_as_float(nv[0]); best.inst = nv[1]; best.block = nv[2]; best.voxel = nv[3]; best.found = nv[4] != 0;
       mc.key = (int)nv[5]; mc.mid = nv[6];
       if (COUNT) st.bricks_tested += nv[7];

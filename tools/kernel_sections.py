@@ -2,7 +2,7 @@
 """Where the traversal kernels' wave cycles go, by code section (s_memtime buckets compiled in with -DDUST_PROFILE).
 
   python tools/kernel_sections.py --build      # here (cross-compiles dust_amd/libdust_hip_prof.so, which travels with gpurun)
-  gpurun -- 'python tools/kernel_sections.py'  # on the GPU box
+  gpurun -- 'python tools/kernel_sections.py [--deep]'  # on the GPU box (--deep: the 4096^3 stress tree instead of the castle)
 
 Buckets are INCLUSIVE wave cycles summed over all waves; the table prints exclusive shares. The timers themselves
 cost ~10 instructions per mark, so treat the shares as relative, not as absolute kernel time.
@@ -69,13 +69,24 @@ def main():
     lib.dust_hip_profile_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     W, H = 1920, 1080
     ctx = api.Context(device=0)
-    data, info = synth.castle_scene()
-    desc = P.SceneDesc.from_vox(data)
-    scene = P.hip_scene(ctx, desc)
+    if "--deep" in sys.argv:  # bench.py --workload deep: the 4096^3 stress tree at 1 % brick occupancy, seen from inside
+        import numpy as np
+        blocks, mats = synth.procedural_deep_blocks(occupancy=0.01, sample=True)
+        model = api.Model(ctx, blocks, mats, synth.make_palette(5), tree_extent_log2=12)
+        scene = api.Scene(ctx)
+        xf = np.eye(3, 4, dtype=np.float32)
+        xf[:, 3] = (-2048.0, -2048.0, -2048.0)
+        scene.add_instance(model, xf.reshape(12))
+        scene.commit()
+        eye = (300.0, 200.0, -150.0)
+    else:
+        data, info = synth.castle_scene()
+        desc = P.SceneDesc.from_vox(data)
+        scene = P.hip_scene(ctx, desc)
+        eye = (122.0, 300.61, 54.45)
     pipe = api.StandardPipeline(ctx, W, H)
     pipe.set_noise(0, synth.stbn_scalar())
     pipe.set_noise(5, synth.stbn_unitvec3_cosine())
-    eye = (122.0, 300.61, 54.45)
     cam = api.make_camera(eye, api.look_at_rotation(eye, (0, 0, 0)), api.PinholeProjection())
     sky = P.sky_state()
     full = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
