@@ -1549,8 +1549,8 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
 }
 DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
                                 uint32_t out_words, uint32_t n) {
-  static const uint32_t kWords[13][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}, {2, 2}};
-  if (!ctx || !in || !out || fn >= 13) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
+  static const uint32_t kWords[14][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}, {2, 2}, {1, 1}};
+  if (!ctx || !in || !out || fn >= 14) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
   if (in_words != kWords[fn][0] || out_words != kWords[fn][1]) return fail(DUST_ERR_INVALID_ARGUMENT, "row width does not match the function");
   if (n == 0) return DUST_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1568,6 +1568,16 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
     HIP_TRY(hipMemcpy(k.data(), in_b ? kb.p : ka.p, size_t(n) * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v.data(), in_b ? vb.p : va.p, size_t(n) * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i) { out[size_t(i) * 2] = k[i]; out[size_t(i) * 2 + 1] = v[i]; }
+    return DUST_OK;
+  }
+  if (fn == 13) {  // the cost-ordered hand-out's sorter (k_tile_order) on caller-given tile costs: rows in = cycles, rows out = tile order
+    DeviceBuffer cost, order;
+    HIP_TRY(cost.upload(in, size_t(n) * 4));
+    HIP_TRY(order.alloc(size_t(n) * 4));
+    HIP_TRY(hipMemsetAsync(order.p, 0xFF, size_t(n) * 4, ctx->stream));
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), n, (n + dust::kRegions - 1) / dust::kRegions, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost));
     return DUST_OK;
   }
   DeviceBuffer din, dout;

@@ -83,3 +83,30 @@ def test_device_radix_sort_is_a_stable_sort(ctx):
         out = ctx.device_eval(12, np.ascontiguousarray(rows), 2)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(out[:, 0], keys[order]) and np.array_equal(out[:, 1], order.astype(np.uint32)), (n, hi)
+
+
+def test_tile_order_is_a_stable_sort_by_cost_class(ctx):
+    """k_tile_order (kernels.hip; what dust_hip_render_frame hands tiles out by) against numpy: per band (8 contiguous bands of the
+    tile list) a stable sort into quarter-octave classes below the band's most expensive tile, most expensive class first,
+    never-timed tiles (cost 0) and everything 8 octaves down in the last class. Costs sit mid-class so that the device's
+    v_log_f32 and numpy agree on every class."""
+    rng = np.random.default_rng(13)
+    for n in (1, 7, 8, 64, 1000, 32400, 129_600, 300_001):
+        k = rng.integers(40, 121, n)
+        cost = np.floor(np.exp2((k + 0.5) / 4.0)).astype(np.uint32)
+        cost[rng.random(n) < 0.1] = 0
+        if n > 100:
+            cost[: n // 16] = 0  # a stretch nobody timed
+        out = ctx.device_eval(13, np.ascontiguousarray(cost.reshape(-1, 1)), 1).reshape(-1)
+        q = np.where(cost == 0, 0, 1 + k)
+        per = (n + 7) // 8
+        expect = np.empty(n, np.uint32)
+        for b in range(8):
+            lo, hi = min(b * per, n), min((b + 1) * per, n)
+            if lo == hi:
+                continue
+            qb = q[lo:hi]
+            top = qb.max()
+            digit = np.where(qb == 0, 31, np.minimum(top - qb, 31))
+            expect[lo:hi] = lo + np.argsort(digit, kind="stable")
+        assert np.array_equal(out, expect), n
