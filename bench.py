@@ -13,7 +13,9 @@ With N GPUs (one process per GPU, torch.distributed over RCCL) the work is cut o
                              scaling. GI workloads keep an identical spatial hash + surfel pool on every GPU through the
                              exchange of dust_hip_pipeline_gi_exchange (three small collectives per frame) and the
                              deterministic apply (DUST_PASS_GI_ORDERED); the surfel pass is replicated.
-Either way every rank's RGBA16F illuminance (frame or band) is gathered to rank 0 over RCCL inside the timed region.
+Either way every rank's RGBA16F illuminance (frame or band) is gathered over RCCL inside the timed region: step k's onto rank
+k % N (--gather-root rotate, the default: xGMI is point to point, a fixed root would push every frame through the peers' one
+link to it) or always onto rank 0 (--gather-root fixed).
 A ray = one traceRayEXT equivalent actually issued, counted per class by the counting build of the kernels in an untimed frame.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes / HIP-event
@@ -46,6 +48,8 @@ def parse():
     ap.add_argument("--workload", choices=["primary_ao", "gi", "deep"], default="primary_ao")
     ap.add_argument("--shard", choices=["samples", "bands"], default=None)
     ap.add_argument("--gi-shard", choices=["samples", "bands"], default=None, help="older spelling of --shard")
+    ap.add_argument("--gather-root", choices=["rotate", "fixed"], default="rotate",
+                    help="N > 1: frame k is assembled on rank k %% N (default: the bytes spread over every xGMI link) or always on rank 0")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
@@ -156,7 +160,8 @@ def main():
     # per_rows rows; a collective with unequal counts is undefined), and rank 0 keeps the first H rows of the assembly.
     tgt_rows = world * per_rows if bands else H
     targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
-    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]])  # step k's gather overlaps step k+1's rendering
+    # step k's gather overlaps step k+1's rendering; its root is rank k % N (every xGMI link carries its share) unless --gather-root fixed
+    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]], rotate=args.gather_root == "rotate")
 
     pix_stats = []
 
@@ -188,7 +193,7 @@ def main():
             frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
             pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         if world > 1:
-            gather.submit_view(targets[k % 2][send[0]:send[1]])  # asynchronous gather to rank 0, straight from the target
+            gather.submit_view(targets[k % 2][send[0]:send[1]])  # asynchronous gather, straight from the target
 
     def barrier():
         gather.finish()
@@ -348,13 +353,14 @@ def main():
             "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
     scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
                   ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}"))
+    root_txt = "k % N for step k (rotating root: the bytes spread over every xGMI link)" if args.gather_root == "rotate" and world > 1 else "0"
     if bands:
         par = (f"bands x{world}: one frame in {world} row bands of {per_rows} rows"
                + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
                   "winning surfels, deterministic apply), surfel pass replicated" if gi_mode else "")
-               + ", RCCL gather of the (equal-size, padded) bands to rank 0")
+               + ", RCCL gather of the (equal-size, padded) bands to rank " + root_txt)
     else:
-        par = f"spp x{world}: one {W}x{H} sample per GPU, RCCL gather of RGBA16F frames to rank 0"
+        par = f"spp x{world}: one {W}x{H} sample per GPU, RCCL gather of RGBA16F frames to rank {root_txt}"
     metric = {"primary_ao": f"Mrays/s at {W}x{H} 1spp castle.vox (primary + sun-shadow + AO rays)",
               "gi": f"Mrays/s at {W}x{H} castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
               "deep": f"Mrays/s at {W}x{H} procedural 4096^3 sparse vdb, diffuse GI frame (deep-tree stress)"}[args.workload]

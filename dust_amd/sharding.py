@@ -1,7 +1,7 @@
 """How the hot path shards over the GPUs of one node (one process per GPU, torch.distributed over RCCL).
 
 Rays are independent given read-only scene data, so there is no data-path collective; the only exchange is
-the gather of finished framebuffers to rank 0. Two partitions are used:
+the gather of finished framebuffers onto one GPU (AsyncGather: rank k % N for frame k). Two partitions are used:
   * row bands of one frame  (DustHipFrameParams.row_begin/row_end)
   * samples of one view     ("N spp" = N consecutive frame indices) -- what bench.py scales with
 Both are exercised on CPU with the gloo backend in tests/test_distributed_cpu.py.
@@ -57,28 +57,46 @@ def assemble_bands(parts, height: int, align: int = 8):
 
 
 class AsyncGather:
-    """Double-buffered gather to rank 0: the gather of step k overlaps the rendering of step k+1.
-    `fill(buf)` must enqueue the copy of this rank's finished frame into `buf` on the current stream."""
+    """Double-buffered gather of finished frames: the gather of step k overlaps the rendering of step k+1.
 
-    def __init__(self, dist, like, depth: int = 2, dst: int = 0):
+    `rotate=True` gathers step k's frames to rank k % world instead of always to rank `dst`. xGMI is point to point: with a fixed
+    root every peer pushes its whole frame through its ONE link to that root, step after step (16.6 MB per 1080p RGBA16F
+    frame: ~0.3 ms at the ~55 GB/s a link sustains in one direction -- longer than the frame takes to render), while the other
+    49 link directions of an 8-GPU node idle. Rotating the root spreads the same bytes over every link in both directions (each link then
+    carries one frame every `world` steps); frame k is assembled on GPU k % world, which is also how an offline renderer would
+    spread the encoding / writing of finished frames."""
+
+    def __init__(self, dist, like, depth: int = 2, dst: int = 0, rotate: bool = False):
         import torch
-        self.dist, self.dst = dist, dst
+        self.dist, self.dst, self.rotate = dist, dst, rotate
         self.active = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.active else 1
+        self.rank = dist.get_rank() if self.active else 0
         self.bufs = [torch.empty_like(like) for _ in range(depth)]
         self.works = [None] * depth
+        self.roots = [dst] * depth
         self.out = None
-        if self.active and dist.get_rank() == dst:
-            self.out = [[torch.empty_like(like) for _ in range(dist.get_world_size())] for _ in range(depth)]
+        if self.active and (rotate or self.rank == dst):
+            self.out = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(depth)]
         self.k = 0
 
+    def _root(self):
+        return self.k % self.world if self.rotate else self.dst
+
+    def _gather(self, b, tensor):
+        root = self._root()
+        self.roots[b] = root
+        self.works[b] = self.dist.gather(tensor, self.out[b] if (self.out is not None and self.rank == root) else None, dst=root,
+                                         async_op=True)
+
     def submit(self, fill):
+        """`fill(buf)` enqueues the copy of this rank's finished frame into `buf` on the current stream."""
         b = self.k % len(self.bufs)
         if self.works[b] is not None:
             self.works[b].wait()          # the send that last used this buffer is done (stream-ordered for NCCL)
         fill(self.bufs[b])
         if self.active:
-            self.works[b] = self.dist.gather(self.bufs[b], self.out[b] if self.out is not None else None, dst=self.dst,
-                                             async_op=True)
+            self._gather(b, self.bufs[b])
         self.k += 1
         return b
 
@@ -90,13 +108,13 @@ class AsyncGather:
             self.works[b] = None
 
     def submit_view(self, view):
-        """Gather `view` (this rank's finished frame or band, still in its render target) to rank dst without a staging
-        copy. The caller alternates between len(self.bufs) targets and calls wait_slot(k) before rendering into one again."""
+        """Gather `view` (this rank's finished frame or band, still in its render target) without a staging copy. The caller
+        alternates between len(self.bufs) targets and calls wait_slot(k) before rendering into one again."""
         b = self.k % len(self.bufs)
         self.wait_slot(b)
         self.bufs[b] = view
         if self.active:
-            self.works[b] = self.dist.gather(view, self.out[b] if self.out is not None else None, dst=self.dst, async_op=True)
+            self._gather(b, view)
         self.k += 1
         return b
 
@@ -106,10 +124,16 @@ class AsyncGather:
                 w.wait()
                 self.works[i] = None
 
+    def last_root(self):
+        """the rank the most recent submit gathered to"""
+        return self.roots[(self.k - 1) % len(self.bufs)] if self.active else 0
+
     def last(self):
-        """Frames gathered by the most recent submit (rank dst only; [own buffer] when not distributed)."""
+        """Frames gathered by the most recent submit (on its root only; [own buffer] when not distributed)."""
         b = (self.k - 1) % len(self.bufs)
-        return self.out[b] if self.out is not None else [self.bufs[b]]
+        if not self.active:
+            return [self.bufs[b]]
+        return self.out[b] if (self.out is not None and self.rank == self.roots[b]) else None
 
 
 # ----------------------------------------------------------------------------------------------------------------------

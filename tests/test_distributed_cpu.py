@@ -107,6 +107,17 @@ WORKER = textwrap.dedent('''
     ag.finish()
     if rank == 0:
         assert [int(x[0]) for x in ag.last()] == [400 + r for r in range(world)]
+    # --- rotating root (bench.py's default: step k's frames are assembled on rank k % world, every xGMI link carries its share)
+    ar = sharding.AsyncGather(dist, torch.zeros(4, dtype=torch.int32), rotate=True)
+    for k in range(5):
+        ar.submit(lambda buf, k=k: buf.fill_(100 * k + rank))
+        ar.finish()
+        assert ar.last_root() == k % world
+        got = ar.last()
+        if rank == k % world:
+            assert [int(x[0]) for x in got] == [100 * k + r for r in range(world)]
+        else:
+            assert got is None
     # --- the same without staging copies: two render targets used in turn, gathered straight from a row view of them
     targets = [torch.zeros((6, 4), dtype=torch.int32) for _ in range(2)]
     av = sharding.AsyncGather(dist, targets[0][2:4])
