@@ -13,9 +13,10 @@ With N GPUs (one process per GPU, torch.distributed over RCCL) the work is cut o
                              scaling. GI workloads keep an identical spatial hash + surfel pool on every GPU through the
                              exchange of dust_hip_pipeline_gi_exchange (three small collectives per frame) and the
                              deterministic apply (DUST_PASS_GI_ORDERED); the surfel pass is replicated.
-Either way every rank's RGBA16F illuminance (frame or band) is gathered over RCCL inside the timed region: step k's onto rank
-k % N (--gather-root rotate, the default: xGMI is point to point, a fixed root would push every frame through the peers' one
-link to it) or always onto rank 0 (--gather-root fixed).
+Either way every rank's RGBA16F illuminance leaves its GPU over RCCL inside the timed region. Whole frames (spp sharding) are
+assembled by row slices -- one all-to-all per step, rank j receives slice j of every rank's frame (--assemble slices, the
+default: xGMI is point to point, and a gather pushes every peer's whole frame through its one link to the root);
+--assemble rotate / fixed gather them onto rank k % N / rank 0 instead. Row bands are gathered (rotating root by default).
 A ray = one traceRayEXT equivalent actually issued, counted per class by the counting build of the kernels in an untimed frame.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes / HIP-event
@@ -48,8 +49,10 @@ def parse():
     ap.add_argument("--workload", choices=["primary_ao", "gi", "deep"], default="primary_ao")
     ap.add_argument("--shard", choices=["samples", "bands"], default=None)
     ap.add_argument("--gi-shard", choices=["samples", "bands"], default=None, help="older spelling of --shard")
-    ap.add_argument("--gather-root", choices=["rotate", "fixed"], default="rotate",
-                    help="N > 1: frame k is assembled on rank k %% N (default: the bytes spread over every xGMI link) or always on rank 0")
+    ap.add_argument("--assemble", choices=["slices", "rotate", "fixed"], default="slices",
+                    help="N > 1, how finished frames leave their GPU: slices = one all-to-all, rank j assembles row slice j of every "
+                         "frame (default; every xGMI link in use); rotate / fixed = RCCL gather of whole frames onto rank k %% N / rank 0 "
+                         "(bound by each peer's single link to the root). Row bands are always gathered (default root: rotating)")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
@@ -158,10 +161,17 @@ def main():
     # so RCCL moves frame k straight out of its render target while frame k+1 renders into the other one -- no staging copy.
     # With bands the targets are padded to world * per_rows rows: every rank sends a slice of the SAME size (its band padded to
     # per_rows rows; a collective with unequal counts is undefined), and rank 0 keeps the first H rows of the assembly.
-    tgt_rows = world * per_rows if bands else H
+    # Whole frames per rank (spp sharding) are assembled by row slices (--assemble slices, the default): one all-to-all per step,
+    # rank j receives slice j of every rank's frame over N-1 links at once; the target is padded to a multiple of N rows.
+    # --assemble rotate / fixed gather whole frames onto rank k % N / rank 0 instead (bands always gather: a band is a slice).
+    assemble = args.assemble if not bands else ("rotate" if args.assemble == "slices" else args.assemble)
+    slices = assemble == "slices" and world > 1
+    tgt_rows = world * per_rows if bands else (-(-H // world) * world if slices else H)
     targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
-    # step k's gather overlaps step k+1's rendering; its root is rank k % N (every xGMI link carries its share) unless --gather-root fixed
-    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]], rotate=args.gather_root == "rotate")
+    if slices:
+        send = (0, tgt_rows)
+    # step k's exchange overlaps step k+1's rendering
+    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]], rotate=assemble == "rotate", slices=slices)
 
     pix_stats = []
 
@@ -353,14 +363,16 @@ def main():
             "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
     scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
                   ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}"))
-    root_txt = "k % N for step k (rotating root: the bytes spread over every xGMI link)" if args.gather_root == "rotate" and world > 1 else "0"
+    root_txt = "k % N for step k (rotating root)" if assemble == "rotate" and world > 1 else "0"
     if bands:
         par = (f"bands x{world}: one frame in {world} row bands of {per_rows} rows"
                + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
                   "winning surfels, deterministic apply), surfel pass replicated" if gi_mode else "")
                + ", RCCL gather of the (equal-size, padded) bands to rank " + root_txt)
     else:
-        par = f"spp x{world}: one {W}x{H} sample per GPU, RCCL gather of RGBA16F frames to rank {root_txt}"
+        par = (f"spp x{world}: one {W}x{H} sample per GPU, " +
+               ("RCCL all-to-all of the RGBA16F frames by row slices (rank j assembles slice j of every sample)" if slices or world == 1 and assemble == "slices"
+                else f"RCCL gather of RGBA16F frames to rank {root_txt}"))
     metric = {"primary_ao": f"Mrays/s at {W}x{H} 1spp castle.vox (primary + sun-shadow + AO rays)",
               "gi": f"Mrays/s at {W}x{H} castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
               "deep": f"Mrays/s at {W}x{H} procedural 4096^3 sparse vdb, diffuse GI frame (deep-tree stress)"}[args.workload]

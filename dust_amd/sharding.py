@@ -59,6 +59,13 @@ def assemble_bands(parts, height: int, align: int = 8):
 class AsyncGather:
     """Double-buffered gather of finished frames: the gather of step k overlaps the rendering of step k+1.
 
+    `slices=True` assembles by row slices instead: one all-to-all per step sends slice j of every rank's frame to rank j, so
+    rank j ends up with slice j of all N frames (for spp sharding: every sample of its rows -- their sum needs no further
+    traffic). Each rank then moves (N-1)/N of a frame over N-1 links AT ONCE, 2.1 MB per link and step for 1080p RGBA16F on 8 GPUs,
+    where a gather makes the root's N-1 peers push a whole frame (16.6 MB) through one link each: ~0.3 ms at the ~55 GB/s a
+    link sustains in one direction, longer than the frame takes to render. (Collectives of one communicator run one after the
+    other, so gathers to different roots do not overlap either.) `last()` then returns the [N * slice_rows, ...] tensor.
+
     `rotate=True` gathers step k's frames to rank k % world instead of always to rank `dst`. xGMI is point to point: with a fixed
     root every peer pushes its whole frame through its ONE link to that root, step after step (16.6 MB per 1080p RGBA16F
     frame: ~0.3 ms at the ~55 GB/s a link sustains in one direction -- longer than the frame takes to render), while the other
@@ -66,9 +73,9 @@ class AsyncGather:
     carries one frame every `world` steps); frame k is assembled on GPU k % world, which is also how an offline renderer would
     spread the encoding / writing of finished frames."""
 
-    def __init__(self, dist, like, depth: int = 2, dst: int = 0, rotate: bool = False):
+    def __init__(self, dist, like, depth: int = 2, dst: int = 0, rotate: bool = False, slices: bool = False):
         import torch
-        self.dist, self.dst, self.rotate = dist, dst, rotate
+        self.dist, self.dst, self.rotate, self.slices = dist, dst, rotate, slices
         self.active = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.active else 1
         self.rank = dist.get_rank() if self.active else 0
@@ -76,7 +83,10 @@ class AsyncGather:
         self.works = [None] * depth
         self.roots = [dst] * depth
         self.out = None
-        if self.active and (rotate or self.rank == dst):
+        if self.active and slices:
+            assert like.shape[0] % self.world == 0, "slices: the frame's rows must divide by the world size (pad the target)"
+            self.out = [torch.empty_like(like) for _ in range(depth)]
+        elif self.active and (rotate or self.rank == dst):
             self.out = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(depth)]
         self.k = 0
 
@@ -84,6 +94,10 @@ class AsyncGather:
         return self.k % self.world if self.rotate else self.dst
 
     def _gather(self, b, tensor):
+        if self.slices:  # one all-to-all: row slice j of every rank's frame lands on rank j
+            self.roots[b] = self.rank
+            self.works[b] = self.dist.all_to_all_single(self.out[b], tensor, async_op=True)
+            return
         root = self._root()
         self.roots[b] = root
         self.works[b] = self.dist.gather(tensor, self.out[b] if (self.out is not None and self.rank == root) else None, dst=root,
@@ -133,6 +147,8 @@ class AsyncGather:
         b = (self.k - 1) % len(self.bufs)
         if not self.active:
             return [self.bufs[b]]
+        if self.slices:
+            return self.out[b]
         return self.out[b] if (self.out is not None and self.rank == self.roots[b]) else None
 
 

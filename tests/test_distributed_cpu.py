@@ -118,6 +118,18 @@ WORKER = textwrap.dedent('''
             assert [int(x[0]) for x in got] == [100 * k + r for r in range(world)]
         else:
             assert got is None
+    # --- assembly by row slices (bench.py's default for spp sharding): one all-to-all, rank j gets slice j of every rank's frame
+    tgs = [torch.zeros((2 * world, 3), dtype=torch.int32) for _ in range(2)]
+    sl = sharding.AsyncGather(dist, tgs[0], slices=True)
+    for k in range(5):
+        sl.wait_slot(k % 2)
+        tgs[k % 2][:] = (1000 * k + 100 * rank + torch.arange(2 * world, dtype=torch.int32)[:, None])  # row index in the last digits
+        sl.submit_view(tgs[k % 2])
+    sl.finish()
+    got = sl.last()
+    assert got.shape == tgs[0].shape
+    for src in range(world):  # rows [2 * rank, 2 * rank + 2) of rank src's frame 4
+        assert got[2 * src:2 * src + 2, 0].tolist() == [4000 + 100 * src + 2 * rank, 4000 + 100 * src + 2 * rank + 1]
     # --- the same without staging copies: two render targets used in turn, gathered straight from a row view of them
     targets = [torch.zeros((6, 4), dtype=torch.int32) for _ in range(2)]
     av = sharding.AsyncGather(dist, targets[0][2:4])
