@@ -22,6 +22,7 @@ tail -1 "$out/${tag}_bench_deep.log" | cut -c1-600
 python bench.py --shard bands > "$out/${tag}_bench_bands.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --shard bands --no-cpu-baseline > "$out/${tag}_bench_gi_bands.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
+python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
