@@ -309,7 +309,10 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
-                "kernel_ms_source": f"HIP events on the launch stream around every launch of the timed region ({max(ev_n)} launches averaged)",
+                "kernel_ms_source": f"HIP events on the launch stream around every launch of the timed region ({max(ev_n)} launches averaged)" +
+                                    ("; the surfel pass of step k runs beside the primary + AO kernel of step k + 1 on a second stream (each on a "
+                                     "share of the workgroup slots), so those two durations overlap in time and are longer than when run alone "
+                                     "(DUST_HIP_NO_OVERLAP=1)" if gi_mode and not gi_bands and "DUST_HIP_NO_OVERLAP" not in os.environ else ""),
                 "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if ms_ao == 0.0 else
                                    {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
                 "per_rank_kernel_ms": [{"primary_ao" if ms_ao == 0.0 else "primary": round(float(v[0]), 4),

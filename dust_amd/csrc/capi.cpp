@@ -151,6 +151,7 @@ struct DustHipContext {
   int num_cus = 256;
   size_t max_lds = 64 * 1024;
   DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
+  std::vector<struct DustHipPipeline*> pipelines;  // alive pipelines of this context (a deferred surfel pass is flushed through it)
 };
 
 // device-side voxel edits (edit.hip): the dense voxel grid and the scratch tables of the rebuild, created on a model's first edit
@@ -200,6 +201,8 @@ struct Tuning {
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
+  bool no_overlap = false;      // DUST_HIP_NO_OVERLAP: the surfel pass runs at the end of its own frame, on the main stream
+  uint32_t overlap_share = 0;   // DUST_HIP_OVERLAP_SHARE: percent of the workgroup slots the overlapped surfel pass gets (0: balanced by feedback)
   static uint32_t num(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
@@ -215,6 +218,9 @@ struct Tuning {
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
+    t.no_overlap = std::getenv("DUST_HIP_NO_OVERLAP") != nullptr;
+    t.overlap_share = num("DUST_HIP_OVERLAP_SHARE", 0);
+    if (t.overlap_share) t.overlap_share = std::min(90u, std::max(10u, t.overlap_share));
     return t;
   }
 };
@@ -239,6 +245,24 @@ struct DustHipPipeline {
     bool measured = false;   // cost[] holds a launch's measurements (maybe not the last launch's)
   } tile_history[4];
   uint64_t view_key = 0;     // this frame's camera + scene revision + sun + row band
+  // Deferred surfel pass (see run_surfel_pass): the pass of frame N, launched with frame N + 1's primary kernels on a second stream
+  struct PendingSurfel {
+    bool valid = false;
+    dust::FrameArgs args{};
+    uint32_t passes = 0;
+    uint64_t view_key = 0;
+    const DustHipScene* scene = nullptr;
+    uint64_t scene_revision = 0;
+  } pending;
+  hipStream_t side = nullptr;               // created on first use
+  uint32_t pending_bpc = 2;                 // workgroups per CU the kept-back pass's LDS size allows
+  hipEvent_t ev_frame_end = nullptr, ev_side_done = nullptr;
+  // Balance of the two sides: timed pairs around each side of an overlapped frame, read back (without waiting) some frames
+  // later; the side that took longer gets a few more of the workgroup slots next time
+  struct Probe { hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr; bool in_flight = false; } probes[8];
+  uint32_t probe_next = 0;
+  int probe_live = -1;       // the probe this frame records into, -1 = none
+  float side_share = 0.0f;   // percent of the slots for the kept-back pass; 0 = not estimated yet
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
@@ -271,6 +295,10 @@ struct DustHipPipeline {
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
+// a kept-back surfel pass (dust_hip_render_frame) is launched before anything looks at what it writes or frees what it reads
+static DustStatus flush_surfel_pass(DustHipPipeline* p);
+static DustStatus flush_context(DustHipContext* c, const DustHipScene* scene /* null: every pipeline */);
+#define FLUSH_TRY(expr) do { const DustStatus fs_ = (expr); if (fs_ != DUST_OK) return fs_; } while (0)
 
 // ------------------------------------------------------------------ device hierarchy build
 namespace {
@@ -639,7 +667,9 @@ void dust_hip_context_destroy(DustHipContext* c) {
 }
 DustStatus dust_hip_sync(DustHipContext* c) {
   if (!c) return fail(DUST_ERR_INVALID_ARGUMENT, "null context");
+  FLUSH_TRY(flush_context(c, nullptr));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  for (DustHipPipeline* p : c->pipelines) if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   return DUST_OK;
 }
 
@@ -719,7 +749,12 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     return DUST_OK;
   });
 }
-void dust_hip_model_destroy(DustHipModel* m) { delete m; }
+void dust_hip_model_destroy(DustHipModel* m) {
+  if (!m) return;
+  (void)flush_context(m->ctx, nullptr);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  delete m;
+}
 
 // ---------------------------------------------------------------- device-side edits (edit.hip)
 namespace {
@@ -826,6 +861,7 @@ DustStatus upload_batch(DustHipModel* m, const uint32_t* xyz, const int32_t* val
 
 DustStatus dust_hip_model_set_voxels(DustHipModel* m, const uint32_t* xyz, const int32_t* values, uint32_t n) {
   if (!m || (n && (!xyz || !values))) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  FLUSH_TRY(flush_context(m->ctx, nullptr));  // a kept-back surfel pass traces the model as it was
   for (uint32_t i = 0; i < n; ++i) {
     if (xyz[i * 3] >= m->dev.extent || xyz[i * 3 + 1] >= m->dev.extent || xyz[i * 3 + 2] >= m->dev.extent)
       return fail(DUST_ERR_INVALID_ARGUMENT, "voxel coordinate outside the tree extent");
@@ -906,7 +942,12 @@ DustStatus dust_hip_scene_create(DustHipContext* ctx, DustHipScene** out) {
     return DUST_OK;
   });
 }
-void dust_hip_scene_destroy(DustHipScene* s) { delete s; }
+void dust_hip_scene_destroy(DustHipScene* s) {
+  if (!s) return;
+  (void)flush_context(s->ctx, s);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  delete s;
+}
 
 static DustStatus check_affine(const float m[12]) {
   for (int i = 0; i < 12; ++i)
@@ -953,6 +994,8 @@ DustStatus dust_hip_scene_set_transform(DustHipScene* s, uint32_t id, const floa
 
 DustStatus dust_hip_scene_commit(DustHipScene* s) {
   if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
+  FLUSH_TRY(flush_context(s->ctx, s));  // a kept-back surfel pass traces the scene as it was committed
+  HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // (the instance buffers are reallocated below)
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(s->ctx->device));
     ++s->revision;
@@ -1047,12 +1090,21 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
           side.assign(DustHipPipeline::kEvRing, nullptr);
           for (auto& e : side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         }
+    ctx->pipelines.push_back(p.get());
     *out = p.release();
     return DUST_OK;
   });
 }
 void dust_hip_pipeline_destroy(DustHipPipeline* p) {
   if (!p) return;
+  p->pending.valid = false;  // nobody can look at its results any more
+  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+  if (p->ev_frame_end) (void)hipEventDestroy(p->ev_frame_end);
+  if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
+  for (auto& pr : p->probes) for (hipEvent_t e : {pr.a0, pr.a1, pr.b0, pr.b1}) if (e) (void)hipEventDestroy(e);
+  auto& reg = p->ctx->pipelines;
+  reg.erase(std::remove(reg.begin(), reg.end(), p), reg.end());
   for (auto& kind : p->ev_ring)
     for (auto& side : kind)
       for (auto& e : side) if (e) (void)hipEventDestroy(e);
@@ -1061,7 +1113,9 @@ void dust_hip_pipeline_destroy(DustHipPipeline* p) {
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
   if (!p || !texels || layers == 0 || (texture != 0 && texture != 5))
     return fail(DUST_ERR_INVALID_ARGUMENT, "noise texture must be 0 (scalar R8) or 5 (unitvec3_cosine RGBA8)");
+  FLUSH_TRY(flush_surfel_pass(p));
   HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   const size_t bytes = size_t(128) * 128 * layers * (texture == 0 ? 1 : 4);
   if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes)); p->noise0_layers = layers; }
   else { HIP_TRY(p->noise5.upload(texels, bytes)); p->noise5_layers = layers; }
@@ -1116,6 +1170,72 @@ static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a)
   a.work_counters = base + size_t(par) * dust::kRegions * dust::kCounterStride;
   a.next_work_counters = base + size_t(par ^ 1u) * dust::kRegions * dust::kCounterStride;
   p->counter_parity[kind] = par ^ 1u;
+}
+
+// The surfel pass of one frame (surfel.rgen + the spatial hash update) on stream `st`, on at most `resident` workgroup slots.
+static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, uint32_t passes, bool count, hipStream_t st, uint32_t resident) {
+  DustHipContext* ctx = p->ctx;
+  const Tuning& tune = p->tune;
+  const uint32_t block = tune.block;
+    dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
+    b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
+    b.tiles_y = 1;
+    take_counters(p, 3, b);
+    { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
+    b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
+    uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
+    uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
+    b.gi.sort_keys = sk[0];
+    b.gi.sort_vals = sv[0];
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
+    if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
+      HIP_TRY(dust::launch_surfel_keys(b, st));
+      bool in_b = false;
+      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
+      b.gi.perm = sv[in_b ? 1 : 0];
+    }
+    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
+    HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+    // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
+    // result of applying them in surfel-index order -- in parallel over independent probe-window clusters (the serial
+    // one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
+    if (!(passes & DUST_PASS_GI_ORDERED)) {
+      HIP_TRY(dust::launch_surfel_apply(b, 0, st));
+    } else if (tune.debug & 16u) {
+      HIP_TRY(dust::launch_surfel_apply(b, 1, st));
+    } else {
+      HIP_TRY(dust::launch_surfel_apply(b, 2, st));
+      uint32_t bits = 1;
+      while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
+      bool in_b = false;
+      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
+      b.gi.apply_keys = sk[in_b ? 1 : 0];
+      b.gi.apply_vals = sv[in_b ? 1 : 0];
+      HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+    }
+    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
+  return DUST_OK;
+}
+// launches a kept-back surfel pass now, on the main stream (nothing to overlap it with)
+static DustStatus flush_surfel_pass(DustHipPipeline* p) {
+  if (!p->pending.valid) return DUST_OK;
+  p->pending.valid = false;
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  const uint64_t key = p->view_key;
+  p->view_key = p->pending.view_key;
+  uint32_t resident = uint32_t(p->ctx->num_cus) * p->pending_bpc;
+  if (p->tune.reserve_blocks && p->tune.reserve_blocks + 8u <= resident) resident -= p->tune.reserve_blocks;
+  const DustStatus rs = run_surfel_pass(p, p->pending.args, p->pending.passes, false, p->ctx->stream, resident);
+  p->view_key = key;
+  return rs;
+}
+static DustStatus flush_context(DustHipContext* c, const DustHipScene* scene /* null: every pipeline */) {
+  for (DustHipPipeline* p : c->pipelines)
+    if (p->pending.valid && (!scene || p->pending.scene == scene)) {
+      const DustStatus rs = flush_surfel_pass(p);
+      if (rs != DUST_OK) return rs;
+    }
+  return DUST_OK;
 }
 
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
@@ -1202,9 +1322,66 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // frame to another GPU) can only become resident next to them where a workgroup slot was left empty.
   uint32_t resident = uint32_t(ctx->num_cus) * bpc;
   if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
-  const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
+  // A kept-back surfel pass (the previous frame's): launch it beside this frame's primary / AO kernels, or before anything else
+  uint32_t main_resident = resident;
+  bool overlapped = false;
+  if (p->pending.valid) {
+    const bool beside = !tune.no_overlap && !count && !sharded && (fp->passes & DUST_PASS_PRIMARY) && p->pending.scene == s &&
+                        p->pending.scene_revision == s->revision && p->ev_frame_end != nullptr;
+    if (beside) {
+      if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+      if (!p->ev_side_done) HIP_TRY(hipEventCreateWithFlags(&p->ev_side_done, hipEventDisableTiming));
+      // The share of the workgroup slots each side gets. A first guess from the ray counts (a surfel ray costs about eighteen
+      // coherent ones), then feedback: both sides are timed, and the pass gets three points more when it ends over a quarter later than the main
+      // side, three fewer when it ends before it.
+      if (p->side_share == 0.0f) {
+        const double surfel = double(p->gi_pool_size) * 18.0, pixel = 3.0 * double(p->width) * double(a.row_end - a.row_begin);
+        p->side_share = float(std::min(60.0, std::max(15.0, 100.0 * surfel / (surfel + pixel))));
+      }
+      for (auto& pr : p->probes) {
+        if (!pr.in_flight || hipEventQuery(pr.a1) != hipSuccess || hipEventQuery(pr.b1) != hipSuccess) continue;
+        float ta = 0.0f, tb = 0.0f;
+        if (hipEventElapsedTime(&ta, pr.a0, pr.a1) == hipSuccess && hipEventElapsedTime(&tb, pr.b0, pr.b1) == hipSuccess && ta > 0.0f && tb > 0.0f) {
+          // (the pass is mostly latency -- a sort, a trace as long as its longest ray, an apply -- and gains little from more
+          // slots while the primary kernels lose in proportion: it is left to finish up to a quarter later than the main side)
+          if (tb > 1.30f * ta) p->side_share = std::min(70.0f, p->side_share + 2.0f);
+          else if (tb < 1.15f * ta) p->side_share = std::max(10.0f, p->side_share - 2.0f);
+        }
+        pr.in_flight = false;
+      }
+      (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
+      const uint32_t share = tune.overlap_share ? tune.overlap_share : uint32_t(p->side_share + 0.5f);
+      const uint32_t side_resident = std::max(8u, (resident * share / 100u) & ~7u);
+      main_resident = std::max(8u, resident - std::min(resident - 8u, side_resident));
+      p->probe_live = -1;
+      {
+        DustHipPipeline::Probe& pr = p->probes[p->probe_next % 8u];
+        if (!pr.in_flight) {
+          if (!pr.a0) for (hipEvent_t* e : {&pr.a0, &pr.a1, &pr.b0, &pr.b1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
+          p->probe_live = int(p->probe_next % 8u);
+          ++p->probe_next;
+        }
+      }
+      HIP_TRY(hipStreamWaitEvent(p->side, p->ev_frame_end, 0));  // the frame that recorded the pass is complete (final gather, commit)
+      if (p->probe_live >= 0) { HIP_TRY(hipEventRecord(p->probes[p->probe_live].b0, p->side)); HIP_TRY(hipEventRecord(p->probes[p->probe_live].a0, st)); }
+      p->pending.valid = false;
+      const uint64_t key = p->view_key;
+      // (p->view_key is set below for THIS frame; the pass orders its work items under the key of the frame it belongs to)
+      p->view_key = p->pending.view_key;
+      const DustStatus rs = run_surfel_pass(p, p->pending.args, p->pending.passes, false, p->side, side_resident);
+      p->view_key = key;
+      if (rs != DUST_OK) return rs;
+      if (p->probe_live >= 0) HIP_TRY(hipEventRecord(p->probes[p->probe_live].b1, p->side));
+      HIP_TRY(hipEventRecord(p->ev_side_done, p->side));
+      overlapped = true;
+    } else {
+      const DustStatus rs = flush_surfel_pass(p);
+      if (rs != DUST_OK) return rs;
+    }
+  }
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(main_resident, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
     auto mix = [&k](const void* data, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(data); for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
@@ -1249,6 +1426,19 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
+  // the hash and the pool are the kept-back pass's until the main stream has waited for it (the final gather's regrouping
+  // pre-pass reads neither and still runs beside it)
+  auto join_side = [&]() -> hipError_t {
+    if (!overlapped) return hipSuccess;
+    overlapped = false;
+    if (p->probe_live >= 0) {
+      const hipError_t e = hipEventRecord(p->probes[p->probe_live].a1, st);
+      if (e != hipSuccess) return e;
+      p->probes[p->probe_live].in_flight = true;
+      p->probe_live = -1;
+    }
+    return hipStreamWaitEvent(st, p->ev_side_done, 0);
+  };
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
     if (sharded) {  // pixels that stamp nothing must read 0 after the all-gather
       a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
@@ -1265,53 +1455,41 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
+      HIP_TRY(join_side());
       g.tiles_x = otx * oty * 16;  // 16 packets of 64 per tile, the empty ones skipped by the kernel
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
+    HIP_TRY(join_side());
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
+  HIP_TRY(join_side());
   if (fp->passes & DUST_PASS_SURFEL) {
-    dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
-    b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
-    b.tiles_y = 1;
-    take_counters(p, 3, b);
-    { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
-    b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
-    uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
-    uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
-    b.gi.sort_keys = sk[0];
-    b.gi.sort_vals = sv[0];
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
-    if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
-      HIP_TRY(dust::launch_surfel_keys(b, st));
-      bool in_b = false;
-      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
-      b.gi.perm = sv[in_b ? 1 : 0];
-    }
-    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
-    HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
-    // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
-    // result of applying them in surfel-index order -- in parallel over independent probe-window clusters (the serial
-    // one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
-    if (!(fp->passes & DUST_PASS_GI_ORDERED)) {
-      HIP_TRY(dust::launch_surfel_apply(b, 0, st));
-    } else if (tune.debug & 16u) {
-      HIP_TRY(dust::launch_surfel_apply(b, 1, st));
+    // The surfel pass of frame N only has to be done before frame N + 1's final gather reads the hash. Its trace is as long as
+    // its longest ray -- the pool is 2.6 work items per resident wave and the most expensive item takes twice the mean wave's
+    // load (tools/tile_costs.py) -- and its sort and apply are a handful of latency-bound launches: half the GPU idles through
+    // it. So it is kept back and launched WITH the next frame's primary / AO kernels, on a second stream, each side on its
+    // share of the workgroup slots (run_surfel_pass, flush_surfel_pass). Same kernels on the same data in the same order of
+    // dependencies: the results cannot differ. Anything that looks at the GI state, or changes what the saved launch
+    // descriptor points to, flushes it first.
+    const bool defer = !tune.no_overlap && !count && !sharded && !(tune.debug & 16u);
+    if (defer) {
+      p->pending.valid = true;
+      p->pending.args = a;
+      p->pending.passes = fp->passes;
+      p->pending.view_key = p->view_key;
+      p->pending.scene = s;
+      p->pending.scene_revision = s->revision;
+      p->pending_bpc = bpc;
+      if (!p->ev_frame_end) HIP_TRY(hipEventCreateWithFlags(&p->ev_frame_end, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(p->ev_frame_end, st));
     } else {
-      HIP_TRY(dust::launch_surfel_apply(b, 2, st));
-      uint32_t bits = 1;
-      while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
-      bool in_b = false;
-      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
-      b.gi.apply_keys = sk[in_b ? 1 : 0];
-      b.gi.apply_vals = sv[in_b ? 1 : 0];
-      HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+      DustStatus rs = run_surfel_pass(p, a, fp->passes, count, st, resident);
+      if (rs != DUST_OK) return rs;
     }
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
     if (fp->passes & DUST_PASS_DENOISE)
@@ -1371,7 +1549,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustHipPassStats* out) {
   if (!p || !out || pass > 5) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
   std::memset(out, 0, sizeof(*out));
+  FLUSH_TRY(flush_surfel_pass(p));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   // pass 0: primary kernel; 1, 2: the two ray classes of the AO kernel (share its time); 3: final gather (+ surfel
   // commit); 4, 5: the two ray classes of the surfel pass (trace + apply kernels)
   const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : (pass == 3 ? 2 : 3));
@@ -1392,6 +1572,7 @@ DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline* p, int mark, float ms
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));  // (a kept-back surfel pass stays kept back: it is not a launch yet)
   for (int k = 0; k < 4; ++k) {
     double sum = 0.0;
     uint32_t n = 0;
@@ -1436,7 +1617,9 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, 
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size) {
   if (!p || hash_capacity < 4 || surfel_pool_size == 0) return fail(DUST_ERR_INVALID_ARGUMENT, "bad GI configuration");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  FLUSH_TRY(flush_surfel_pass(p));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   const size_t hash_bytes = (size_t(hash_capacity) + 2) * 12;  // probes run up to 2 past the end (spatial_hash.glsl:154-158)
   HIP_TRY(p->gi_hash.alloc(hash_bytes));
   HIP_TRY(hipMemset(p->gi_hash.p, 0, hash_bytes));             // standard.rs:348-358 relies on a zeroed allocation
@@ -1466,6 +1649,7 @@ DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_row
   if (!p || !out || padded_rows < p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "padded_rows must cover the frame");
   STRUCT_TRY(out, "DustHipGiExchange");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  FLUSH_TRY(flush_surfel_pass(p));
   if (!p->gi_hash.p) {
     DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
     if (gs != DUST_OK) return gs;
@@ -1492,6 +1676,7 @@ static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uin
   // stamps and commits the winners
   if (row_begin > row_end || (row_begin == row_end && !import) || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  FLUSH_TRY(flush_surfel_pass(p));
   dust::FrameArgs a{};
   a.width = p->width; a.height = p->height;
   a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
@@ -1516,6 +1701,7 @@ DustStatus dust_hip_gi_import(DustHipPipeline* p, uint32_t row_begin, uint32_t r
 }
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* dst, size_t dst_bytes) {
   if (!p || !dst || which > 1 || !p->gi_hash.p) return fail(DUST_ERR_INVALID_ARGUMENT, "GI state not configured");
+  FLUSH_TRY(flush_surfel_pass(p));
   const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
   if (dst_bytes < b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
@@ -1591,6 +1777,7 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
 }
 DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, uint32_t* cycles, uint32_t capacity, uint32_t* tiles_x, uint32_t* tiles_y) {
   if (!p || pass_kind > 3) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass kind");
+  if (pass_kind == 3) FLUSH_TRY(flush_surfel_pass(p));
   const DustHipPipeline::TileHistory& h = p->tile_history[pass_kind];
   if (tiles_x) *tiles_x = h.measured ? h.tiles_x : 0;
   if (tiles_y) *tiles_y = h.measured ? h.tiles_y : 0;
@@ -1619,6 +1806,7 @@ DustStatus dust_hip_pipeline_restart_denoiser(DustHipPipeline* p) {
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  FLUSH_TRY(flush_surfel_pass(p));
   for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->plane(i), 0, p->planes[i].bytes, p->ctx->stream));
   p->have_history = false;
   p->accum_count = 0;

@@ -282,7 +282,14 @@ void dust_hip_pipeline_destroy(DustHipPipeline*);
 /* BlueNoise (noise.rs:7-56): texture 0 (scalar, R8) or 5 (unitvec3_cosine, RGBA8), 128 x 128 x layers */
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const uint8_t* texels, uint32_t layers);
 /* StandardPipeline::render (standard.rs:228-810). Asynchronous on the context's stream.
- * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set. */
+ * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set.
+ * The surfel pass of a frame (DUST_PASS_SURFEL) only has to be complete before the NEXT frame's final gather reads the spatial
+ * hash, and it is latency-bound: it is kept back and launched with the next dust_hip_render_frame, beside that frame's primary / AO
+ * kernels on a second stream. Results are those of running it at the end of its own frame. Everything that looks at the GI
+ * state or at the pass's statistics (dust_hip_pipeline_read_gi, _pass_stats, the GI exchange calls), changes what it reads
+ * (dust_hip_scene_commit, dust_hip_model_set_voxels, _set_noise, _configure_gi, _clear, destroying a scene or model) or is
+ * dust_hip_sync launches it first. Frames with DUST_PASS_COUNT_STATS or DUST_PASS_GI_SHARDED run it in place, as does
+ * DUST_HIP_NO_OVERLAP=1. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
 /* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
