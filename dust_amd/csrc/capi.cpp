@@ -259,10 +259,11 @@ struct DustHipPipeline {
   hipEvent_t ev_frame_end = nullptr, ev_side_done = nullptr;
   // Balance of the two sides: timed pairs around each side of an overlapped frame, read back (without waiting) some frames
   // later; the side that took longer gets a few more of the workgroup slots next time
-  struct Probe { hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr; bool in_flight = false; } probes[8];
+  struct Probe { hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr; bool in_flight = false; float share = 0.0f; uint32_t seq = 0; } probes[8];
   uint32_t probe_next = 0;
   int probe_live = -1;       // the probe this frame records into, -1 = none
   float side_share = 0.0f;   // percent of the slots for the kept-back pass; 0 = not estimated yet
+  int calibration = 0;       // 0: the next kept-back pass runs in place, timed, and so do that frame's primary kernels; 1: read; 2: done
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
@@ -1326,30 +1327,60 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   p->stats_valid = false;
   // A kept-back surfel pass (the previous frame's): launch it beside this frame's primary / AO kernels, or before anything else
   uint32_t main_resident = resident;
-  bool overlapped = false;
+  bool overlapped = false, calibrating = false;
   if (p->pending.valid) {
     const bool beside = !tune.no_overlap && !count && !sharded && (fp->passes & DUST_PASS_PRIMARY) && p->pending.scene == s &&
                         p->pending.scene_revision == s->revision && p->ev_frame_end != nullptr;
-    if (beside) {
+    if (beside && !tune.overlap_share && p->calibration == 0) {
+      // Calibration, once: this kept-back pass runs in place and this frame's primary side alone, both timed; the next frame
+      // reads the two durations Q and P (one wait) and starts from the share 100 Q / (Q + 1.05 P) - 3, which is where the
+      // measured optima of three workloads lie (castle 1080p 55 %, 4K 20 %, the 4096^3 tree 25 %). Feedback takes over from there.
+      DustHipPipeline::Probe& pr = p->probes[0];
+      if (!pr.a0) for (hipEvent_t* e : {&pr.a0, &pr.a1, &pr.b0, &pr.b1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
+      HIP_TRY(hipEventRecord(pr.b0, st));
+      const DustStatus rs = flush_surfel_pass(p);
+      if (rs != DUST_OK) return rs;
+      HIP_TRY(hipEventRecord(pr.b1, st));
+      HIP_TRY(hipEventRecord(pr.a0, st));
+      calibrating = true;
+      p->calibration = 1;
+    } else if (beside) {
+      if (!tune.overlap_share && p->calibration == 1) {
+        DustHipPipeline::Probe& pr = p->probes[0];
+        float P = 0.0f, Q = 0.0f;
+        HIP_TRY(hipEventSynchronize(pr.a1));
+        HIP_TRY(hipEventElapsedTime(&Q, pr.b0, pr.b1));
+        HIP_TRY(hipEventElapsedTime(&P, pr.a0, pr.a1));
+        if (P > 0.0f && Q > 0.0f) p->side_share = std::min(65.0f, std::max(10.0f, 100.0f * Q / (Q + 1.05f * P) - 3.0f));
+        p->calibration = 2;
+      }
       if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
       if (!p->ev_side_done) HIP_TRY(hipEventCreateWithFlags(&p->ev_side_done, hipEventDisableTiming));
-      // The share of the workgroup slots each side gets. A first guess from the ray counts (a surfel ray costs about eighteen
-      // coherent ones), then feedback: both sides are timed, and the pass gets three points more when it ends over a quarter later than the main
-      // side, three fewer when it ends before it.
+      // The share of the workgroup slots each side gets: from the calibration above (or, with a fixed DUST_HIP_OVERLAP_SHARE
+      // that skipped it, a guess from the ray counts), then feedback: both sides are timed, and the share moves until the pass
+      // ends about 6 % after the main side reaches the join.
       if (p->side_share == 0.0f) {
         const double surfel = double(p->gi_pool_size) * 18.0, pixel = 3.0 * double(p->width) * double(a.row_end - a.row_begin);
         p->side_share = float(std::min(60.0, std::max(15.0, 100.0 * surfel / (surfel + pixel))));
       }
-      for (auto& pr : p->probes) {
-        if (!pr.in_flight || hipEventQuery(pr.a1) != hipSuccess || hipEventQuery(pr.b1) != hipSuccess) continue;
-        float ta = 0.0f, tb = 0.0f;
-        if (hipEventElapsedTime(&ta, pr.a0, pr.a1) == hipSuccess && hipEventElapsedTime(&tb, pr.b0, pr.b1) == hipSuccess && ta > 0.0f && tb > 0.0f) {
-          // (the pass is mostly latency -- a sort, a trace as long as its longest ray, an apply -- and gains little from more
-          // slots while the primary kernels lose in proportion: it is left to finish up to a quarter later than the main side)
-          if (tb > 1.30f * ta) p->side_share = std::min(70.0f, p->side_share + 2.0f);
-          else if (tb < 1.15f * ta) p->side_share = std::max(10.0f, p->side_share - 2.0f);
+      {
+        float target = 0.0f;
+        uint32_t newest = 0;
+        for (auto& pr : p->probes) {
+          if (!pr.in_flight || hipEventQuery(pr.a1) != hipSuccess || hipEventQuery(pr.b1) != hipSuccess) continue;
+          float ta = 0.0f, tb = 0.0f;
+          if (hipEventElapsedTime(&ta, pr.a0, pr.a1) == hipSuccess && hipEventElapsedTime(&tb, pr.b0, pr.b1) == hipSuccess && ta > 0.0f && tb > 0.0f &&
+              pr.seq >= newest) {
+            // Measured optimum on three workloads (castle 1080p, castle 4K, the 4096^3 tree: shares 55, 20, 25 %): the pass
+            // ends 3 - 13 % after the main side reaches the join. The measurement is some frames old: the correction applies
+            // to the share IT ran under (proportional, at most six points), and the current share moves halfway there.
+            const float err = tb / ta - 1.06f;
+            newest = pr.seq;
+            target = (err > 0.05f || err < -0.05f) ? pr.share + std::min(6.0f, std::max(-6.0f, 20.0f * err)) : pr.share;
+          }
+          pr.in_flight = false;
         }
-        pr.in_flight = false;
+        if (target > 0.0f) p->side_share = std::min(70.0f, std::max(10.0f, 0.5f * (p->side_share + target)));
       }
       (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
       const uint32_t share = tune.overlap_share ? tune.overlap_share : uint32_t(p->side_share + 0.5f);
@@ -1361,7 +1392,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
         if (!pr.in_flight) {
           if (!pr.a0) for (hipEvent_t* e : {&pr.a0, &pr.a1, &pr.b0, &pr.b1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
           p->probe_live = int(p->probe_next % 8u);
-          ++p->probe_next;
+          pr.share = float(share);
+          pr.seq = ++p->probe_next;
         }
       }
       HIP_TRY(hipStreamWaitEvent(p->side, p->ev_frame_end, 0));  // the frame that recorded the pass is complete (final gather, commit)
@@ -1429,6 +1461,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // the hash and the pool are the kept-back pass's until the main stream has waited for it (the final gather's regrouping
   // pre-pass reads neither and still runs beside it)
   auto join_side = [&]() -> hipError_t {
+    if (calibrating) { calibrating = false; return hipEventRecord(p->probes[0].a1, st); }
     if (!overlapped) return hipSuccess;
     overlapped = false;
     if (p->probe_live >= 0) {
