@@ -282,7 +282,10 @@ def main():
         # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
         bytes_sf = (algorithmic_bytes(st[4], 0) + algorithmic_bytes(st[5], st[5].rays * (16 + 48 + 24)) - (st[4].hits + st[5].hits) * 5)
         kernels_ms_extra = {"k_final_gather": round(ms_fg, 4), "k_surfel_trace+apply": round(ms_sf, 4)}
-    if gi_mode and max(ms_fg, ms_sf) > ms_primary:
+    overlapped = gi_mode and not gi_bands and "DUST_HIP_NO_OVERLAP" not in os.environ
+    if overlapped:  # the primary + AO kernel and the surfel pass run beside each other: their durations are not their own
+        dominant = ("final_gather", bytes_fg, ms_fg)
+    elif gi_mode and max(ms_fg, ms_sf) > ms_primary:
         dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
     elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
         dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)

@@ -1479,9 +1479,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
     dust::FrameArgs g = a;
-    uint32_t ggrid = grid;
+    uint32_t ggrid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
     if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
       const uint32_t otx = (p->width + 31) / 32, oty = (a.row_end - a.row_begin + 31) / 32;
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
@@ -1496,6 +1495,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(join_side());
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
+    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }

@@ -297,7 +297,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const Du
  * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline*, uint32_t pass, DustHipPassStats* out);
 /* Kernel time over a run of frames (DUST_HIP_CONTEXT_TIMING): per pass kind -- 0 primary (or the fused primary + AO kernel), 1 AO,
- * 2 final gather (+ regroup, commit), 3 surfel pass (keys, sort, trace, apply) -- the summed HIP-event durations of its launches
+ * 2 final gather (+ commit; not the regrouping pre-pass), 3 surfel pass (keys, sort, trace, apply) -- the summed HIP-event durations of its launches
  * since the last call with mark != 0 (at most the 256 most recent ones), and how many launches that was. Waits for the stream.
  * Nothing is synchronised per frame: the pairs are recorded into a ring on the launch stream and read here. */
 DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline*, int mark, float ms_sum[4], uint32_t launches[4]);
