@@ -1545,32 +1545,45 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 
 // Regrouping pre-pass. Gather rays leave neighbouring pixels in unrelated directions, so an 8x8 pixel packet bounds
 // nothing by direction and most of its lanes idle through every instance visit. One workgroup per 32x32 pixel tile
-// orders the tile's LIVE pixels by the octant their ray points into (a stable counting sort on ballots: deterministic);
-// k_final_gather then takes 64 consecutive entries as a packet: same neighbourhood, one octant, no dead lanes.
+// orders the tile's LIVE pixels by direction bin -- the octant their ray points into times the order of its components'
+// magnitudes, 48 bins (a stable counting sort on ballots: deterministic; 8 octants alone: final gather +9 %, 24 bins: +2 %);
+// k_final_gather then takes 64 consecutive entries as a packet: same neighbourhood, similar directions, no dead lanes.
 // Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
 constexpr uint32_t kOrderTile = 32, kOrderSlots = kOrderTile * kOrderTile;
 __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
   ArgsRef a = launch_args();
   constexpr uint32_t kWaves = kOrderSlots / 64;
-  __shared__ uint32_t cnt[8 * kWaves];   // [octant][wave] counts, then their exclusive prefix in that (octant-major) order
-  __shared__ uint32_t half_total[2];
+  constexpr uint32_t kBins = 48;          // direction octant x order of the components' magnitudes
+  constexpr uint32_t kScanWaves = kBins * kWaves / 64;
+  __shared__ uint32_t cnt[kBins * kWaves];   // [bin][wave] counts, then their exclusive prefix in that (bin-major) order
+  __shared__ uint32_t part_total[kScanWaves];
   const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
   const uint32_t px = tx * kOrderTile + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTile + (threadIdx.x / kOrderTile);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   V3 inval, loc, ad;
   const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
-  const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) : 8u;
-  uint32_t below = 0;  // lanes of this wave with the same key and a lower lane id
-#pragma unroll
-  for (uint32_t k = 0; k < 8; ++k) {
-    const uint64_t m = __ballot(key == k);
-    if (lane == 0) cnt[k * kWaves + wave] = (uint32_t)__popcll(m);
-    if (key == k) below = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  }
+  const float ax = fabsf(ad.x), ay = fabsf(ad.y), az = fabsf(ad.z);
+  // which of the 6 orders |x|,|y|,|z| are in: dominant axis, then which of the other two is larger
+  const uint32_t dom = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+  const uint32_t sec = dom == 0u ? (ay >= az ? 0u : 1u) : (dom == 1u ? (ax >= az ? 0u : 1u) : (ax >= ay ? 0u : 1u));
+  const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec : kBins;
+  // rank among the wave's lanes of the same bin: the lanes that agree with this one on every bit of the key (six ballots,
+  // whatever the number of bins), as radix.hip ranks digits; the first lane of each group publishes the group's size
+  for (uint32_t i = threadIdx.x; i < kBins * kWaves; i += kOrderSlots) cnt[i] = 0u;
   __syncthreads();
-  // exclusive scan of the 128 counters by the first two waves (each scans its 64, the second adds the first's total)
+  uint64_t peers = ~0ull;
+#pragma unroll
+  for (uint32_t bit = 0; bit < 6; ++bit) {
+    const bool one = (key >> bit) & 1u;
+    const uint64_t m = __ballot(one);
+    peers &= one ? m : ~m;
+  }
+  const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));  // lanes of this wave with the same key and a lower lane id
+  if (key < kBins && below == 0) cnt[key * kWaves + wave] = (uint32_t)__popcll(peers);
+  __syncthreads();
+  // exclusive scan of the kBins x kWaves counters by the first kScanWaves waves (each scans its 64, then adds the totals before it)
   uint32_t v = 0, inc = 0;
-  if (threadIdx.x < 8 * kWaves) {
+  if (threadIdx.x < kBins * kWaves) {
     v = cnt[threadIdx.x];
     inc = v;
 #pragma unroll
@@ -1578,13 +1591,21 @@ __global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
       const uint32_t up = __shfl_up(inc, d);
       if (lane >= d) inc += up;
     }
-    if (lane == 63) half_total[wave] = inc;
+    if (lane == 63) part_total[wave] = inc;
   }
   __syncthreads();
-  if (threadIdx.x < 8 * kWaves) cnt[threadIdx.x] = inc - v + (wave == 1 ? half_total[0] : 0u);
+  if (threadIdx.x < kBins * kWaves) {
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += part_total[w];
+    cnt[threadIdx.x] = inc - v + before;
+  }
   __syncthreads();
   if (live) a.gi.order[(size_t)tile * kOrderSlots + cnt[key * kWaves + wave] + below] = py * a.width + px;
-  if (threadIdx.x == 0) a.gi.order_count[tile] = half_total[0] + half_total[1];
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < kScanWaves; ++w) total += part_total[w];
+    a.gi.order_count[tile] = total;
+  }
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
