@@ -268,7 +268,7 @@ struct DustHipPipeline {
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
   DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
-  DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 32x32 tile grouped by ray octant
+  DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 64x64 tile grouped by ray direction bin
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
@@ -1482,13 +1482,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     dust::FrameArgs g = a;
     uint32_t ggrid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
     if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
-      const uint32_t otx = (p->width + 31) / 32, oty = (a.row_end - a.row_begin + 31) / 32;
+      const uint32_t otx = (p->width + 63) / 64, oty = (a.row_end - a.row_begin + 63) / 64;
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
       HIP_TRY(join_side());
-      g.tiles_x = otx * oty * 16;  // 16 packets of 64 per tile, the empty ones skipped by the kernel
+      g.tiles_x = otx * oty * 64;  // 64 packets of 64 per tile, the empty ones skipped by the kernel
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
@@ -1662,8 +1662,8 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(hipMemset(p->gi_owner.p, 0, size_t(surfel_pool_size) * 4));
   HIP_TRY(p->gi_pixel_surfel.alloc(size_t(p->width) * p->height * 16));
   {
-    const size_t tiles = size_t((p->width + 31) / 32) * ((p->height + 31) / 32);
-    HIP_TRY(p->gi_order.alloc(tiles * 1024 * 4));
+    const size_t tiles = size_t((p->width + 63) / 64) * ((p->height + 63) / 64 + 1);
+    HIP_TRY(p->gi_order.alloc(tiles * 4096 * 4));
     HIP_TRY(p->gi_order_count.alloc(tiles * 4));
   }
   HIP_TRY(p->gi_requests.alloc(size_t(surfel_pool_size) * sizeof(dust::DevHashRequest)));

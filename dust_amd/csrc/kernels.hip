@@ -1544,68 +1544,74 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 }
 
 // Regrouping pre-pass. Gather rays leave neighbouring pixels in unrelated directions, so an 8x8 pixel packet bounds
-// nothing by direction and most of its lanes idle through every instance visit. One workgroup per 32x32 pixel tile
-// orders the tile's LIVE pixels by direction bin -- the octant their ray points into times the order of its components'
-// magnitudes, 48 bins (a stable counting sort on ballots: deterministic; 8 octants alone: final gather +9 %, 24 bins: +2 %);
-// k_final_gather then takes 64 consecutive entries as a packet: same neighbourhood, similar directions, no dead lanes.
+// nothing by direction and most of its lanes idle through every instance visit. One workgroup per 64x64 pixel tile (four
+// pixels per thread) orders the tile's LIVE pixels by direction bin -- the octant their ray points into times the order of
+// its components' magnitudes, 48 bins -- with a stable counting sort on ballots (deterministic); k_final_gather then takes
+// 64 consecutive entries as a packet: same neighbourhood, similar directions, no dead lanes. Measured on the castle, final
+// gather kernel: 32x32 tiles and 8 octants (round 1) 0.304 ms, 24 bins 0.281, 48 bins 0.276, 96 bins 0.273 (but the frame no
+// faster); 48 bins on 64x32 tiles 0.267, 64x64 0.256, 128x64 0.255 (frame no faster): more rays per tile make a packet's 64
+// entries fall into fewer bins, until the spread of their origins costs as much.
 // Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
-constexpr uint32_t kOrderTile = 32, kOrderSlots = kOrderTile * kOrderTile;
-__global__ void __launch_bounds__(kOrderSlots) k_gather_order(const FrameArgs) {
+constexpr uint32_t kOrderTile = 32, kOrderTileW = 64, kOrderTileH = 64, kOrderThreads = kOrderTile * kOrderTile, kOrderSlots = kOrderTileW * kOrderTileH;
+__global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs) {
   ArgsRef a = launch_args();
-  constexpr uint32_t kWaves = kOrderSlots / 64;
-  constexpr uint32_t kBins = 48;          // direction octant x order of the components' magnitudes
-  constexpr uint32_t kScanWaves = kBins * kWaves / 64;
-  __shared__ uint32_t cnt[kBins * kWaves];   // [bin][wave] counts, then their exclusive prefix in that (bin-major) order
-  __shared__ uint32_t part_total[kScanWaves];
+  constexpr uint32_t kWaves = kOrderSlots / 64;   // "virtual" waves: the tile's 32x32 quarter h is waves 16 h .. 16 h + 15 of the order
+  constexpr uint32_t kBins = 48;
+  constexpr uint32_t kCounters = kBins * kWaves, kChunks = (kCounters + kOrderThreads - 1) / kOrderThreads;
+  __shared__ uint32_t cnt[kCounters];
+  __shared__ uint32_t part_total[kOrderThreads / 64];
+  __shared__ uint32_t grand_total;
   const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
-  const uint32_t px = tx * kOrderTile + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTile + (threadIdx.x / kOrderTile);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  V3 inval, loc, ad;
-  const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
-  const float ax = fabsf(ad.x), ay = fabsf(ad.y), az = fabsf(ad.z);
-  // which of the 6 orders |x|,|y|,|z| are in: dominant axis, then which of the other two is larger
-  const uint32_t dom = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
-  const uint32_t sec = dom == 0u ? (ay >= az ? 0u : 1u) : (dom == 1u ? (ax >= az ? 0u : 1u) : (ax >= ay ? 0u : 1u));
-  const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec : kBins;
-  // rank among the wave's lanes of the same bin: the lanes that agree with this one on every bit of the key (six ballots,
-  // whatever the number of bins), as radix.hip ranks digits; the first lane of each group publishes the group's size
-  for (uint32_t i = threadIdx.x; i < kBins * kWaves; i += kOrderSlots) cnt[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < kCounters; i += kOrderThreads) cnt[i] = 0u;
+  if (threadIdx.x == 0) grand_total = 0u;
   __syncthreads();
-  uint64_t peers = ~0ull;
+  constexpr uint32_t kSub = kOrderSlots / kOrderThreads;
+  uint32_t keys[kSub], below[kSub], pix[kSub];
+  bool lives[kSub];
 #pragma unroll
-  for (uint32_t bit = 0; bit < 6; ++bit) {
-    const bool one = (key >> bit) & 1u;
-    const uint64_t m = __ballot(one);
-    peers &= one ? m : ~m;
+  for (uint32_t h = 0; h < kSub; ++h) {
+    constexpr uint32_t kSubX = kOrderTileW / kOrderTile;
+    const uint32_t px = tx * kOrderTileW + (h % kSubX) * 32u + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTileH + (h / kSubX) * 32u + (threadIdx.x / kOrderTile);
+    V3 inval, loc, ad;
+    const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
+    const float ax = fabsf(ad.x), ay = fabsf(ad.y), az = fabsf(ad.z);
+    const uint32_t dom = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+    const uint32_t sec = dom == 0u ? (ay >= az ? 0u : 1u) : (dom == 1u ? (ax >= az ? 0u : 1u) : (ax >= ay ? 0u : 1u));
+    const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec : kBins;
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 6; ++bit) {
+      const bool one = (key >> bit) & 1u;
+      const uint64_t m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    keys[h] = key; lives[h] = live; pix[h] = py * a.width + px;
+    below[h] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    if (key < kBins && below[h] == 0) cnt[key * kWaves + h * 16u + wave] = (uint32_t)__popcll(peers);
   }
-  const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));  // lanes of this wave with the same key and a lower lane id
-  if (key < kBins && below == 0) cnt[key * kWaves + wave] = (uint32_t)__popcll(peers);
   __syncthreads();
-  // exclusive scan of the kBins x kWaves counters by the first kScanWaves waves (each scans its 64, then adds the totals before it)
-  uint32_t v = 0, inc = 0;
-  if (threadIdx.x < kBins * kWaves) {
-    v = cnt[threadIdx.x];
-    inc = v;
+  for (uint32_t chunk = 0; chunk < kChunks; ++chunk) {
+    const uint32_t i = chunk * kOrderThreads + threadIdx.x;
+    uint32_t v = i < kCounters ? cnt[i] : 0u, inc = v;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
       const uint32_t up = __shfl_up(inc, d);
       if (lane >= d) inc += up;
     }
     if (lane == 63) part_total[wave] = inc;
-  }
-  __syncthreads();
-  if (threadIdx.x < kBins * kWaves) {
-    uint32_t before = 0;
+    __syncthreads();
+    uint32_t before = grand_total;
     for (uint32_t w = 0; w < wave; ++w) before += part_total[w];
-    cnt[threadIdx.x] = inc - v + before;
+    if (i < kCounters) cnt[i] = inc - v + before;
+    __syncthreads();
+    if (threadIdx.x == kOrderThreads - 1u) grand_total = before + inc;
+    __syncthreads();
   }
-  __syncthreads();
-  if (live) a.gi.order[(size_t)tile * kOrderSlots + cnt[key * kWaves + wave] + below] = py * a.width + px;
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (uint32_t w = 0; w < kScanWaves; ++w) total += part_total[w];
-    a.gi.order_count[tile] = total;
-  }
+#pragma unroll
+  for (uint32_t h = 0; h < kSub; ++h)
+    if (lives[h]) a.gi.order[(size_t)tile * kOrderSlots + cnt[keys[h] * kWaves + h * 16u + wave] + below[h]] = pix[h];
+  if (threadIdx.x == 0) a.gi.order_count[tile] = grand_total;
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
@@ -2353,7 +2359,7 @@ hipError_t launch_gi_import(const FrameArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderSlots), 0, s, a);
+  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderThreads), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
