@@ -1402,6 +1402,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       const uint64_t key = p->view_key;
       // (p->view_key is set below for THIS frame; the pass orders its work items under the key of the frame it belongs to)
       p->view_key = p->pending.view_key;
+      p->pending.args.prio_floor = 3u;  // the longer side of the two: its waves win the issue arbitration on the SIMDs they share (GI frame -2 %)
       const DustStatus rs = run_surfel_pass(p, p->pending.args, p->pending.passes, false, p->side, side_resident);
       p->view_key = key;
       if (rs != DUST_OK) return rs;

@@ -1010,9 +1010,11 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t tile, Packet&
     // the few at the front get the arbiter's priority, so the critical path runs at nearly a lone wave's speed while the
     // waves that give way have slack.
     const uint32_t per = (a.tiles_x * a.tiles_y + kRegions - 1u) / kRegions, pos = tile % per;
-    if (pos < (per >> 5)) __builtin_amdgcn_s_setprio(3);
-    else if (pos < (per >> 3)) __builtin_amdgcn_s_setprio(2);
-    else if (pos < (per >> 1)) __builtin_amdgcn_s_setprio(1);
+    const uint32_t rank = pos < (per >> 5) ? 3u : (pos < (per >> 3) ? 2u : (pos < (per >> 1) ? 1u : 0u));
+    const uint32_t prio = rank > a.prio_floor ? rank : a.prio_floor;
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     tile = a.tile_order[tile];  // ticket -> tile, most expensive tiles of the band first
   }
