@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ keeps for a round:
 #   python tools/kernel_sections.py --build && gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
-# writes gpurun_out/<tag>_{gpu_tests.log,bench.log,bench_gi.log,kernel_stats.{txt,json},pmc.txt}.
+# writes gpurun_out/<tag>_{gpu_tests.log,bench*.log,kernel_stats*.{txt,json},pmc*.txt,sections*.txt,tile_costs.txt,denoise_kernels.txt}.
 # Counter passes run separately from the kernel-trace/stats pass (one counter group per run).
 tag=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -22,6 +22,7 @@ tail -1 "$out/${tag}_bench_deep.log" | cut -c1-600
 python bench.py --shard bands > "$out/${tag}_bench_bands.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --shard bands --no-cpu-baseline > "$out/${tag}_bench_gi_bands.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_NO_OVERLAP=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 
 cd /tmp || exit 1
@@ -58,6 +59,7 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o denoise -- \
     python "$R/tools/denoise_timing.py" > "$out/${tag}_denoise_timing.log" 2>&1
 { grep "GI frame" "$out/${tag}_denoise_timing.log"; python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'denoise_results.db') | grep -i "denoise\|kernel  "; } > "$out/${tag}_denoise_kernels.txt" 2>&1
 python "$R/tools/kernel_sections.py" > "$out/${tag}_sections.txt" 2>&1
+python "$R/tools/kernel_sections.py" --deep > "$out/${tag}_sections_deep.txt" 2>&1
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
