@@ -1254,6 +1254,11 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->noise0.p)
     return fail(DUST_ERR_NOT_READY, "blue-noise texture 0 (scalar) not loaded");
   const bool sharded = (fp->passes & DUST_PASS_GI_SHARDED) != 0;
+  // (argument checks all come before the first launch: a frame that has started is finished)
+  if ((fp->passes & DUST_PASS_ACCUMULATE) && (fp->passes & DUST_PASS_DENOISE))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "DUST_PASS_ACCUMULATE and DUST_PASS_DENOISE both keep their running result in DUST_PLANE_ACCUM: one per frame");
+  if ((fp->passes & DUST_PASS_DENOISE) && (fp->row_begin != 0 || (fp->row_end != 0 && fp->row_end != p->height)))
+    return fail(DUST_ERR_UNSUPPORTED, "DUST_PASS_DENOISE reprojects and blurs across rows: run it on the whole (gathered) frame");
   if (!sharded && (fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && (fp->row_begin != 0 || (fp->row_end != 0 && fp->row_end != p->height)))
     return fail(DUST_ERR_UNSUPPORTED, "a GI pass on a row band needs DUST_PASS_GI_SHARDED and the exchange of dust_hip_pipeline_gi_exchange");
   if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && (fp->passes & DUST_PASS_SURFEL))
@@ -1526,15 +1531,11 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
-    if (fp->passes & DUST_PASS_DENOISE)
-      return fail(DUST_ERR_INVALID_ARGUMENT, "DUST_PASS_ACCUMULATE and DUST_PASS_DENOISE both keep their running result in DUST_PLANE_ACCUM: one per frame");
     p->have_history = false;  // the plane now holds an N-frame mean, not the denoiser's history
     HIP_TRY(dust::launch_accumulate(a, st));
     p->accum_count += 1;
   }
   if (fp->passes & DUST_PASS_DENOISE) {
-    if (a.row_begin != 0 || a.row_end != p->height)
-      return fail(DUST_ERR_UNSUPPORTED, "DUST_PASS_DENOISE reprojects and blurs across rows: run it on the whole (gathered) frame");
     const size_t px = size_t(p->width) * p->height;
     if (!p->hist_accum[0].p) {
       for (int k = 0; k < 2; ++k) {
