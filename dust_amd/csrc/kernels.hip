@@ -1551,7 +1551,7 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 // its components' magnitudes, 48 bins -- with a stable counting sort on ballots (deterministic); k_final_gather then takes
 // 64 consecutive entries as a packet: same neighbourhood, similar directions, no dead lanes. Measured on the castle, final
 // gather kernel: 32x32 tiles and 8 octants (round 1) 0.304 ms, 24 bins 0.281, 48 bins 0.276, 96 bins 0.273 (but the frame no
-// faster); 48 bins on 64x32 tiles 0.267, 64x64 0.256, 128x64 0.255 (frame no faster): more rays per tile make a packet's 64
+// faster); 48 bins on 64x32 tiles 0.267, 64x64 0.256 (96 bins there: 0.250, frame 0.3 % faster), 128x64 0.255 (frame no faster): more rays per tile make a packet's 64
 // entries fall into fewer bins, until the spread of their origins costs as much.
 // Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
 constexpr uint32_t kOrderTile = 32, kOrderTileW = 64, kOrderTileH = 64, kOrderThreads = kOrderTile * kOrderTile, kOrderSlots = kOrderTileW * kOrderTileH;
@@ -1559,9 +1559,9 @@ __global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs)
   ArgsRef a = launch_args();
   constexpr uint32_t kWaves = kOrderSlots / 64;   // "virtual" waves: the tile's 32x32 quarter h is waves 16 h .. 16 h + 15 of the order
   constexpr uint32_t kBins = 48;
-  constexpr uint32_t kCounters = kBins * kWaves, kChunks = (kCounters + kOrderThreads - 1) / kOrderThreads;
+  constexpr uint32_t kCounters = kBins * kWaves;
   __shared__ uint32_t cnt[kCounters];
-  __shared__ uint32_t part_total[kOrderThreads / 64];
+  __shared__ uint32_t bin_base[kBins];
   __shared__ uint32_t grand_total;
   const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1593,26 +1593,40 @@ __global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs)
     if (key < kBins && below[h] == 0) cnt[key * kWaves + h * 16u + wave] = (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  for (uint32_t chunk = 0; chunk < kChunks; ++chunk) {
-    const uint32_t i = chunk * kOrderThreads + threadIdx.x;
-    uint32_t v = i < kCounters ? cnt[i] : 0u, inc = v;
+  // a bin's counters are one per lane of a wavefront (64 virtual waves): each wave scans whole bins with shuffles, then the first
+  // wave scans the bins' totals -- two barriers, whatever the number of bins
+  static_assert(kWaves == 64, "one counter per lane");
+  for (uint32_t b = wave; b < kBins; b += kOrderThreads / 64u) {
+    const uint32_t v = cnt[b * kWaves + lane];
+    uint32_t inc = v;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
       const uint32_t up = __shfl_up(inc, d);
       if (lane >= d) inc += up;
     }
-    if (lane == 63) part_total[wave] = inc;
-    __syncthreads();
-    uint32_t before = grand_total;
-    for (uint32_t w = 0; w < wave; ++w) before += part_total[w];
-    if (i < kCounters) cnt[i] = inc - v + before;
-    __syncthreads();
-    if (threadIdx.x == kOrderThreads - 1u) grand_total = before + inc;
-    __syncthreads();
+    cnt[b * kWaves + lane] = inc - v;
+    if (lane == 63) bin_base[b] = inc;
   }
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < kBins; base += 64u) {
+      const uint32_t v = base + lane < kBins ? bin_base[base + lane] : 0u;
+      uint32_t inc = v;
+#pragma unroll
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+      }
+      if (base + lane < kBins) bin_base[base + lane] = carry + inc - v;
+      carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) grand_total = carry;
+  }
+  __syncthreads();
 #pragma unroll
   for (uint32_t h = 0; h < kSub; ++h)
-    if (lives[h]) a.gi.order[(size_t)tile * kOrderSlots + cnt[keys[h] * kWaves + h * 16u + wave] + below[h]] = pix[h];
+    if (lives[h]) a.gi.order[(size_t)tile * kOrderSlots + bin_base[keys[h]] + cnt[keys[h] * kWaves + h * 16u + wave] + below[h]] = pix[h];
   if (threadIdx.x == 0) a.gi.order_count[tile] = grand_total;
 }
 
