@@ -161,7 +161,8 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
                                                        {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
                                                        {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"},
-                                                       {"DUST_HIP_NO_OVERLAP": "1"}, {"DUST_HIP_OVERLAP_SHARE": "75"}], frames=5)
+                                                       {"DUST_HIP_NO_OVERLAP": "1"}, {"DUST_HIP_OVERLAP_SHARE": "75"}, {"DUST_HIP_OVERLAP_SHARE": "10"}],
+                                          frames=5)
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:
         for x, y in zip(st[0], other):
