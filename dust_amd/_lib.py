@@ -162,6 +162,7 @@ SYMBOLS = {
     "dust_hip_pipeline_read_plane": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "dust_hip_pipeline_configure_gi": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "dust_hip_pipeline_read_gi": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
+    "dust_hip_pipeline_write_gi": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
     "dust_hip_pipeline_gi_exchange": (C.c_int, [_P, C.c_uint32, C.POINTER(GiExchange)]),
     "dust_hip_gi_export": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "dust_hip_gi_import": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),

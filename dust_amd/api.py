@@ -482,6 +482,17 @@ class StandardPipeline:
         return h, s
 
 
+def _write_gi(self, hash_entries, pool):
+    """Restore a state saved with read_gi() into a pipeline configured with the same capacity and pool size."""
+    h = np.ascontiguousarray(hash_entries, np.uint32)
+    s = np.ascontiguousarray(pool, SURFEL_DTYPE)
+    L.check(self._lib.dust_hip_pipeline_write_gi(self._h, 0, _ptr(h), h.nbytes))
+    L.check(self._lib.dust_hip_pipeline_write_gi(self._h, 1, _ptr(s), s.nbytes))
+
+
+StandardPipeline.write_gi = _write_gi
+
+
 def load_png_array(data: bytes):
     """PNG / APNG -> array (layers, height, width, channels), uint8 (big-endian uint16 for 16-bit files): the reference's
     PngLoader (rhyolite_bevy/src/loaders/png.rs:70-200). RGB comes back as RGBA with a zero fourth channel."""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,12 +128,34 @@ struct DeviceBuffer {
     bytes = n;
     return hipMalloc(&p, n ? n : 16);
   }
-  hipError_t upload(const void* src, size_t n) {
+  // Host -> device on the CONTEXT's stream, then wait: a blocking hipMemcpy is a null-stream operation, which a
+  // hipStreamNonBlocking stream is not ordered against (and from pageable memory it may return before the DMA has landed).
+  hipError_t upload(const void* src, size_t n, hipStream_t st) {
     hipError_t e = alloc(n);
     if (e != hipSuccess || n == 0) return e;
-    return hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
   }
 };
+
+// Copies between host and device go through the context's stream and wait for it: the blocking hipMemcpy / hipMemset are
+// null-stream operations, and the context's stream is created hipStreamNonBlocking, i.e. NOT ordered against those.
+hipError_t copy_wait(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
+// Lifetimes. Every handle of the device side is reference-counted inside the library: a model, scene or pipeline keeps its
+// context alive, a scene keeps the models it instances alive. dust_hip_*_destroy gives up the CALLER's reference; the object
+// (and its device memory) goes when the last user does. So handles may be destroyed in any order -- a garbage collector
+// finalising a context before its models (Python's cycle collector does exactly that, in creation order) is fine.
+struct RefCounted {
+  std::atomic<uint32_t> refs{1};
+};
+template <class T> T* retain(T* o) { if (o) o->refs.fetch_add(1, std::memory_order_relaxed); return o; }
+// (release() per type below: what dies with the last reference differs)
 
 }  // namespace
 
@@ -142,7 +165,7 @@ struct DustVdbPool { dust::vdb::Pool pool; DustVdbPool(size_t b, unsigned c) : p
 struct DustVoxScene { dust::vox::Scene scene; };
 struct DustSkyDataset { dust::sky::Dataset data; };
 
-struct DustHipContext {
+struct DustHipContext : RefCounted {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -151,8 +174,15 @@ struct DustHipContext {
   int num_cus = 256;
   size_t max_lds = 64 * 1024;
   DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
-  std::vector<struct DustHipPipeline*> pipelines;  // alive pipelines of this context (a deferred surfel pass is flushed through it)
 };
+static void release(DustHipContext* c) {
+  if (!c || c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->srgb_lut.release();
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
 
 // device-side voxel edits (edit.hip): the dense voxel grid and the scratch tables of the rebuild, created on a model's first edit
 struct EditState {
@@ -160,35 +190,95 @@ struct EditState {
   uint32_t batch_capacity = 0;
 };
 
-struct DustHipModel {
-  DustHipContext* ctx = nullptr;
+struct DustHipModel : RefCounted {
+  DustHipContext* ctx = nullptr;  // retained
   DeviceBuffer root, l2, l2_cells, mid, dense_mask, blocks, materials, palette;
   std::vector<uint8_t> host_root;  // 640 B: mask + prefix, what the kernels stage in LDS
   dust::DevModel dev{};
   uint32_t id = 0;
   uint64_t n_materials = 0;
   uint32_t generation = 0;  // bumped by every edit: scenes record it at commit and refuse to render a stale copy
+  bool has_material_255 = false;  // the edit grid stores palette index + 1 in a byte: such a model cannot become editable
   std::unique_ptr<EditState> edit;
 };
+static void release(const DustHipModel* cm) {
+  DustHipModel* m = const_cast<DustHipModel*>(cm);
+  if (!m || m->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  DustHipContext* c = m->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);  // launches that read the arrays are done before they go
+  delete m;
+  release(c);
+}
 
 struct HostInstance {
-  const DustHipModel* model;
+  const DustHipModel* model;  // retained
   float o2w[12];
   float prev[16];
 };
 
-struct DustHipScene {
-  DustHipContext* ctx = nullptr;
+// Where a committed scene lives on the device: ONE allocation, the arrays at offsets inside it -- what depends on the models
+// first, what depends on the instance transforms behind it. A commit fills a pinned host image of the same layout and sends
+// it (all of it after a structural change, the transform-dependent tail otherwise) with one asynchronous copy on the context's
+// stream (tlas.rs:37-65 rebuilds the TLAS inside the frame's command stream the same way): no allocation, no wait, and the
+// kernels' pointers stay what they were until instances are added.
+struct SceneLayout {
+  size_t models = 0, root_table = 0, instances = 0, boxes = 0, visits = 0, total = 0;
+  static SceneLayout make(size_t n_inst, size_t n_models, size_t n_roots) {
+    SceneLayout l;
+    auto place = [&l](size_t bytes) { const size_t at = l.total; l.total = (l.total + bytes + 255) & ~size_t(255); return at; };
+    l.models = place(n_models * sizeof(dust::DevModel));
+    l.root_table = place(n_roots * dust::kN16LdsBytes);
+    l.instances = place(n_inst * sizeof(dust::DevInstance));
+    l.boxes = place((n_inst + 1) * sizeof(dust::DevBox));
+    l.visits = place((n_inst + 1) * sizeof(dust::DevVisit));
+    return l;
+  }
+};
+
+struct DustHipScene : RefCounted {
+  DustHipContext* ctx = nullptr;  // retained
   std::vector<HostInstance> instances;
-  std::vector<const DustHipModel*> models;  // distinct models, index == DevModel slot
+  std::vector<uint8_t> dirty;                // per instance: transform changed since the last commit
+  std::vector<const DustHipModel*> models;   // distinct models, index == DevModel slot (kept alive through `instances`)
   std::vector<uint32_t> model_generation;    // their edit generations when the scene was committed
-  DeviceBuffer d_models, d_instances, d_root_table, d_boxes, d_visits;
-  std::vector<uint8_t> root_table;  // host copy of the packed LDS roots
+  std::vector<uint32_t> instance_slot;       // per instance: its model's slot
+  bool structure_dirty = true;               // instances were added (or a model edited): slots, roots and capacity are re-derived
+  // device image + pinned staging copies of it, used in turn (a slot is rewritten only after the copy that read it has run)
+  DeviceBuffer image;
+  SceneLayout layout;
+  size_t image_capacity = 0;  // bytes
+  static constexpr int kStaging = 3;
+  struct Staging { void* host = nullptr; hipEvent_t copied = nullptr; bool in_flight = false; } staging[kStaging];
+  size_t staging_bytes = 0;
+  uint32_t staging_next = 0;
+  std::vector<uint8_t> master;   // host master copy of the image (dirty instances are re-derived in place)
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
   uint32_t n_lds_models = 0;
-  uint64_t revision = 0;  // bumped by every add / set_transform / commit (what the cost-ordered hand-out keys its view on)
+  uint64_t revision = 0;  // bumped by every commit (what the cost-ordered hand-out keys its view on)
   bool committed = false;
+  const uint8_t* dev(size_t off) const { return static_cast<const uint8_t*>(image.p) + off; }
+  void free_staging() {
+    for (Staging& st : staging) {
+      if (st.copied) { (void)hipEventSynchronize(st.copied); (void)hipEventDestroy(st.copied); st.copied = nullptr; }
+      if (st.host) { (void)hipHostFree(st.host); st.host = nullptr; }
+      st.in_flight = false;
+    }
+    staging_bytes = 0;
+  }
 };
+static void release(const DustHipScene* cs) {
+  DustHipScene* s = const_cast<DustHipScene*>(cs);
+  if (!s || s->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  DustHipContext* c = s->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  s->free_staging();
+  s->image.release();
+  for (HostInstance& hi : s->instances) release(hi.model);
+  delete s;
+  release(c);
+}
 
 // DUST_HIP_* diagnostic switches, read ONCE when a pipeline is created (not per frame: a frame is ~0.3 ms of GPU time)
 struct Tuning {
@@ -201,8 +291,6 @@ struct Tuning {
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
-  bool no_overlap = false;      // DUST_HIP_NO_OVERLAP: the surfel pass runs at the end of its own frame, on the main stream
-  uint32_t overlap_share = 0;   // DUST_HIP_OVERLAP_SHARE: percent of the workgroup slots the overlapped surfel pass gets (0: balanced by feedback)
   static uint32_t num(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
@@ -218,15 +306,12 @@ struct Tuning {
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
-    t.no_overlap = std::getenv("DUST_HIP_NO_OVERLAP") != nullptr;
-    t.overlap_share = num("DUST_HIP_OVERLAP_SHARE", 0);
-    if (t.overlap_share) t.overlap_share = std::min(90u, std::max(10u, t.overlap_share));
     return t;
   }
 };
 
 struct DustHipPipeline {
-  DustHipContext* ctx = nullptr;
+  DustHipContext* ctx = nullptr;  // retained
   Tuning tune;
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
@@ -245,25 +330,6 @@ struct DustHipPipeline {
     bool measured = false;   // cost[] holds a launch's measurements (maybe not the last launch's)
   } tile_history[4];
   uint64_t view_key = 0;     // this frame's camera + scene revision + sun + row band
-  // Deferred surfel pass (see run_surfel_pass): the pass of frame N, launched with frame N + 1's primary kernels on a second stream
-  struct PendingSurfel {
-    bool valid = false;
-    dust::FrameArgs args{};
-    uint32_t passes = 0;
-    uint64_t view_key = 0;
-    const DustHipScene* scene = nullptr;
-    uint64_t scene_revision = 0;
-  } pending;
-  hipStream_t side = nullptr;               // created on first use
-  uint32_t pending_bpc = 2;                 // workgroups per CU the kept-back pass's LDS size allows
-  hipEvent_t ev_frame_end = nullptr, ev_side_done = nullptr;
-  // Balance of the two sides: timed pairs around each side of an overlapped frame, read back (without waiting) some frames
-  // later; the side that took longer gets a few more of the workgroup slots next time
-  struct Probe { hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr; bool in_flight = false; float share = 0.0f; uint32_t seq = 0; } probes[8];
-  uint32_t probe_next = 0;
-  int probe_live = -1;       // the probe this frame records into, -1 = none
-  float side_share = 0.0f;   // percent of the slots for the kept-back pass; 0 = not estimated yet
-  int calibration = 0;       // 0: the next kept-back pass runs in place, timed, and so do that frame's primary kernels; 1: read; 2: done
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
@@ -292,15 +358,10 @@ struct DustHipPipeline {
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
   bool stats_valid = false;
   bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
-  dust::DevStats host_stats[8] = {};
+  dust::DevStats* host_stats = nullptr;  // pinned, 8 records: where the counting build's statistics land
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
-// a kept-back surfel pass (dust_hip_render_frame) is launched before anything looks at what it writes or frees what it reads
-static DustStatus flush_surfel_pass(DustHipPipeline* p);
-static DustStatus flush_context(DustHipContext* c, const DustHipScene* scene /* null: every pipeline */);
-#define FLUSH_TRY(expr) do { const DustStatus fs_ = (expr); if (fs_ != DUST_OK) return fs_; } while (0)
-
 // ------------------------------------------------------------------ device hierarchy build
 namespace {
 
@@ -661,16 +722,11 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   *out = c.release();
   return DUST_OK;
 }
-void dust_hip_context_destroy(DustHipContext* c) {
-  if (!c) return;
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-  delete c;
-}
+void dust_hip_context_destroy(DustHipContext* c) { release(c); }  // (models, scenes and pipelines made from it keep it alive)
 DustStatus dust_hip_sync(DustHipContext* c) {
   if (!c) return fail(DUST_ERR_INVALID_ARGUMENT, "null context");
-  FLUSH_TRY(flush_context(c, nullptr));
+  HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  for (DustHipPipeline* p : c->pipelines) if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   return DUST_OK;
 }
 
@@ -693,11 +749,14 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
       if (need > n_materials) return fail(DUST_ERR_INVALID_ARGUMENT, "block material_ptr runs past the material buffer");
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    std::unique_ptr<DustHipModel> m(new DustHipModel);
-    m->ctx = ctx;
-    HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size()));
+    // (owned through the reference count from here on: an early return releases it, and with it the context reference)
+    struct Drop { DustHipModel* m; ~Drop() { release(m); } } owner{new DustHipModel};
+    DustHipModel* m = owner.m;
+    m->ctx = retain(ctx);
+    const hipStream_t up = ctx->stream;
+    HIP_TRY(m->root.upload(root.bytes.data(), root.bytes.size(), up));
     m->host_root.assign(root.bytes.begin(), root.bytes.begin() + dust::kN16LdsBytes);
-    HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size()));
+    HIP_TRY(m->l2.upload(l2.bytes.data(), l2.bytes.size(), up));
     if (tree_extent_log2 == 12) {  // the per-cell table the DEEP kernel variants look 16-cells up in: {mid index, child mask} per cell
       const size_t n_l2 = l2.bytes.size() / dust::kN16Bytes;
       std::vector<dust::DevL2Cell> cells(n_l2 * 4096, dust::DevL2Cell{0xFFFFFFFFu, 0u, 0ull});
@@ -720,16 +779,17 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
             ++run;
           }
       }
-      HIP_TRY(m->l2_cells.upload(cells.data(), cells.size() * sizeof(dust::DevL2Cell)));
+      HIP_TRY(m->l2_cells.upload(cells.data(), cells.size() * sizeof(dust::DevL2Cell), up));
     }
-    HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4)));
-    HIP_TRY(m->dense_mask.upload(dense_mask.data(), dense_mask.size() * 8));
-    HIP_TRY(m->blocks.upload(blocks, size_t(n_blocks) * sizeof(DustHipBlock)));
-    HIP_TRY(m->materials.upload(materials, size_t(n_materials)));
+    HIP_TRY(m->mid.upload(mid.data(), mid.size() * sizeof(dust::DevN4), up));
+    HIP_TRY(m->dense_mask.upload(dense_mask.data(), dense_mask.size() * 8, up));
+    HIP_TRY(m->blocks.upload(blocks, size_t(n_blocks) * sizeof(DustHipBlock), up));
+    HIP_TRY(m->materials.upload(materials, size_t(n_materials), up));
+    m->has_material_255 = n_materials && std::memchr(materials, 255, size_t(n_materials)) != nullptr;
     uint32_t pal[256];
     std::memset(pal, 0, sizeof(pal));
     std::memcpy(pal, palette, 255 * 4);  // loader.rs:214-218: entries 0..254
-    HIP_TRY(m->palette.upload(pal, sizeof(pal)));
+    HIP_TRY(m->palette.upload(pal, sizeof(pal), up));
     dust::DevModel& d = m->dev;
     d.root = static_cast<const uint8_t*>(m->root.p);
     d.l2 = tree_extent_log2 == 12 ? static_cast<const uint8_t*>(m->l2.p) : nullptr;
@@ -746,16 +806,11 @@ DustStatus dust_hip_model_create(DustHipContext* ctx, const DustHipBlock* blocks
     d.n_blocks = n_blocks;
     d.lds_slot = -1;
     m->n_materials = n_materials;
-    *out = m.release();
+    *out = retain(m);  // the caller's reference (the guard drops the builder's)
     return DUST_OK;
   });
 }
-void dust_hip_model_destroy(DustHipModel* m) {
-  if (!m) return;
-  (void)flush_context(m->ctx, nullptr);
-  (void)hipStreamSynchronize(m->ctx->stream);
-  delete m;
-}
+void dust_hip_model_destroy(DustHipModel* m) { release(m); }  // (a scene that instances it keeps it alive)
 
 // ---------------------------------------------------------------- device-side edits (edit.hip)
 namespace {
@@ -769,13 +824,12 @@ DustStatus ensure_srgb_lut(DustHipContext* ctx) {
     for (uint32_t sum = 0; sum <= n * 255u; ++sum)
       lut[size_t(n - 1) * dust::kSrgbRow + sum] = uint16_t(uint32_t(linear2srgb_host(float(sum) / denom) * 1023.0f));
   }
-  HIP_TRY(ctx->srgb_lut.upload(lut.data(), lut.size() * 2));
+  HIP_TRY(ctx->srgb_lut.upload(lut.data(), lut.size() * 2, ctx->stream));
   return DUST_OK;
 }
 
-dust::EditArgs edit_args(DustHipModel* m) {
+dust::EditArgs edit_args(DustHipModel* m, EditState& st) {
   dust::EditArgs e{};
-  EditState& st = *m->edit;
   e.grid = static_cast<uint8_t*>(st.grid.p);
   e.brick_mask = static_cast<uint64_t*>(st.brick_mask.p);
   e.flag_leaf = static_cast<uint32_t*>(st.flag_leaf.p);
@@ -793,11 +847,11 @@ dust::EditArgs edit_args(DustHipModel* m) {
 }
 
 // run the rebuild kernels and bring the model record up to date (sizes, bounds, the root the scene stages in LDS)
-DustStatus rebuild_and_refresh(DustHipModel* m) {
+DustStatus rebuild_and_refresh(DustHipModel* m, EditState& es) {
   hipStream_t st = m->ctx->stream;
-  HIP_TRY(dust::launch_edit_rebuild(edit_args(m), st));
+  HIP_TRY(dust::launch_edit_rebuild(edit_args(m, es), st));
   dust::EditHeader h{};
-  HIP_TRY(hipMemcpyAsync(&h, m->edit->header.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&h, es.header.p, sizeof(h), hipMemcpyDeviceToHost, st));
   m->host_root.resize(dust::kN16LdsBytes);
   HIP_TRY(hipMemcpyAsync(m->host_root.data(), m->root.p, dust::kN16LdsBytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -809,10 +863,12 @@ DustStatus rebuild_and_refresh(DustHipModel* m) {
   return DUST_OK;
 }
 
-// first edit: move the model into full-capacity buffers and expand its voxels into the dense grid
+// first edit: move the model into full-capacity buffers and expand its voxels into the dense grid. The model becomes
+// editable (m->edit set) only when every step has succeeded: a failure leaves it exactly as it was.
 DustStatus make_editable(DustHipModel* m) {
   if (m->edit) return DUST_OK;
   if (m->dev.extent != 256) return fail(DUST_ERR_UNSUPPORTED, "device-side edits cover hierarchy (4,2,2) models (256^3); rebuild larger trees with dust_hip_model_create");
+  if (m->has_material_255) return fail(DUST_ERR_UNSUPPORTED, "the model holds material byte 255 (the edit grid stores palette index + 1 in a byte; dust_hip_model_set_voxels takes 0..254)");
   DustStatus s = ensure_srgb_lut(m->ctx);
   if (s != DUST_OK) return s;
   hipStream_t st = m->ctx->stream;
@@ -830,19 +886,25 @@ DustStatus make_editable(DustHipModel* m) {
   HIP_TRY(materials.alloc(L * 64));
   HIP_TRY(mid.alloc(4096 * sizeof(dust::DevN4)));
   HIP_TRY(dense_mask.alloc(size_t(4096) * 64 * 8));
-  m->edit = std::move(e);
-  dust::EditArgs a = edit_args(m);
+  dust::EditArgs a = edit_args(m, *e);  // (expand only writes the grid)
   HIP_TRY(dust::launch_edit_expand(a, static_cast<const DustHipBlock*>(m->blocks.p), static_cast<const uint8_t*>(m->materials.p), m->dev.n_blocks, st));
-  HIP_TRY(hipStreamSynchronize(st));  // the old arrays are released below
-  std::swap(m->blocks.p, blocks.p); std::swap(m->blocks.bytes, blocks.bytes);
-  std::swap(m->materials.p, materials.p); std::swap(m->materials.bytes, materials.bytes);
-  std::swap(m->mid.p, mid.p); std::swap(m->mid.bytes, mid.bytes);
-  std::swap(m->dense_mask.p, dense_mask.p); std::swap(m->dense_mask.bytes, dense_mask.bytes);
-  m->dev.mid = static_cast<const dust::DevN4*>(m->mid.p);
-  m->dev.dense_mask = static_cast<const uint64_t*>(m->dense_mask.p);
-  m->dev.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
-  m->dev.materials = static_cast<const uint8_t*>(m->materials.p);
-  return rebuild_and_refresh(m);  // the same voxels, now in the full-capacity arrays
+  HIP_TRY(hipStreamSynchronize(st));  // every launch that reads the old arrays is done (frames of this context run on `st`)
+  auto swap_all = [&] {
+    std::swap(m->blocks.p, blocks.p); std::swap(m->blocks.bytes, blocks.bytes);
+    std::swap(m->materials.p, materials.p); std::swap(m->materials.bytes, materials.bytes);
+    std::swap(m->mid.p, mid.p); std::swap(m->mid.bytes, mid.bytes);
+    std::swap(m->dense_mask.p, dense_mask.p); std::swap(m->dense_mask.bytes, dense_mask.bytes);
+    m->dev.mid = static_cast<const dust::DevN4*>(m->mid.p);
+    m->dev.dense_mask = static_cast<const uint64_t*>(m->dense_mask.p);
+    m->dev.blocks = static_cast<const DustHipBlock*>(m->blocks.p);
+    m->dev.materials = static_cast<const uint8_t*>(m->materials.p);
+  };
+  swap_all();
+  // the same voxels, now in the full-capacity arrays (bumps the generation: scenes holding the old addresses commit again)
+  s = rebuild_and_refresh(m, *e);
+  if (s != DUST_OK) { swap_all(); return s; }  // back to the tightly sized originals, untouched
+  m->edit = std::move(e);
+  return DUST_OK;
 }
 
 DustStatus upload_batch(DustHipModel* m, const uint32_t* xyz, const int32_t* values, uint32_t n, bool with_values) {
@@ -862,7 +924,6 @@ DustStatus upload_batch(DustHipModel* m, const uint32_t* xyz, const int32_t* val
 
 DustStatus dust_hip_model_set_voxels(DustHipModel* m, const uint32_t* xyz, const int32_t* values, uint32_t n) {
   if (!m || (n && (!xyz || !values))) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
-  FLUSH_TRY(flush_context(m->ctx, nullptr));  // a kept-back surfel pass traces the model as it was
   for (uint32_t i = 0; i < n; ++i) {
     if (xyz[i * 3] >= m->dev.extent || xyz[i * 3 + 1] >= m->dev.extent || xyz[i * 3 + 2] >= m->dev.extent)
       return fail(DUST_ERR_INVALID_ARGUMENT, "voxel coordinate outside the tree extent");
@@ -886,12 +947,12 @@ DustStatus dust_hip_model_set_voxels(DustHipModel* m, const uint32_t* xyz, const
     const uint32_t un = uint32_t(uv.size());
     s = upload_batch(m, ux.data(), uv.data(), un, true);
     if (s != DUST_OK) return s;
-    dust::EditArgs a = edit_args(m);
+    dust::EditArgs a = edit_args(m, *m->edit);
     a.xyz = static_cast<const uint32_t*>(m->edit->xyz.p);
     a.values = static_cast<const int32_t*>(m->edit->values.p);
     a.n_edits = un;
     HIP_TRY(dust::launch_edit_apply(a, false, m->ctx->stream));
-    return rebuild_and_refresh(m);  // synchronises: the host vectors above stay alive until the copies are done
+    return rebuild_and_refresh(m, *m->edit);  // synchronises: the host vectors above stay alive until the copies are done
   });
 }
 
@@ -906,7 +967,7 @@ DustStatus dust_hip_model_get_voxels(DustHipModel* m, const uint32_t* xyz, int32
     if (s != DUST_OK || n == 0) return s;
     s = upload_batch(m, xyz, nullptr, n, false);
     if (s != DUST_OK) return s;
-    dust::EditArgs a = edit_args(m);
+    dust::EditArgs a = edit_args(m, *m->edit);
     a.xyz = static_cast<const uint32_t*>(m->edit->xyz.p);
     a.values_out = static_cast<int32_t*>(m->edit->values.p);
     a.n_edits = n;
@@ -929,26 +990,23 @@ DustStatus dust_hip_model_read(const DustHipModel* m, DustHipBlock* blocks, uint
   if ((blocks && block_capacity < m->dev.n_blocks) || (materials && material_capacity < m->n_materials))
     return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small (see dust_hip_model_info)");
   HIP_TRY(hipSetDevice(m->ctx->device));
-  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
-  if (blocks && m->dev.n_blocks) HIP_TRY(hipMemcpy(blocks, m->blocks.p, size_t(m->dev.n_blocks) * sizeof(DustHipBlock), hipMemcpyDeviceToHost));
-  if (materials && m->n_materials) HIP_TRY(hipMemcpy(materials, m->materials.p, size_t(m->n_materials), hipMemcpyDeviceToHost));
+  const hipStream_t st = m->ctx->stream;
+  if (blocks && m->dev.n_blocks) HIP_TRY(hipMemcpyAsync(blocks, m->blocks.p, size_t(m->dev.n_blocks) * sizeof(DustHipBlock), hipMemcpyDeviceToHost, st));
+  if (materials && m->n_materials) HIP_TRY(hipMemcpyAsync(materials, m->materials.p, size_t(m->n_materials), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return DUST_OK;
 }
 
 DustStatus dust_hip_scene_create(DustHipContext* ctx, DustHipScene** out) {
   if (!ctx || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&] {
-    *out = new DustHipScene;
-    (*out)->ctx = ctx;
+    DustHipScene* s = new DustHipScene;
+    s->ctx = retain(ctx);
+    *out = s;
     return DUST_OK;
   });
 }
-void dust_hip_scene_destroy(DustHipScene* s) {
-  if (!s) return;
-  (void)flush_context(s->ctx, s);
-  (void)hipStreamSynchronize(s->ctx->stream);
-  delete s;
-}
+void dust_hip_scene_destroy(DustHipScene* s) { release(s); }
 
 static DustStatus check_affine(const float m[12]) {
   for (int i = 0; i < 12; ++i)
@@ -976,8 +1034,13 @@ DustStatus dust_hip_scene_add_instance(DustHipScene* s, const DustHipModel* mode
       for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 4; ++r) hi.prev[c * 4 + r] = r < 3 ? o2w[r * 4 + c] : (c == 3 ? 1.0f : 0.0f);
     }
+    s->instances.reserve(s->instances.size() + 1);
+    s->dirty.reserve(s->dirty.size() + 1);
     if (instance_id) *instance_id = uint32_t(s->instances.size());
     s->instances.push_back(hi);
+    s->dirty.push_back(1);
+    retain(const_cast<DustHipModel*>(model));  // the scene keeps what it instances alive
+    s->structure_dirty = true;
     s->committed = false;
     return DUST_OK;
   });
@@ -989,101 +1052,150 @@ DustStatus dust_hip_scene_set_transform(DustHipScene* s, uint32_t id, const floa
   HostInstance& hi = s->instances[id];
   std::memcpy(hi.o2w, o2w, sizeof(hi.o2w));
   if (prev) std::memcpy(hi.prev, prev, sizeof(hi.prev));
+  s->dirty[id] = 1;
   s->committed = false;
   return DUST_OK;
 }
 
+namespace {
+// the device records of instance i, re-derived in the host master image (instance, box, visit)
+void derive_instance(DustHipScene* s, size_t i) {
+  const HostInstance& hi = s->instances[i];
+  uint8_t* img = s->master.data();
+  dust::DevInstance& d = reinterpret_cast<dust::DevInstance*>(img + s->layout.instances)[i];
+  std::memcpy(d.o2w, hi.o2w, sizeof(d.o2w));
+  std::memcpy(d.prev, hi.prev, sizeof(d.prev));
+  invert_affine(hi.o2w, d.w2o);
+  d.model = s->instance_slot[i];
+  d.pad = 0;
+  const dust::DevModel& m = hi.model->dev;
+  for (int a = 0; a < 3; ++a) { d.wmin[a] = 1e30f; d.wmax[a] = -1e30f; }
+  for (int c = 0; c < 8; ++c) {
+    const double p[3] = {(c & 1) ? m.bmax[0] : m.bmin[0], (c & 2) ? m.bmax[1] : m.bmin[1], (c & 4) ? m.bmax[2] : m.bmin[2]};
+    for (int a = 0; a < 3; ++a) {
+      const float* r = hi.o2w + a * 4;
+      const double w = double(r[0]) * p[0] + double(r[1]) * p[1] + double(r[2]) * p[2] + double(r[3]);
+      const double pad = 1e-4 * (std::fabs(w) + 1.0);
+      d.wmin[a] = std::min(d.wmin[a], float(w - pad));
+      d.wmax[a] = std::max(d.wmax[a], float(w + pad));
+    }
+  }
+  // the world box again, packed 32 bytes apiece: what the packet culling streams through (coalesced) and the candidate
+  // loop reads with one scalar load; and the flattened visit record (box, world -> object, model)
+  dust::DevBox& bx = reinterpret_cast<dust::DevBox*>(img + s->layout.boxes)[i];
+  dust::DevVisit& v = reinterpret_cast<dust::DevVisit*>(img + s->layout.visits)[i];
+  for (int a = 0; a < 3; ++a) { bx.lo[a] = v.lo[a] = d.wmin[a]; bx.hi[a] = v.hi[a] = d.wmax[a]; }
+  bx.pad0 = bx.pad1 = v.pad0 = v.pad1 = 0.0f;
+  std::memcpy(v.w2o, d.w2o, sizeof(v.w2o));
+  v.m = reinterpret_cast<const dust::DevModel*>(img + s->layout.models)[d.model];
+}
+}  // namespace
+
 DustStatus dust_hip_scene_commit(DustHipScene* s) {
   if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
-  FLUSH_TRY(flush_context(s->ctx, s));  // a kept-back surfel pass traces the scene as it was committed
-  HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // (the instance buffers are reallocated below)
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(s->ctx->device));
-    ++s->revision;
-    s->models.clear();
-    std::vector<dust::DevInstance> di(s->instances.size());
-    for (size_t i = 0; i < s->instances.size(); ++i) {
-      const HostInstance& hi = s->instances[i];
-      auto it = std::find(s->models.begin(), s->models.end(), hi.model);
-      uint32_t slot = uint32_t(it - s->models.begin());
-      if (it == s->models.end()) s->models.push_back(hi.model);
-      dust::DevInstance& d = di[i];
-      std::memcpy(d.o2w, hi.o2w, sizeof(d.o2w));
-      std::memcpy(d.prev, hi.prev, sizeof(d.prev));
-      invert_affine(hi.o2w, d.w2o);
-      d.model = slot;
-      d.pad = 0;
-      const dust::DevModel& m = hi.model->dev;
-      for (int a = 0; a < 3; ++a) { d.wmin[a] = 1e30f; d.wmax[a] = -1e30f; }
-      for (int c = 0; c < 8; ++c) {
-        const double p[3] = {(c & 1) ? m.bmax[0] : m.bmin[0], (c & 2) ? m.bmax[1] : m.bmin[1], (c & 4) ? m.bmax[2] : m.bmin[2]};
-        for (int a = 0; a < 3; ++a) {
-          const float* r = hi.o2w + a * 4;
-          const double w = double(r[0]) * p[0] + double(r[1]) * p[1] + double(r[2]) * p[2] + double(r[3]);
-          const double pad = 1e-4 * (std::fabs(w) + 1.0);
-          d.wmin[a] = std::min(d.wmin[a], float(w - pad));
-          d.wmax[a] = std::max(d.wmax[a], float(w + pad));
-        }
+    const hipStream_t st = s->ctx->stream;
+    const size_t n = s->instances.size();
+    // a model edited since the last commit changes its record (bounds, sizes, maybe addresses): everything is derived again
+    for (size_t i = 0; i < s->models.size() && !s->structure_dirty; ++i)
+      if (s->models[i]->generation != s->model_generation[i]) s->structure_dirty = true;
+    const bool full = s->structure_dirty;
+    if (full) {
+      s->models.clear();
+      s->instance_slot.resize(n);
+      for (size_t i = 0; i < n; ++i) {
+        const DustHipModel* m = s->instances[i].model;
+        auto it = std::find(s->models.begin(), s->models.end(), m);
+        s->instance_slot[i] = uint32_t(it - s->models.begin());
+        if (it == s->models.end()) s->models.push_back(m);
       }
+      // roots of the first models go to LDS, as many as the budget holds
+      s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
+      s->layout = SceneLayout::make(n, s->models.size(), s->n_lds_models);
+      if (s->layout.total > s->image_capacity || !s->image.p) {
+        // grow (rare: instances were added). Launches that read the old image are done before it goes.
+        HIP_TRY(hipStreamSynchronize(st));
+        s->free_staging();
+        s->image_capacity = s->layout.total + s->layout.total / 2 + 4096;
+        HIP_TRY(s->image.alloc(s->image_capacity));
+        for (DustHipScene::Staging& sg : s->staging) {
+          HIP_TRY(hipHostMalloc(&sg.host, s->image_capacity, hipHostMallocDefault));
+          HIP_TRY(hipEventCreateWithFlags(&sg.copied, hipEventDisableTiming));
+        }
+        s->staging_bytes = s->image_capacity;
+      }
+      s->master.assign(s->layout.total, 0);
+      uint8_t* img = s->master.data();
+      dust::DevModel* dm = reinterpret_cast<dust::DevModel*>(img + s->layout.models);
+      for (size_t i = 0; i < s->models.size(); ++i) {
+        dm[i] = s->models[i]->dev;
+        dm[i].lds_slot = i < s->n_lds_models ? int32_t(i) : -1;
+      }
+      for (uint32_t i = 0; i < s->n_lds_models; ++i)
+        std::memcpy(img + s->layout.root_table + size_t(i) * dust::kN16LdsBytes, s->models[i]->host_root.data(), dust::kN16LdsBytes);
+      s->model_generation.clear();
+      for (const DustHipModel* m : s->models) s->model_generation.push_back(m->generation);
     }
+    uint8_t* img = s->master.data();
+    for (size_t i = 0; i < n; ++i)
+      if (full || s->dirty[i]) { derive_instance(s, i); s->dirty[i] = 0; }
+    // (the record behind the last instance stays zero: the cull reads boxes 64 at a time)
+    const dust::DevInstance* di = reinterpret_cast<const dust::DevInstance*>(img + s->layout.instances);
     for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
-    for (const dust::DevInstance& d : di)
-      for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], d.wmin[a]); s->world_max[a] = std::max(s->world_max[a], d.wmax[a]); }
-    // roots of the first models go to LDS, as many as the budget holds
-    s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
-    std::vector<dust::DevModel> dm(s->models.size());
-    for (size_t i = 0; i < s->models.size(); ++i) {
-      dm[i] = s->models[i]->dev;
-      dm[i].lds_slot = i < s->n_lds_models ? int32_t(i) : -1;
-    }
-    s->root_table.clear();
-    for (uint32_t i = 0; i < s->n_lds_models; ++i)
-      s->root_table.insert(s->root_table.end(), s->models[i]->host_root.begin(), s->models[i]->host_root.end());
-    HIP_TRY(s->d_root_table.upload(s->root_table.data(), s->root_table.size()));
-    HIP_TRY(s->d_models.upload(dm.data(), dm.size() * sizeof(dust::DevModel)));
-    HIP_TRY(s->d_instances.upload(di.data(), di.size() * sizeof(dust::DevInstance)));
-    // the world boxes again, packed 32 bytes apiece: what the packet culling streams through (coalesced) and the
-    // candidate loop reads with one scalar load
-    std::vector<dust::DevBox> boxes(di.size() + 1);
-    for (size_t i = 0; i < di.size(); ++i) {
-      for (int a = 0; a < 3; ++a) { boxes[i].lo[a] = di[i].wmin[a]; boxes[i].hi[a] = di[i].wmax[a]; }
-      boxes[i].pad0 = boxes[i].pad1 = 0.0f;
-    }
-    HIP_TRY(s->d_boxes.upload(boxes.data(), boxes.size() * sizeof(dust::DevBox)));
-    std::vector<dust::DevVisit> visits(di.size() + 1);
-    for (size_t i = 0; i < di.size(); ++i) {
-      for (int a = 0; a < 3; ++a) { visits[i].lo[a] = di[i].wmin[a]; visits[i].hi[a] = di[i].wmax[a]; }
-      visits[i].pad0 = visits[i].pad1 = 0.0f;
-      std::memcpy(visits[i].w2o, di[i].w2o, sizeof(visits[i].w2o));
-      visits[i].m = dm[di[i].model];
-    }
-    HIP_TRY(s->d_visits.upload(visits.data(), visits.size() * sizeof(dust::DevVisit)));
-    s->model_generation.clear();
-    for (const DustHipModel* m : s->models) s->model_generation.push_back(m->generation);
+    for (size_t i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], di[i].wmin[a]); s->world_max[a] = std::max(s->world_max[a], di[i].wmax[a]); }
+    // one asynchronous copy of the image, from the next pinned slot, behind whatever frame is in flight on the stream
+    DustHipScene::Staging& sg = s->staging[s->staging_next++ % DustHipScene::kStaging];
+    if (sg.in_flight) { HIP_TRY(hipEventSynchronize(sg.copied)); sg.in_flight = false; }  // (three commits ago: long done)
+    const size_t from = full ? 0 : s->layout.instances;  // transforms only: the models and roots already there stand
+    std::memcpy(static_cast<uint8_t*>(sg.host) + from, img + from, s->layout.total - from);
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->image.p) + from, static_cast<uint8_t*>(sg.host) + from, s->layout.total - from, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(sg.copied, st));
+    sg.in_flight = true;
+    ++s->revision;
+    s->structure_dirty = false;
     s->committed = true;
     return DUST_OK;
   });
 }
 
+static void destroy_pipeline(DustHipPipeline* p) {
+  if (!p) return;
+  DustHipContext* c = p->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kind : p->ev_ring)
+    for (auto& side : kind)
+      for (auto& e : side) if (e) (void)hipEventDestroy(e);
+  if (p->host_stats) (void)hipHostFree(p->host_stats);
+  delete p;
+  release(c);
+}
 DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_t height, DustHipPipeline** out) {
   if (!ctx || !out || width == 0 || height == 0 || width > 16384 || height > 16384)
     return fail(DUST_ERR_INVALID_ARGUMENT, "bad pipeline size");
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(ctx->device));
-    std::unique_ptr<DustHipPipeline> p(new DustHipPipeline);
-    p->ctx = ctx;
+    struct Drop { DustHipPipeline* p; ~Drop() { destroy_pipeline(p); } } owner{new DustHipPipeline};
+    DustHipPipeline* p = owner.p;
+    p->ctx = retain(ctx);
     p->tune = Tuning::from_environment();
     p->width = width; p->height = height;
+    const hipStream_t st = ctx->stream;  // (every fill below is ordered on the stream the frames run on)
     const size_t px = size_t(width) * height;
     for (int i = 0; i < DUST_PLANE_COUNT; ++i) {
       HIP_TRY(p->planes[i].alloc(px * kPlaneBytesPerPixel[i]));
-      HIP_TRY(hipMemset(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i]));
+      HIP_TRY(hipMemsetAsync(p->planes[i].p, 0, px * kPlaneBytesPerPixel[i], st));
     }
     HIP_TRY(p->counters.alloc(8 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(p->counters.p, 0, 8 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(p->counters.p, 0, 8 * dust::kRegions * dust::kCounterStride * sizeof(uint32_t), st));
     HIP_TRY(p->stats.alloc(8 * sizeof(dust::DevStats)));
+    HIP_TRY(hipMemsetAsync(p->stats.p, 0, 8 * sizeof(dust::DevStats), st));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->host_stats), 8 * sizeof(dust::DevStats), hipHostMallocDefault));
+    std::memset(p->host_stats, 0, 8 * sizeof(dust::DevStats));
     HIP_TRY(p->exposure.alloc(257 * 4));
-    HIP_TRY(hipMemset(p->exposure.p, 0, 257 * 4));  // auto_exposure.rs:117: fill_buffer(0)
+    HIP_TRY(hipMemsetAsync(p->exposure.p, 0, 257 * 4, st));  // auto_exposure.rs:117: fill_buffer(0)
     // timing only (nothing waits on them for visibility): without the system-scope fence a record does not flush L2 between passes
     if (ctx->timing)
       for (auto& kind : p->ev_ring)
@@ -1091,35 +1203,21 @@ DustStatus dust_hip_pipeline_create(DustHipContext* ctx, uint32_t width, uint32_
           side.assign(DustHipPipeline::kEvRing, nullptr);
           for (auto& e : side) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
         }
-    ctx->pipelines.push_back(p.get());
-    *out = p.release();
+    HIP_TRY(hipStreamSynchronize(st));
+    owner.p = nullptr;
+    *out = p;
     return DUST_OK;
   });
 }
-void dust_hip_pipeline_destroy(DustHipPipeline* p) {
-  if (!p) return;
-  p->pending.valid = false;  // nobody can look at its results any more
-  (void)hipStreamSynchronize(p->ctx->stream);
-  if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
-  if (p->ev_frame_end) (void)hipEventDestroy(p->ev_frame_end);
-  if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
-  for (auto& pr : p->probes) for (hipEvent_t e : {pr.a0, pr.a1, pr.b0, pr.b1}) if (e) (void)hipEventDestroy(e);
-  auto& reg = p->ctx->pipelines;
-  reg.erase(std::remove(reg.begin(), reg.end(), p), reg.end());
-  for (auto& kind : p->ev_ring)
-    for (auto& side : kind)
-      for (auto& e : side) if (e) (void)hipEventDestroy(e);
-  delete p;
-}
+void dust_hip_pipeline_destroy(DustHipPipeline* p) { destroy_pipeline(p); }
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, const uint8_t* texels, uint32_t layers) {
   if (!p || !texels || layers == 0 || (texture != 0 && texture != 5))
     return fail(DUST_ERR_INVALID_ARGUMENT, "noise texture must be 0 (scalar R8) or 5 (unitvec3_cosine RGBA8)");
-  FLUSH_TRY(flush_surfel_pass(p));
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));  // (frames that read the old texture are done before it is replaced)
   const size_t bytes = size_t(128) * 128 * layers * (texture == 0 ? 1 : 4);
-  if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes)); p->noise0_layers = layers; }
-  else { HIP_TRY(p->noise5.upload(texels, bytes)); p->noise5_layers = layers; }
+  if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes, p->ctx->stream)); p->noise0_layers = layers; }
+  else { HIP_TRY(p->noise5.upload(texels, bytes, p->ctx->stream)); p->noise5_layers = layers; }
   return DUST_OK;
 }
 
@@ -1217,28 +1315,6 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   return DUST_OK;
 }
-// launches a kept-back surfel pass now, on the main stream (nothing to overlap it with)
-static DustStatus flush_surfel_pass(DustHipPipeline* p) {
-  if (!p->pending.valid) return DUST_OK;
-  p->pending.valid = false;
-  HIP_TRY(hipSetDevice(p->ctx->device));
-  const uint64_t key = p->view_key;
-  p->view_key = p->pending.view_key;
-  uint32_t resident = uint32_t(p->ctx->num_cus) * p->pending_bpc;
-  if (p->tune.reserve_blocks && p->tune.reserve_blocks + 8u <= resident) resident -= p->tune.reserve_blocks;
-  const DustStatus rs = run_surfel_pass(p, p->pending.args, p->pending.passes, false, p->ctx->stream, resident);
-  p->view_key = key;
-  return rs;
-}
-static DustStatus flush_context(DustHipContext* c, const DustHipScene* scene /* null: every pipeline */) {
-  for (DustHipPipeline* p : c->pipelines)
-    if (p->pending.valid && (!scene || p->pending.scene == scene)) {
-      const DustStatus rs = flush_surfel_pass(p);
-      if (rs != DUST_OK) return rs;
-    }
-  return DUST_OK;
-}
-
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
                                  const DustHipSky* sky, const DustHipFrameParams* fp) {
   if (!p || !s || !cam || !sky || !fp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
@@ -1272,14 +1348,14 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   DustHipContext* ctx = p->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
   dust::FrameArgs a{};
-  a.models = static_cast<const dust::DevModel*>(s->d_models.p);
-  a.instances = static_cast<const dust::DevInstance*>(s->d_instances.p);
+  a.models = reinterpret_cast<const dust::DevModel*>(s->dev(s->layout.models));
+  a.instances = reinterpret_cast<const dust::DevInstance*>(s->dev(s->layout.instances));
   a.n_models = uint32_t(s->models.size());
   a.n_instances = uint32_t(s->instances.size());
   a.n_lds_models = s->n_lds_models;
-  a.root_table = static_cast<const uint8_t*>(s->d_root_table.p);
-  a.boxes = static_cast<const dust::DevBox*>(s->d_boxes.p);
-  a.visits = static_cast<const dust::DevVisit*>(s->d_visits.p);
+  a.root_table = s->dev(s->layout.root_table);
+  a.boxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.boxes));
+  a.visits = reinterpret_cast<const dust::DevVisit*>(s->dev(s->layout.visits));
   for (int k = 0; k < 3; ++k) { a.world_min[k] = s->world_min[k]; a.world_max[k] = s->world_max[k]; }
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
@@ -1330,96 +1406,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
-  // A kept-back surfel pass (the previous frame's): launch it beside this frame's primary / AO kernels, or before anything else
-  uint32_t main_resident = resident;
-  bool overlapped = false, calibrating = false;
-  if (p->pending.valid) {
-    const bool beside = !tune.no_overlap && !count && !sharded && (fp->passes & DUST_PASS_PRIMARY) && p->pending.scene == s &&
-                        p->pending.scene_revision == s->revision && p->ev_frame_end != nullptr;
-    if (beside && !tune.overlap_share && p->calibration == 0) {
-      // Calibration, once: this kept-back pass runs in place and this frame's primary side alone, both timed; the next frame
-      // reads the two durations Q and P (one wait) and starts from the share 100 Q / (Q + 1.05 P) - 3, which is where the
-      // measured optima of three workloads lie (castle 1080p 55 %, 4K 20 %, the 4096^3 tree 25 %). Feedback takes over from there.
-      DustHipPipeline::Probe& pr = p->probes[0];
-      if (!pr.a0) for (hipEvent_t* e : {&pr.a0, &pr.a1, &pr.b0, &pr.b1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
-      HIP_TRY(hipEventRecord(pr.b0, st));
-      const DustStatus rs = flush_surfel_pass(p);
-      if (rs != DUST_OK) return rs;
-      HIP_TRY(hipEventRecord(pr.b1, st));
-      HIP_TRY(hipEventRecord(pr.a0, st));
-      calibrating = true;
-      p->calibration = 1;
-    } else if (beside) {
-      if (!tune.overlap_share && p->calibration == 1) {
-        DustHipPipeline::Probe& pr = p->probes[0];
-        float P = 0.0f, Q = 0.0f;
-        HIP_TRY(hipEventSynchronize(pr.a1));
-        HIP_TRY(hipEventElapsedTime(&Q, pr.b0, pr.b1));
-        HIP_TRY(hipEventElapsedTime(&P, pr.a0, pr.a1));
-        if (P > 0.0f && Q > 0.0f) p->side_share = std::min(65.0f, std::max(10.0f, 100.0f * Q / (Q + 1.05f * P) - 3.0f));
-        p->calibration = 2;
-      }
-      if (!p->side) HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-      if (!p->ev_side_done) HIP_TRY(hipEventCreateWithFlags(&p->ev_side_done, hipEventDisableTiming));
-      // The share of the workgroup slots each side gets: from the calibration above (or, with a fixed DUST_HIP_OVERLAP_SHARE
-      // that skipped it, a guess from the ray counts), then feedback: both sides are timed, and the share moves until the pass
-      // ends about 6 % after the main side reaches the join.
-      if (p->side_share == 0.0f) {
-        const double surfel = double(p->gi_pool_size) * 18.0, pixel = 3.0 * double(p->width) * double(a.row_end - a.row_begin);
-        p->side_share = float(std::min(60.0, std::max(15.0, 100.0 * surfel / (surfel + pixel))));
-      }
-      {
-        float target = 0.0f;
-        uint32_t newest = 0;
-        for (auto& pr : p->probes) {
-          if (!pr.in_flight || hipEventQuery(pr.a1) != hipSuccess || hipEventQuery(pr.b1) != hipSuccess) continue;
-          float ta = 0.0f, tb = 0.0f;
-          if (hipEventElapsedTime(&ta, pr.a0, pr.a1) == hipSuccess && hipEventElapsedTime(&tb, pr.b0, pr.b1) == hipSuccess && ta > 0.0f && tb > 0.0f &&
-              pr.seq >= newest) {
-            // Measured optimum on three workloads (castle 1080p, castle 4K, the 4096^3 tree: shares 55, 20, 25 %): the pass
-            // ends 3 - 13 % after the main side reaches the join. The measurement is some frames old: the correction applies
-            // to the share IT ran under (proportional, at most six points), and the current share moves halfway there.
-            const float err = tb / ta - 1.06f;
-            newest = pr.seq;
-            target = (err > 0.05f || err < -0.05f) ? pr.share + std::min(6.0f, std::max(-6.0f, 20.0f * err)) : pr.share;
-          }
-          pr.in_flight = false;
-        }
-        if (target > 0.0f) p->side_share = std::min(70.0f, std::max(10.0f, 0.5f * (p->side_share + target)));
-      }
-      (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
-      const uint32_t share = tune.overlap_share ? tune.overlap_share : uint32_t(p->side_share + 0.5f);
-      const uint32_t side_resident = std::max(8u, (resident * share / 100u) & ~7u);
-      main_resident = std::max(8u, resident - std::min(resident - 8u, side_resident));
-      p->probe_live = -1;
-      {
-        DustHipPipeline::Probe& pr = p->probes[p->probe_next % 8u];
-        if (!pr.in_flight) {
-          if (!pr.a0) for (hipEvent_t* e : {&pr.a0, &pr.a1, &pr.b0, &pr.b1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
-          p->probe_live = int(p->probe_next % 8u);
-          pr.share = float(share);
-          pr.seq = ++p->probe_next;
-        }
-      }
-      HIP_TRY(hipStreamWaitEvent(p->side, p->ev_frame_end, 0));  // the frame that recorded the pass is complete (final gather, commit)
-      if (p->probe_live >= 0) { HIP_TRY(hipEventRecord(p->probes[p->probe_live].b0, p->side)); HIP_TRY(hipEventRecord(p->probes[p->probe_live].a0, st)); }
-      p->pending.valid = false;
-      const uint64_t key = p->view_key;
-      // (p->view_key is set below for THIS frame; the pass orders its work items under the key of the frame it belongs to)
-      p->view_key = p->pending.view_key;
-      p->pending.args.prio_floor = 3u;  // the longer side of the two: its waves win the issue arbitration on the SIMDs they share (GI frame -2 %)
-      const DustStatus rs = run_surfel_pass(p, p->pending.args, p->pending.passes, false, p->side, side_resident);
-      p->view_key = key;
-      if (rs != DUST_OK) return rs;
-      if (p->probe_live >= 0) HIP_TRY(hipEventRecord(p->probes[p->probe_live].b1, p->side));
-      HIP_TRY(hipEventRecord(p->ev_side_done, p->side));
-      overlapped = true;
-    } else {
-      const DustStatus rs = flush_surfel_pass(p);
-      if (rs != DUST_OK) return rs;
-    }
-  }
-  const uint32_t grid = std::max(8u, std::min<uint32_t>(main_resident, (total_tiles + 7) / 8));
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
     auto mix = [&k](const void* data, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(data); for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
@@ -1464,20 +1451,6 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
-  // the hash and the pool are the kept-back pass's until the main stream has waited for it (the final gather's regrouping
-  // pre-pass reads neither and still runs beside it)
-  auto join_side = [&]() -> hipError_t {
-    if (calibrating) { calibrating = false; return hipEventRecord(p->probes[0].a1, st); }
-    if (!overlapped) return hipSuccess;
-    overlapped = false;
-    if (p->probe_live >= 0) {
-      const hipError_t e = hipEventRecord(p->probes[p->probe_live].a1, st);
-      if (e != hipSuccess) return e;
-      p->probes[p->probe_live].in_flight = true;
-      p->probe_live = -1;
-    }
-    return hipStreamWaitEvent(st, p->ev_side_done, 0);
-  };
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
     if (sharded) {  // pixels that stamp nothing must read 0 after the all-gather
       a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
@@ -1493,42 +1466,19 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
-      HIP_TRY(join_side());
       g.tiles_x = otx * oty * 64;  // 64 packets of 64 per tile, the empty ones skipped by the kernel
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
-    HIP_TRY(join_side());
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
-  HIP_TRY(join_side());
   if (fp->passes & DUST_PASS_SURFEL) {
-    // The surfel pass of frame N only has to be done before frame N + 1's final gather reads the hash. Its trace is as long as
-    // its longest ray -- the pool is 2.6 work items per resident wave and the most expensive item takes twice the mean wave's
-    // load (tools/tile_costs.py) -- and its sort and apply are a handful of latency-bound launches: half the GPU idles through
-    // it. So it is kept back and launched WITH the next frame's primary / AO kernels, on a second stream, each side on its
-    // share of the workgroup slots (run_surfel_pass, flush_surfel_pass). Same kernels on the same data in the same order of
-    // dependencies: the results cannot differ. Anything that looks at the GI state, or changes what the saved launch
-    // descriptor points to, flushes it first.
-    const bool defer = !tune.no_overlap && !count && !sharded && !(tune.debug & 16u);
-    if (defer) {
-      p->pending.valid = true;
-      p->pending.args = a;
-      p->pending.passes = fp->passes;
-      p->pending.view_key = p->view_key;
-      p->pending.scene = s;
-      p->pending.scene_revision = s->revision;
-      p->pending_bpc = bpc;
-      if (!p->ev_frame_end) HIP_TRY(hipEventCreateWithFlags(&p->ev_frame_end, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(p->ev_frame_end, st));
-    } else {
-      DustStatus rs = run_surfel_pass(p, a, fp->passes, count, st, resident);
-      if (rs != DUST_OK) return rs;
-    }
+    DustStatus rs = run_surfel_pass(p, a, fp->passes, count, st, resident);
+    if (rs != DUST_OK) return rs;
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
     p->have_history = false;  // the plane now holds an N-frame mean, not the denoiser's history
@@ -1584,9 +1534,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustHipPassStats* out) {
   if (!p || !out || pass > 5) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
   std::memset(out, 0, sizeof(*out));
-  FLUSH_TRY(flush_surfel_pass(p));
+  HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   // pass 0: primary kernel; 1, 2: the two ray classes of the AO kernel (share its time); 3: final gather (+ surfel
   // commit); 4, 5: the two ray classes of the surfel pass (trace + apply kernels)
   const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : (pass == 3 ? 2 : 3));
@@ -1607,7 +1556,6 @@ DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline* p, int mark, float ms
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));  // (a kept-back surfel pass stays kept back: it is not a launch yet)
   for (int k = 0; k < 4; ++k) {
     double sum = 0.0;
     uint32_t n = 0;
@@ -1646,22 +1594,20 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, 
   if (dst_bytes < p->planes[plane].bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  HIP_TRY(hipMemcpy(dst, p->plane(plane), p->planes[plane].bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(copy_wait(dst, p->plane(plane), p->planes[plane].bytes, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size) {
   if (!p || hash_capacity < 4 || surfel_pool_size == 0) return fail(DUST_ERR_INVALID_ARGUMENT, "bad GI configuration");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  FLUSH_TRY(flush_surfel_pass(p));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   const size_t hash_bytes = (size_t(hash_capacity) + 2) * 12;  // probes run up to 2 past the end (spatial_hash.glsl:154-158)
   HIP_TRY(p->gi_hash.alloc(hash_bytes));
-  HIP_TRY(hipMemset(p->gi_hash.p, 0, hash_bytes));             // standard.rs:348-358 relies on a zeroed allocation
+  HIP_TRY(hipMemsetAsync(p->gi_hash.p, 0, hash_bytes, p->ctx->stream));             // standard.rs:348-358 relies on a zeroed allocation
   HIP_TRY(p->gi_pool.alloc(size_t(surfel_pool_size) * 16));
-  HIP_TRY(hipMemset(p->gi_pool.p, 0xFF, size_t(surfel_pool_size) * 16));  // fill_buffer(u32::MAX), standard.rs:345-347
+  HIP_TRY(hipMemsetAsync(p->gi_pool.p, 0xFF, size_t(surfel_pool_size) * 16, p->ctx->stream));  // fill_buffer(u32::MAX), standard.rs:345-347
   HIP_TRY(p->gi_owner.alloc(size_t(surfel_pool_size) * 4));
-  HIP_TRY(hipMemset(p->gi_owner.p, 0, size_t(surfel_pool_size) * 4));
+  HIP_TRY(hipMemsetAsync(p->gi_owner.p, 0, size_t(surfel_pool_size) * 4, p->ctx->stream));
   HIP_TRY(p->gi_pixel_surfel.alloc(size_t(p->width) * p->height * 16));
   {
     const size_t tiles = size_t((p->width + 63) / 64) * ((p->height + 63) / 64 + 1);
@@ -1684,7 +1630,6 @@ DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_row
   if (!p || !out || padded_rows < p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "padded_rows must cover the frame");
   STRUCT_TRY(out, "DustHipGiExchange");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  FLUSH_TRY(flush_surfel_pass(p));
   if (!p->gi_hash.p) {
     DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
     if (gs != DUST_OK) return gs;
@@ -1692,9 +1637,9 @@ DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_row
   if (!p->gi_touched.p || p->gi_touched_rows != padded_rows) {
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     HIP_TRY(p->gi_touched.alloc(size_t(padded_rows) * p->width * 4));
-    HIP_TRY(hipMemset(p->gi_touched.p, 0, size_t(padded_rows) * p->width * 4));
+    HIP_TRY(hipMemsetAsync(p->gi_touched.p, 0, size_t(padded_rows) * p->width * 4, p->ctx->stream));
     HIP_TRY(p->gi_merged.alloc(size_t(p->gi_pool_size) * 16));
-    HIP_TRY(hipMemset(p->gi_merged.p, 0, size_t(p->gi_pool_size) * 16));
+    HIP_TRY(hipMemsetAsync(p->gi_merged.p, 0, size_t(p->gi_pool_size) * 16, p->ctx->stream));
     p->gi_touched_rows = padded_rows;
   }
   out->pool_size = p->gi_pool_size;
@@ -1711,7 +1656,6 @@ static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uin
   // stamps and commits the winners
   if (row_begin > row_end || (row_begin == row_end && !import) || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  FLUSH_TRY(flush_surfel_pass(p));
   dust::FrameArgs a{};
   a.width = p->width; a.height = p->height;
   a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
@@ -1736,12 +1680,19 @@ DustStatus dust_hip_gi_import(DustHipPipeline* p, uint32_t row_begin, uint32_t r
 }
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* dst, size_t dst_bytes) {
   if (!p || !dst || which > 1 || !p->gi_hash.p) return fail(DUST_ERR_INVALID_ARGUMENT, "GI state not configured");
-  FLUSH_TRY(flush_surfel_pass(p));
   const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
   if (dst_bytes < b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  HIP_TRY(hipMemcpy(dst, b.p, b.bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(copy_wait(dst, b.p, b.bytes, hipMemcpyDeviceToHost, p->ctx->stream));
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_write_gi(DustHipPipeline* p, uint32_t which, const void* src, size_t src_bytes) {
+  if (!p || !src || which > 1 || !p->gi_hash.p) return fail(DUST_ERR_INVALID_ARGUMENT, "GI state not configured");
+  const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
+  if (src_bytes != b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "saved GI state does not match the configured capacity / pool size");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(copy_wait(b.p, src, b.bytes, hipMemcpyHostToDevice, p->ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_tone_map(DustHipPipeline* p, const DustHipToneMapParams* tp) {
@@ -1764,8 +1715,8 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   float* avg = reinterpret_cast<float*>(static_cast<uint32_t*>(p->exposure.p) + 256);
-  if (set_to) HIP_TRY(hipMemcpy(avg, set_to, 4, hipMemcpyHostToDevice));
-  if (avg_luminance) HIP_TRY(hipMemcpy(avg_luminance, avg, 4, hipMemcpyDeviceToHost));
+  if (set_to) HIP_TRY(copy_wait(avg, set_to, 4, hipMemcpyHostToDevice, p->ctx->stream));
+  if (avg_luminance) HIP_TRY(copy_wait(avg_luminance, avg, 4, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
@@ -1779,40 +1730,39 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
     std::vector<uint32_t> k(n), v(n);
     for (uint32_t i = 0; i < n; ++i) { k[i] = in[size_t(i) * 2]; v[i] = in[size_t(i) * 2 + 1]; }
     DeviceBuffer ka, va, kb, vb, scratch;
-    HIP_TRY(ka.upload(k.data(), size_t(n) * 4)); HIP_TRY(va.upload(v.data(), size_t(n) * 4));
+    HIP_TRY(ka.upload(k.data(), size_t(n) * 4, ctx->stream)); HIP_TRY(va.upload(v.data(), size_t(n) * 4, ctx->stream));
     HIP_TRY(kb.alloc(size_t(n) * 4)); HIP_TRY(vb.alloc(size_t(n) * 4));
     HIP_TRY(scratch.alloc(dust::radix_sort_scratch_bytes(n)));
     bool in_b = false;
     HIP_TRY(dust::radix_sort_pairs(scratch.p, static_cast<uint32_t*>(ka.p), static_cast<uint32_t*>(va.p), static_cast<uint32_t*>(kb.p),
                                    static_cast<uint32_t*>(vb.p), n, in_words == 2 ? 32u : 32u, &in_b, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(k.data(), in_b ? kb.p : ka.p, size_t(n) * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(v.data(), in_b ? vb.p : va.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_wait(k.data(), in_b ? kb.p : ka.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_wait(v.data(), in_b ? vb.p : va.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
     for (uint32_t i = 0; i < n; ++i) { out[size_t(i) * 2] = k[i]; out[size_t(i) * 2 + 1] = v[i]; }
     return DUST_OK;
   }
   if (fn == 13) {  // the cost-ordered hand-out's sorter (k_tile_order) on caller-given tile costs: rows in = cycles, rows out = tile order
     DeviceBuffer cost, order;
-    HIP_TRY(cost.upload(in, size_t(n) * 4));
+    HIP_TRY(cost.upload(in, size_t(n) * 4, ctx->stream));
     HIP_TRY(order.alloc(size_t(n) * 4));
     HIP_TRY(hipMemsetAsync(order.p, 0xFF, size_t(n) * 4, ctx->stream));
     HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), n, (n + dust::kRegions - 1) / dust::kRegions, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_wait(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
     return DUST_OK;
   }
   DeviceBuffer din, dout;
-  HIP_TRY(din.upload(in, size_t(n) * in_words * 4));
+  HIP_TRY(din.upload(in, size_t(n) * in_words * 4, ctx->stream));
   HIP_TRY(dout.alloc(size_t(n) * out_words * 4));
   HIP_TRY(hipMemsetAsync(dout.p, 0, size_t(n) * out_words * 4, ctx->stream));
   HIP_TRY(dust::launch_device_eval(fn, static_cast<const uint32_t*>(din.p), in_words, static_cast<uint32_t*>(dout.p), out_words, n, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipMemcpy(out, dout.p, size_t(n) * out_words * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(copy_wait(out, dout.p, size_t(n) * out_words * 4, hipMemcpyDeviceToHost, ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, uint32_t* cycles, uint32_t capacity, uint32_t* tiles_x, uint32_t* tiles_y) {
   if (!p || pass_kind > 3) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass kind");
-  if (pass_kind == 3) FLUSH_TRY(flush_surfel_pass(p));
   const DustHipPipeline::TileHistory& h = p->tile_history[pass_kind];
   if (tiles_x) *tiles_x = h.measured ? h.tiles_x : 0;
   if (tiles_y) *tiles_y = h.measured ? h.tiles_y : 0;
@@ -1820,7 +1770,7 @@ DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, 
   if (capacity < h.tiles_x * h.tiles_y) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  HIP_TRY(hipMemcpy(cycles, h.cost.p, size_t(h.tiles_x) * h.tiles_y * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(copy_wait(cycles, h.cost.p, size_t(h.tiles_x) * h.tiles_y * 4, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_set_denoiser(DustHipPipeline* p, const DustHipDenoiseParams* dp) {
@@ -1841,7 +1791,6 @@ DustStatus dust_hip_pipeline_restart_denoiser(DustHipPipeline* p) {
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  FLUSH_TRY(flush_surfel_pass(p));
   for (int i = 0; i < DUST_PLANE_COUNT; ++i) HIP_TRY(hipMemsetAsync(p->plane(i), 0, p->planes[i].bytes, p->ctx->stream));
   p->have_history = false;
   p->accum_count = 0;

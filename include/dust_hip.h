@@ -8,6 +8,11 @@
  *
  * Ownership: handles are owned by the library and released by the matching *_destroy; input
  * arrays are borrowed for the duration of the call only (the library copies what it keeps).
+ * Device-side handles (context, model, scene, pipeline) are reference-counted inside the library
+ * the way the reference's are Arc / Handle<T> (Handle<VoxGeometry>, Arc<PipelineLayout> ...):
+ * *_destroy gives up the caller's reference, and an object lives until its last user is gone, so
+ * the destroy calls may come in ANY order (a garbage-collected host may finalise a context before
+ * the models made from it).
  * Threading: a context and everything created from it is externally synchronised (one thread
  * at a time), matching the reference's single render system per frame (examples/castle.rs:139-236).
  */
@@ -200,9 +205,10 @@ DustStatus dust_hip_model_get_voxels(DustHipModel*, const uint32_t* xyz, int32_t
 /* current size of a model's Block array and material stream, and a synchronous copy of both to the host */
 DustStatus dust_hip_model_info(const DustHipModel*, uint32_t* n_blocks, uint64_t* n_materials);
 DustStatus dust_hip_model_read(const DustHipModel*, DustHipBlock* blocks, uint32_t block_capacity, uint8_t* materials, uint64_t material_capacity);
-/* Lifetimes: a model must outlive every scene that instances it, a scene every frame in flight that renders it
- * (dust_hip_sync before destroying), a context everything created from it. Calls on one context are not thread-safe
- * against each other; dust_hip_last_error() is per thread. */
+/* Lifetimes: a scene keeps the models it instances alive, every model / scene / pipeline its context; destroying a scene or
+ * pipeline first waits for the frames in flight on the context's stream. After *_destroy the CALLER must not use the handle
+ * again, whatever else still holds the object. Calls on one context are not thread-safe against each other;
+ * dust_hip_last_error() is per thread. */
 
 /* TLASStore (render/src/accel_struct/tlas.rs:28-180) + the prev-frame transform vec (standard.rs:845-878) */
 DustStatus dust_hip_scene_create(DustHipContext*, DustHipScene** out);
@@ -212,7 +218,10 @@ DustStatus dust_hip_scene_add_instance(DustHipScene*, const DustHipModel*, const
                                        const float prev_obj_to_world_mat4[16], uint32_t* instance_id);
 DustStatus dust_hip_scene_set_transform(DustHipScene*, uint32_t instance_id, const float obj_to_world[12],
                                         const float prev_obj_to_world_mat4[16]);
-/* TLAS build (tlas.rs:43-64): uploads instance records; must be called after add/set before rendering */
+/* TLAS build (tlas.rs:43-64, rebuilt inside the frame's command stream whenever an instance moved): must be called after
+ * add / set_transform (and after editing an instanced model) before rendering. Asynchronous: the records of the instances
+ * that changed are re-derived on the host and one stream-ordered copy from pinned memory carries them to the device behind
+ * the frame in flight -- no allocation and no wait unless instances were added since the last commit. */
 DustStatus dust_hip_scene_commit(DustHipScene*);
 
 /* the members of CameraSettings the shaders read (standard.rs:277-302,813-827; layout.playout:20-33) */
@@ -283,13 +292,7 @@ void dust_hip_pipeline_destroy(DustHipPipeline*);
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const uint8_t* texels, uint32_t layers);
 /* StandardPipeline::render (standard.rs:228-810). Asynchronous on the context's stream.
  * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set.
- * The surfel pass of a frame (DUST_PASS_SURFEL) only has to be complete before the NEXT frame's final gather reads the spatial
- * hash, and it is latency-bound: it is kept back and launched with the next dust_hip_render_frame, beside that frame's primary / AO
- * kernels on a second stream. Results are those of running it at the end of its own frame. Everything that looks at the GI
- * state or at the pass's statistics (dust_hip_pipeline_read_gi, _pass_stats, the GI exchange calls), changes what it reads
- * (dust_hip_scene_commit, dust_hip_model_set_voxels, _set_noise, _configure_gi, _clear, destroying a scene or model) or is
- * dust_hip_sync launches it first. Frames with DUST_PASS_COUNT_STATS or DUST_PASS_GI_SHARDED run it in place, as does
- * DUST_HIP_NO_OVERLAP=1. */
+ * Every pass of the frame is enqueued before the call returns (nothing is kept back for a later call). */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
 /* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
@@ -323,8 +326,11 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline*, DustHipPlane, void* ds
  * spatial_hash.glsl:1, default 32 Mi entries) and the surfel pool (SurfelPoolSize, surfel.glsl:2, default 345600).
  * Called implicitly with the defaults by the first frame that runs a GI pass. */
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline*, uint32_t hash_capacity, uint32_t surfel_pool_size);
-/* synchronous copy of GI state to the host: which = 0 spatial hash ((capacity+2) x 12 B), 1 surfel pool (16 B each) */
+/* synchronous copy of GI state to the host: which = 0 spatial hash ((capacity+2) x 12 B), 1 surfel pool (16 B each);
+ * and its inverse, which restores a saved state into a pipeline configured with the same capacity and pool size (checkpoint /
+ * resume of a converged hash: the reference keeps its hash for the life of the process, standard.rs:334-358) */
 DustStatus dust_hip_pipeline_read_gi(DustHipPipeline*, uint32_t which, void* dst, size_t dst_bytes);
+DustStatus dust_hip_pipeline_write_gi(DustHipPipeline*, uint32_t which, const void* src, size_t src_bytes);
 /* Multi-GPU GI: every GPU keeps an identical spatial hash and surfel pool, the pixel passes run on row bands and the
  * (small) surfel pass is replicated. The reference has no multi-device path; the merge rule is this library's defined
  * order (final_gather.rchit:52-63 leaves the winner among the pixels aliasing a slot to a race): the highest pixel

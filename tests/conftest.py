@@ -29,3 +29,17 @@ def _built():
 def has_gpu():
     from dust_amd import _lib
     return _lib.load().dust_hip_device_count() > 0
+
+
+# the long tests go last (a failure in a short one reports in seconds), the process-isolated stress slices at the very end
+_LATE = ("test_gpu_fullsize", "test_gpu_config4k", "test_configs", "test_gpu_stress")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        for k, late in enumerate(_LATE):
+            if name.startswith(late):
+                return k + 1
+        return 0
+    items.sort(key=rank)   # stable: the order inside a rank stays the collection order

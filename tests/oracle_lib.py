@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+SO = os.environ.get("DUST_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")  # (override: a sanitizer build, tools/asan_host_check.sh)
 
 BLOCK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("w", "<u2"), ("mask", "<u8"),
                         ("material_ptr", "<u4"), ("avg_albedo", "<u4")])

@@ -116,7 +116,7 @@ def test_surfel_position_sort_only_regroups(monkeypatch):
 
 
 _SWITCHES = ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
-             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_NO_OVERLAP", "DUST_HIP_OVERLAP_SHARE")
+             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU")
 
 
 def _castle_gi_states(monkeypatch, settings, frames=3):
@@ -154,14 +154,12 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4; every lane on its own instance vs the whole
     wave on one, bit 8) nor of which rays share a wavefront
     (octant-ordered gather packets, position-ordered surfels), which wave traces which tile when (cost-ordered hand-out), where
-    the cull reads its boxes from, the launch shape, or whether the surfel pass runs at the end of its frame or beside the next
-    frame's primary kernels (the default). Caught a build whose out-of-line neighbour visit passed the
+    the cull reads its boxes from, or the launch shape. Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
     _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
                                                        {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
-                                                       {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"},
-                                                       {"DUST_HIP_NO_OVERLAP": "1"}, {"DUST_HIP_OVERLAP_SHARE": "75"}, {"DUST_HIP_OVERLAP_SHARE": "10"}],
+                                                       {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"}],
                                           frames=5)
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:
@@ -323,56 +321,3 @@ def test_clustered_apply_equals_serial_apply(monkeypatch):
         assert (states[0][0][:, 0] != 0).sum() > 100
         for x, y in zip(*states):
             assert np.array_equal(x, y), capacity
-
-
-def test_kept_back_surfel_pass_is_flushed_where_it_matters(monkeypatch):
-    """The surfel pass of a frame is kept back and launched beside the next frame's primary kernels (capi.cpp). Whatever could
-    observe the difference must launch it first: reading the GI state, dust_hip_sync, pass statistics, a scene commit or a noise
-    upload between two frames, a frame that has no primary pass. Each variant must leave the state of the in-place run."""
-    for k in _SWITCHES:
-        monkeypatch.delenv(k, raising=False)
-    data, _ = synth.castle_scene(scale=0.15)
-    desc = P.SceneDesc.from_vox(data)
-    ctx = api.Context(device=0)
-    s = 0.15
-    sky, cam = P.sky_state(), P.camera_for((122.0 * s, 300.61 * s, 54.45 * s))
-    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
-    gi = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
-
-    def run(between, in_place=False):
-        if in_place:
-            monkeypatch.setenv("DUST_HIP_NO_OVERLAP", "1")
-        else:
-            monkeypatch.delenv("DUST_HIP_NO_OVERLAP", raising=False)
-        scene = P.hip_scene(ctx, desc)
-        pipe = api.StandardPipeline(ctx, 160, 96)
-        pipe.set_noise(0, n0)
-        pipe.set_noise(5, n5)
-        pipe.configure_gi(1 << 14, 640)
-        for f in range(1, 6):
-            pipe.render(scene, cam, sky, gi, frame_index=f, rand=synth.frame_rand(3, f))
-            between(f, pipe, scene)
-        h, sp = pipe.read_gi()
-        monkeypatch.delenv("DUST_HIP_NO_OVERLAP", raising=False)
-        return h, sp.view(np.uint32).copy(), pipe.read_plane(L.PLANE_ILLUMINANCE)
-
-    def split_passes(f, pipe, scene):  # the next call has no primary pass to run beside: the pass must go first, in place
-        if f == 2:
-            pipe.render(scene, cam, sky, L.PASS_FINAL_GATHER | L.PASS_GI_ORDERED, frame_index=f, rand=synth.frame_rand(3, f))
-
-    ref = run(lambda f, pipe, scene: None, in_place=True)
-    ref_split = run(split_passes, in_place=True)
-    variants = {
-        "nothing in between": (lambda f, pipe, scene: None, ref),
-        "sync": (lambda f, pipe, scene: ctx.sync(), ref),
-        "read_gi": (lambda f, pipe, scene: pipe.read_gi() if f in (2, 3) else None, ref),
-        "pass_stats": (lambda f, pipe, scene: pipe.pass_stats(4) if f == 3 else None, ref),
-        "scene commit": (lambda f, pipe, scene: scene.commit() if f in (1, 4) else None, ref),
-        "noise upload": (lambda f, pipe, scene: pipe.set_noise(0, n0) if f == 2 else None, ref),
-        "frame without a primary pass": (split_passes, ref_split),
-    }
-    assert (ref[0][:, 0] != 0).sum() > 50
-    for name, (between, want) in variants.items():
-        got = run(between)
-        for x, y in zip(want, got):
-            assert np.array_equal(x, y), name
