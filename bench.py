@@ -4,19 +4,22 @@
   --workload primary_ao   configs[1] (the headline, default): castle stand-in, 1920x1080, primary + sun-shadow + AO rays
   --workload gi           configs[2]/[3]: the same scene, all four passes + accumulation (--width 3840 --height 2160 for [3])
   --workload deep         configs[4]: procedural 4096^3 tree (hierarchy (4,4,2,2)) at 1 % brick occupancy, GI frame
+  --workload teapot_cpu   configs[0]: teapot, 256x256, one primary ray per pixel, CPU software traversal only (no GPU touched)
 
 One "step" = one frame of the hot path over resident inputs (StandardPipeline::render, standard.rs:477-725).
-With N GPUs (one process per GPU, torch.distributed over RCCL) the work is cut one of two ways:
-  --shard samples (default)  "N spp" in the reference is N consecutive frames (frame_index -> STBN slice, fresh rand):
-                             rank r renders sample k*N + r of the same view; weak scaling, one whole frame per GPU and step.
-  --shard bands              ONE frame per step, cut into N row bands (DustHipFrameParams.row_begin/row_end): strong
-                             scaling. GI workloads keep an identical spatial hash + surfel pool on every GPU through the
-                             exchange of dust_hip_pipeline_gi_exchange (three small collectives per frame) and the
-                             deterministic apply (DUST_PASS_GI_ORDERED); the surfel pass is replicated.
-Either way every rank's RGBA16F illuminance leaves its GPU over RCCL inside the timed region. Whole frames (spp sharding) are
-assembled by row slices -- one all-to-all per step, rank j receives slice j of every rank's frame (--assemble slices, the
-default: xGMI is point to point, and a gather pushes every peer's whole frame through its one link to the root);
---assemble rotate / fixed gather them onto rank k % N / rank 0 instead. Row bands are gathered (rotating root by default).
+With N GPUs (one process per GPU, torch.distributed over RCCL; `python bench.py --gpus N` starts the N ranks itself when it
+was not started by torch.distributed.run) the work is cut two ways, and by default BOTH are measured in one run:
+  bands    ONE frame per step, cut into N row bands (DustHipFrameParams.row_begin/row_end; SURVEY 8e, north_star's partition)
+           with an RCCL gather of the bands: STRONG scaling. This is `value`. GI workloads keep an identical spatial hash +
+           surfel pool on every GPU through the exchange of dust_hip_pipeline_gi_exchange (three small collectives per frame)
+           and the deterministic apply (DUST_PASS_GI_ORDERED); the surfel pass is replicated.
+  samples  "N spp" in the reference is N consecutive frames (frame_index -> STBN slice, fresh rand): rank r renders
+           sample k*N + r of the same view, one whole frame per GPU and step: WEAK scaling, reported under `curves.weak`.
+--shard bands|samples measures only that one. Either way every rank's RGBA16F illuminance leaves its GPU over RCCL inside the
+timed region. Whole frames (samples) are assembled by row slices -- one all-to-all per step, rank j receives slice j of every
+rank's frame (--assemble slices, the default: xGMI is point to point, and a gather pushes every peer's whole frame through its
+one link to the root); --assemble rotate / fixed gather them onto rank k % N / rank 0 instead. Row bands are gathered
+(rotating root by default).
 A ray = one traceRayEXT equivalent actually issued, counted per class by the counting build of the kernels in an untimed frame.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes / HIP-event
@@ -25,8 +28,11 @@ SURVEY F2 -- on a bounded row sample of the same frame).
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -36,9 +42,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 NAMES = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_sun", "surfel_cosine")
+# Untimed frames before the timed region, whatever --warmup says: the cost-ordered hand-out needs measured frames of the SAME
+# view to settle (it re-measures every 8th launch of a still view, capi.cpp order_tiles) and the clocks ramp up over the first
+# few milliseconds -- a 20-step run after 5 warm-up frames read 11 % low in round 2.
+SETTLE_STEPS = 64
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -46,8 +56,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale", type=float, default=1.0, help="castle stand-in scale (1.0 = BASELINE config)")
-    ap.add_argument("--workload", choices=["primary_ao", "gi", "deep"], default="primary_ao")
-    ap.add_argument("--shard", choices=["samples", "bands"], default=None)
+    ap.add_argument("--workload", choices=["primary_ao", "gi", "deep", "teapot_cpu"], default="primary_ao")
+    ap.add_argument("--shard", choices=["samples", "bands", "both"], default=None,
+                    help="N > 1: bands = one frame in N row bands (strong scaling), samples = one frame per GPU (weak scaling); "
+                         "default both, `value` = bands")
     ap.add_argument("--gi-shard", choices=["samples", "bands"], default=None, help="older spelling of --shard")
     ap.add_argument("--assemble", choices=["slices", "rotate", "fixed"], default="slices",
                     help="N > 1, how finished frames leave their GPU: slices = one all-to-all, rank j assembles row slice j of every "
@@ -56,8 +68,8 @@ def parse():
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
-    a = ap.parse_args()
-    a.shard = a.shard or a.gi_shard or "samples"
+    a = ap.parse_args(argv)
+    a.shard = a.shard or a.gi_shard or "both"
     return a
 
 
@@ -68,117 +80,143 @@ def algorithmic_bytes(st, gbuffer_bytes):
             + gbuffer_bytes)
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+# ---------------------------------------------------------------------------------------------------------------------
+# Backends. The measurement below talks to the GPU through this object only, so that tests/test_bench_ranks.py can run the same
+# rank function under gloo on CPU tensors with a recording stand-in for the pipeline (the N > 1 control flow must have executed
+# somewhere before the driver's 8-GPU node is the first to try it).
 
-    import numpy as np
-    import torch  # device memory for the gathered framebuffer, streams, torch.distributed (RCCL): plumbing only
+class HipBackend:
+    """The product: libdust_hip.so through dust_amd.api, torch for device tensors, streams and RCCL."""
+    dist_backend = "nccl"
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
+    def __init__(self, rank, local_rank, world):
+        import torch
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            sys.exit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        from dust_amd import _lib as L
+        from dust_amd import api, sharding, synth
+        from dust_amd import scenes as P  # scene helpers + packaged sky; the oracle is only imported in the cpu_baseline leg
+        self.torch, self.L, self.api, self.sharding, self.synth, self.P = torch, L, api, sharding, synth, P
+        self.rank, self.local_rank, self.world = rank, local_rank, world
+        self.device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(local_rank)
+        # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
+        # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
+        # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
+        self.stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(self.stream)
+        assert self.stream.cuda_stream != 0
+        if world > 1:
+            # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
+            # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1
+            os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
+        self.ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(self.stream.cuda_stream))
+
+    def init_dist(self):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+        return dist
 
-    from dust_amd import _lib as L
-    from dust_amd import api, sharding, synth
-    from dust_amd import scenes as P  # scene description helpers + packaged sky; the oracle is only imported in the cpu_baseline leg
+    def sync(self):
+        self.torch.cuda.synchronize()
 
+    def build_scene(self, args):
+        """-> dict(scene, cam, sky, info, n_bricks, t_load, desc, deep=(blocks, mats, pal, xf) or None)"""
+        import numpy as np
+        api, synth, P = self.api, self.synth, self.P
+        t0 = time.time()
+        out = {"deep": None, "desc": None}
+        if args.workload == "deep":  # SURVEY 8(d) C5: brick occupied iff hash(seed, bx, by, bz) < occupancy, voxels set with p = 0.5
+            blocks, mats = synth.procedural_deep_blocks(occupancy=args.deep_occupancy, sample=True)
+            pal = synth.make_palette(5)
+            t0 = time.time()
+            model = api.Model(self.ctx, blocks, mats, pal, tree_extent_log2=12)
+            scene = api.Scene(self.ctx)
+            xf = np.eye(3, 4, dtype=np.float32)
+            xf[:, 3] = (-2048.0, -2048.0, -2048.0)
+            scene.add_instance(model, xf.reshape(12))
+            scene.commit()
+            out.update(t_load=time.time() - t0, info={"n_models": 1, "n_instances": 1, "n_voxels": int(len(mats))},
+                       n_bricks=int(len(blocks)), deep=(blocks, mats, pal, xf))
+            eye, target = (300.0, 200.0, -150.0), (0.0, 0.0, 0.0)  # inside the volume
+        else:
+            data, info = synth.castle_scene(scale=args.scale)
+            t0 = time.time()
+            desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
+            t_load = time.time() - t0
+            scene = P.hip_scene(self.ctx, desc)
+            s = args.scale
+            eye, target = (122.0 * s, 300.61 * s, 54.45 * s), (0.0, 0.0, 0.0)  # examples/castle.rs:120-129, fov pi/4
+            out.update(t_load=t_load, info=info, n_bricks=desc.n_bricks(), desc=desc)
+        out.update(scene=scene, sky=P.sky_state("default"),
+                   cam=api.make_camera(eye, api.look_at_rotation(eye, target), api.PinholeProjection()))
+        return out
+
+    def make_pipeline(self, w, h):
+        return self.api.StandardPipeline(self.ctx, w, h)
+
+    def noise(self):
+        return self.synth.stbn_scalar(), self.synth.stbn_unitvec3_cosine()
+
+    def bind_target(self, pipe, tensor):
+        pipe.bind_plane(self.L.PLANE_ILLUMINANCE, tensor.data_ptr(), tensor.numel() * 2)
+
+    def alias_exchange(self, ex):
+        return self.sharding.alias_exchange_buffers(ex)
+
+    def check_target(self, pipe, target, rows):
+        """untimed self-check of the plumbing the gather relies on: the bound torch tensor is where the frame went
+        (tests/test_gpu_parity.py::test_bound_plane_equals_own_storage shows a bound target gets the pipeline's own bits)"""
+        import numpy as np
+        torch = self.torch
+        own = torch.from_numpy(pipe.read_plane(self.L.PLANE_ILLUMINANCE)[rows[0]:rows[1]].view(np.int16))
+        assert bool((own != 0).any()) and torch.equal(target[rows[0]:rows[1]].cpu().view(torch.int16), own)
+
+
+def measure_curve(be, dist, args, sc, pipe, shard):
+    """One timed region: the untimed counting frame, the settle + warm-up frames, K timed steps bracketed by barriers.
+    shard: "bands" (one frame in world row bands) or "samples" (one frame per rank). Returns a dict (same on every rank after
+    the reductions) with the whole job's rays per step, the max-over-ranks time and every rank's kernel times."""
+    torch, L, sharding, synth = be.torch, be.L, be.sharding, be.synth
+    rank, world = be.rank, be.world
     W, H = args.width, args.height
-    # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
-    # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
-    # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
-    torch_stream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(torch_stream)
-    stream = torch_stream.cuda_stream
-    assert stream != 0
-    if world > 1:
-        # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
-        # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1
-        os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
-    ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(stream))
-
-    # ------------------------------------------------------------------ scene
+    scene, cam, sky = sc["scene"], sc["cam"], sc["sky"]
     gi_mode = args.workload in ("gi", "deep")
-    deep = args.workload == "deep"
-    t0 = time.time()
-    if deep:  # brick occupied iff hash(seed, bx, by, bz) < occupancy, voxels set with p = 0.5
-        blocks, mats = synth.procedural_deep_blocks(occupancy=args.deep_occupancy, sample=True)
-        pal = synth.make_palette(5)
-        t_gen = time.time() - t0
-        t0 = time.time()
-        model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
-        scene = api.Scene(ctx)
-        xf = np.eye(3, 4, dtype=np.float32)
-        xf[:, 3] = (-2048.0, -2048.0, -2048.0)
-        scene.add_instance(model, xf.reshape(12))
-        scene.commit()
-        t_load = time.time() - t0
-        info = {"n_models": 1, "n_instances": 1, "n_voxels": int(len(mats))}
-        n_bricks = int(len(blocks))
-        eye, target = (300.0, 200.0, -150.0), (0.0, 0.0, 0.0)  # inside the volume
-        desc = None
-    else:
-        data, info = synth.castle_scene(scale=args.scale)
-        t_gen = time.time() - t0
-        t0 = time.time()
-        desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
-        t_load = time.time() - t0
-        scene = P.hip_scene(ctx, desc)
-        n_bricks = desc.n_bricks()
-        s = args.scale
-        eye, target = (122.0 * s, 300.61 * s, 54.45 * s), (0.0, 0.0, 0.0)  # examples/castle.rs:120-129, fov pi/4
-    pipe = api.StandardPipeline(ctx, W, H)
-    noise5 = synth.stbn_unitvec3_cosine()
-    pipe.set_noise(5, noise5)
-    sky = P.sky_state("default")
-    cam = api.make_camera(eye, api.look_at_rotation(eye, target), api.PinholeProjection())
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
     if gi_mode:  # diffuse GI through the surfel-fed spatial hash
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
-        pipe.set_noise(0, synth.stbn_scalar())
-
-    # ------------------------------------------------------------------ partition
-    bands = args.shard == "bands" and world >= 1
+    bands = shard == "bands"
     per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
     have_rows = rows[0] < rows[1]                                        # a rank past the end of the frame renders no pixels
-    gi_bands = gi_mode and bands
+    gi_bands = gi_mode and bands and world > 1   # (one GPU: the band is the frame, nothing to exchange, the racy apply is fine)
     if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
         ex = pipe.gi_exchange(world * per_rows)
-        ex_owner, ex_touched, ex_merged = sharding.alias_exchange_buffers(ex)
+        ex_owner, ex_touched, ex_merged = be.alias_exchange(ex)
 
     # Framebuffer gather: two illuminance targets in torch tensors, bound to the pipeline in turn (dust_hip_pipeline_bind_plane),
     # so RCCL moves frame k straight out of its render target while frame k+1 renders into the other one -- no staging copy.
     # With bands the targets are padded to world * per_rows rows: every rank sends a slice of the SAME size (its band padded to
     # per_rows rows; a collective with unequal counts is undefined), and rank 0 keeps the first H rows of the assembly.
-    # Whole frames per rank (spp sharding) are assembled by row slices (--assemble slices, the default): one all-to-all per step,
+    # Whole frames per rank (samples) are assembled by row slices (--assemble slices, the default): one all-to-all per step,
     # rank j receives slice j of every rank's frame over N-1 links at once; the target is padded to a multiple of N rows.
     # --assemble rotate / fixed gather whole frames onto rank k % N / rank 0 instead (bands always gather: a band is a slice).
     assemble = args.assemble if not bands else ("rotate" if args.assemble == "slices" else args.assemble)
     slices = assemble == "slices" and world > 1
     tgt_rows = world * per_rows if bands else (-(-H // world) * world if slices else H)
-    targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
+    targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device=be.device) for _ in range(2)]
     if slices:
         send = (0, tgt_rows)
     # step k's exchange overlaps step k+1's rendering
     gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]], rotate=assemble == "rotate", slices=slices)
-
     pix_stats = []
 
     def step(k, count=False):
         cs = L.PASS_COUNT_STATS if count else 0
         gather.wait_slot(k % 2)  # the gather that last read this target is done
-        pipe.bind_plane(L.PLANE_ILLUMINANCE, targets[k % 2].data_ptr(), targets[k % 2].numel() * 2)
+        be.bind_target(pipe, targets[k % 2])
         if gi_bands:
             frame_index = 1 + k  # every rank works on the same frame
             rnd = synth.frame_rand(1, frame_index)
@@ -186,7 +224,7 @@ def main():
             if have_rows:
                 pipe.render(scene, cam, sky, pix | cs, frame_index=frame_index, rand=rnd, rows=rows)
             if count:  # the second call restarts the counters: keep the pixel passes' now
-                torch.cuda.synchronize()
+                be.sync()
                 pix_stats[:] = [pipe.pass_stats(i) for i in range(4)] if have_rows else []
             sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
                                       (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: None),
@@ -209,7 +247,7 @@ def main():
         gather.finish()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
 
     # untimed counting frame: rays per class and algorithmic bytes per launch
     step(0, count=True)
@@ -223,20 +261,11 @@ def main():
     rays_rank = sum(x.rays for x in st)
     if gi_bands and rank != 0:
         rays_rank -= st[4].rays + st[5].rays  # the replicated surfel pass counts once
-    # self-check of the plumbing the gather relies on (untimed): the bound torch tensor is where the frame went
-    # (tests/test_gpu_parity.py::test_bound_plane_equals_own_storage shows a bound target gets the same bits as the
-    # pipeline's own plane)
     if have_rows:
-        own = torch.from_numpy(pipe.read_plane(L.PLANE_ILLUMINANCE)[rows[0]:rows[1]].view(np.int16))
-        assert bool((own != 0).any()) and torch.equal(targets[0][rows[0]:rows[1]].cpu().view(torch.int16), own)
-    hit_px = st[0].hits
-    miss_px = st[0].rays - st[0].hits
-    bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
-    # AO kernel: per live pixel read depth 4 + normal 4 + illuminance 8, write illuminance 8 (hit.rchit/ao.rgen)
-    bytes_ao = algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0) - (st[1].hits + st[2].hits) * 5 + hit_px * 24
+        be.check_target(pipe, targets[0], rows)
 
-    import gc
-    for i in range(args.warmup):
+    settle = max(args.warmup, SETTLE_STEPS)
+    for i in range(settle):
         step(1 + i)
     barrier()
     gc.collect()
@@ -244,36 +273,70 @@ def main():
     pipe.kernel_times(mark=True)  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE ...
     t_start = time.perf_counter()
     for i in range(args.steps):
-        step(1 + args.warmup + i)
+        step(1 + settle + i)
     barrier()
     elapsed = time.perf_counter() - t_start
     gc.enable()
     # ... TO HERE: the timed region's own launches, on the launch stream, read back after it (a ring of 256 pairs per pass
     # kind: with more steps than that, the last 256); nothing was synchronised per step
     ev_ms, ev_n = pipe.kernel_times(mark=True)
-    ms_primary, ms_ao, ms_fg, ms_sf = [(ev_ms[k] / ev_n[k]) if ev_n[k] else 0.0 for k in range(4)]
+    ms = [(ev_ms[k] / ev_n[k]) if ev_n[k] else 0.0 for k in range(4)]
     if not gi_mode:
-        ms_fg = ms_sf = 0.0
+        ms[2] = ms[3] = 0.0
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays_all = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
-    mine = torch.tensor([ms_primary, ms_ao, ms_fg, ms_sf], dtype=torch.float64, device="cuda")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
+    rays_all = torch.tensor([float(rays_rank)], dtype=torch.float64, device=be.device)
+    seen = torch.tensor([1.0], dtype=torch.float64, device=be.device)
+    mine = torch.tensor(ms, dtype=torch.float64, device=be.device)
     per_rank = [mine]
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         per_rank = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
     elapsed = float(t_max.item())
-    total_rays_per_step = float(rays_all.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    mrays = total_rays_per_step * args.steps / elapsed / 1e6
+    rays = float(rays_all.item())
+    return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
+            "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
+            "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle}
 
+
+def run_rank(args, be, dist):
+    """Everything one rank does. Rank 0 returns the JSON line's dict, the others None."""
+    rank, world = be.rank, be.world
+    W, H = args.width, args.height
+    gi_mode = args.workload in ("gi", "deep")
+    deep = args.workload == "deep"
+    sc = be.build_scene(args)
+    pipe = be.make_pipeline(W, H)
+    noise0, noise5 = be.noise()
+    pipe.set_noise(5, noise5)
+    if gi_mode:
+        pipe.set_noise(0, noise0)
+
+    if world == 1:
+        wanted = ["bands" if args.shard in ("both", "bands") else "samples"]   # one GPU: the two partitions are the same frame
+    else:
+        wanted = ["bands", "samples"] if args.shard == "both" else [args.shard]
+    curves = {}
+    for shard in wanted:
+        if len(curves) and gi_mode:  # a second curve starts from a fresh hash, like the first
+            pipe.configure_gi(*(getattr(pipe, "_gi", None) or (32 * 1024 * 1024, 720 * 480)))
+            pipe.clear()
+        curves[shard] = measure_curve(be, dist, args, sc, pipe, shard)
+    main_curve = curves[wanted[0]]
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return None
 
+    st, ms = main_curve["st"], main_curve["ms"]
+    ms_primary, ms_ao, ms_fg, ms_sf = ms
+    hit_px = st[0].hits
+    miss_px = st[0].rays - st[0].hits
+    bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
+    # AO kernel: per live pixel read depth 4 + normal 4 + illuminance 8, write illuminance 8 (hit.rchit/ao.rgen)
+    bytes_ao = algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0) - (st[1].hits + st[2].hits) * 5 + hit_px * 24
     kernels_ms_extra = {}
     bytes_fg = bytes_sf = 0
     if gi_mode:
@@ -282,10 +345,7 @@ def main():
         # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
         bytes_sf = (algorithmic_bytes(st[4], 0) + algorithmic_bytes(st[5], st[5].rays * (16 + 48 + 24)) - (st[4].hits + st[5].hits) * 5)
         kernels_ms_extra = {"k_final_gather": round(ms_fg, 4), "k_surfel_trace+apply": round(ms_sf, 4)}
-    overlapped = gi_mode and not gi_bands and "DUST_HIP_NO_OVERLAP" not in os.environ
-    if overlapped:  # the primary + AO kernel and the surfel pass run beside each other: their durations are not their own
-        dominant = ("final_gather", bytes_fg, ms_fg)
-    elif gi_mode and max(ms_fg, ms_sf) > ms_primary:
+    if gi_mode and max(ms_fg, ms_sf) > ms_primary:
         dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
     elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
         dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)
@@ -296,7 +356,7 @@ def main():
     # (tools/profile_round.sh); the committed summary of the latest one is quoted with its provenance, or nothing is
     traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path) and not bands and (W, H) == (1920, 1080):
+    if os.path.exists(pmc_path) and world == 1 and (W, H) == (1920, 1080):
         try:
             pm = json.load(open(pmc_path))
             key = "castle-standin" if not deep else "deep-tree"
@@ -309,93 +369,201 @@ def main():
                                   "passes of this command, 2 x FETCH + WRITE per MI355X_MICROARCH.md; not measured in this run)")
         except Exception:
             traffic, traffic_source = None, None
+    fused = ms_ao == 0.0
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
-                "kernel_ms_source": f"HIP events on the launch stream around every launch of the timed region ({max(ev_n)} launches averaged)" +
-                                    ("; the surfel pass of step k runs beside the primary + AO kernel of step k + 1 on a second stream (each on a "
-                                     "share of the workgroup slots), so those two durations overlap in time and are longer than when run alone "
-                                     "(DUST_HIP_NO_OVERLAP=1)" if gi_mode and not gi_bands and "DUST_HIP_NO_OVERLAP" not in os.environ else ""),
-                "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if ms_ao == 0.0 else
+                "kernel_ms_source": f"HIP events on the launch stream around every launch of the timed region ({main_curve['launches']} launches averaged)",
+                "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if fused else
                                    {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
-                "per_rank_kernel_ms": [{"primary_ao" if ms_ao == 0.0 else "primary": round(float(v[0]), 4),
-                                        **({"ambient_occlusion": round(float(v[1]), 4)} if ms_ao != 0.0 else {}),
-                                        **({"final_gather": round(float(v[2]), 4), "surfel": round(float(v[3]), 4)} if gi_mode else {})}
-                                       for v in per_rank],
+                "per_rank_kernel_ms": [{"primary_ao" if fused else "primary": round(v[0], 4),
+                                        **({"ambient_occlusion": round(v[1], 4)} if not fused else {}),
+                                        **({"final_gather": round(v[2], 4), "surfel": round(v[3], 4)} if gi_mode else {})}
+                                       for v in main_curve["per_rank"]],
                 "bytes_per_ray": {"primary": round(bytes_primary / max(1, st[0].rays), 1),
                                   "ao_pass": round(bytes_ao / max(1, st[1].rays + st[2].rays), 1)}}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O  # the checker, used here only as the reported CPU baseline (never in the timed GPU path)
-        import parity_util
-        if deep:
-            oscene = O.Scene()
-            oscene.add_model(blocks, mats, pal, extent=4096)
-            oscene.add_instance(0, xf.reshape(12))
-            oscene.commit()
-        else:
-            oscene = parity_util.oracle_scene(desc)
-        cores = os.cpu_count() or 1
-        n_rows = args.cpu_rows or max(cores, min(H, (2 if deep else 8) * cores))
-        n_rows = min(n_rows, H)
-        y0 = (H - n_rows) // 2
-        g = O.GBuffer(W, H)
-        oc, osky = O.camera_from(cam), O.sky_from(sky)
-        n5 = np.ascontiguousarray(noise5[1 % len(noise5)])
-        stats = [[O.OrcRayStats(), O.OrcRayStats(), O.OrcRayStats()] for _ in range(cores)]
-        lib = O.lib()
-
-        def work(t):
-            a = y0 + (n_rows * t) // cores
-            b = y0 + (n_rows * (t + 1)) // cores
-            lib.orc_pass_primary(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c), a, b,
-                                 ctypes.byref(stats[t][0]))
-            lib.orc_pass_ao(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c),
-                            n5.ctypes.data_as(ctypes.c_void_p), synth.frame_rand(1, 1), a, b, ctypes.byref(stats[t][1]),
-                            ctypes.byref(stats[t][2]))
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        dt = time.perf_counter() - t0
-        cpu_rays = sum(s_.rays for ss in stats for s_ in ss)
-        cpu = {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"primary + sun-shadow + AO rays of rows {y0}..{y0 + n_rows} of the same frame ({cpu_rays} rays, {dt:.1f} s), oracle "
-                         f"hierarchical mode, {cores} threads; scene build (tree build + flatten / hierarchy upload) took {t_load:.2f} s on the same cores"}
+        cpu = cpu_baseline(args, sc, noise5, be.synth)
 
     what = {"primary_ao": "1spp primary+shadow+AO", "gi": "1 GI frame: primary+shadow+AO+final gather+surfel",
             "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
     scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
                   ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}"))
-    root_txt = "k % N for step k (rotating root)" if assemble == "rotate" and world > 1 else "0"
-    if bands:
-        par = (f"bands x{world}: one frame in {world} row bands of {per_rows} rows"
-               + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
-                  "winning surfels, deterministic apply), surfel pass replicated" if gi_mode else "")
-               + ", RCCL gather of the (equal-size, padded) bands to rank " + root_txt)
-    else:
-        par = (f"spp x{world}: one {W}x{H} sample per GPU, " +
-               ("RCCL all-to-all of the RGBA16F frames by row slices (rank j assembles slice j of every sample)" if slices or world == 1 and assemble == "slices"
-                else f"RCCL gather of RGBA16F frames to rank {root_txt}"))
+
+    def parallelism(c):
+        root_txt = "k % N for step k (rotating root)" if c["assemble"] == "rotate" and world > 1 else "0"
+        if c["shard"] == "bands":
+            return (f"bands x{world}: one frame in {world} row bands of {c['per_rows']} rows"
+                    + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
+                       "winning surfels, deterministic apply), surfel pass replicated" if gi_mode and world > 1 else "")
+                    + (", RCCL gather of the (equal-size, padded) bands to rank " + root_txt if world > 1 else ""))
+        return (f"spp x{world}: one {W}x{H} sample per GPU, " +
+                ("RCCL all-to-all of the RGBA16F frames by row slices (rank j assembles slice j of every sample)" if c["slices"] or world == 1
+                 else f"RCCL gather of RGBA16F frames to rank {root_txt}"))
     metric = {"primary_ao": f"Mrays/s at {W}x{H} 1spp castle.vox (primary + sun-shadow + AO rays)",
               "gi": f"Mrays/s at {W}x{H} castle.vox, diffuse GI frame (primary, shadow, AO, final gather, surfel rays)",
               "deep": f"Mrays/s at {W}x{H} procedural 4096^3 sparse vdb, diffuse GI frame (deep-tree stress)"}[args.workload]
+    info = sc["info"]
+    bands_main = main_curve["shard"] == "bands"
     out = {
-        "metric": metric, "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
+        "metric": metric, "value": round(main_curve["mrays"], 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(main_curve["ms_per_step"], 4), "higher_is_better": True, "scaling": main_curve["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene_name}, {W}x{H}{'' if bands else ' per GPU'}, {what}",
-                   "frame": [W, H], "spp_per_step": 1 if bands else world, "parallelism": par,
+        "config": {"workload": f"{scene_name}, {W}x{H}{'' if bands_main else ' per GPU'}, {what}",
+                   "frame": [W, H], "spp_per_step": 1 if bands_main else world, "parallelism": parallelism(main_curve),
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
-                   "bricks": n_bricks, "scene_build_s": round(t_load, 3),
-                   "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(total_rays_per_step)},
+                   "bricks": sc["n_bricks"], "scene_build_s": round(sc["t_load"], 3), "untimed_steps_before_timing": main_curve["settle"],
+                   "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(main_curve["rays_per_step"])},
+        "ranks_seen": main_curve["ranks_seen"],
+        "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
+                                  "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c),
+                                  "per_rank_kernel_ms": [[round(x, 4) for x in v] for v in c["per_rank"]]} for c in curves.values()},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    return out
+
+
+def cpu_baseline(args, sc, noise5, synth):
+    """The oracle's hierarchical traversal on the host cores, on a bounded row sample of the same frame (a reported baseline)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker, used here only as the reported CPU baseline (never in the timed GPU path)
+    import parity_util
+    W, H = args.width, args.height
+    deep = args.workload == "deep"
+    if deep:
+        blocks, mats, pal, xf = sc["deep"]
+        oscene = O.Scene()
+        oscene.add_model(blocks, mats, pal, extent=4096)
+        oscene.add_instance(0, xf.reshape(12))
+        oscene.commit()
+    else:
+        oscene = parity_util.oracle_scene(sc["desc"])
+    cores = os.cpu_count() or 1
+    n_rows = args.cpu_rows or max(cores, min(H, (2 if deep else 8) * cores))
+    n_rows = min(n_rows, H)
+    y0 = (H - n_rows) // 2
+    g = O.GBuffer(W, H)
+    oc, osky = O.camera_from(sc["cam"]), O.sky_from(sc["sky"])
+    n5 = np.ascontiguousarray(noise5[1 % len(noise5)])
+    stats = [[O.OrcRayStats(), O.OrcRayStats(), O.OrcRayStats()] for _ in range(cores)]
+    lib = O.lib()
+
+    def work(t):
+        a = y0 + (n_rows * t) // cores
+        b = y0 + (n_rows * (t + 1)) // cores
+        lib.orc_pass_primary(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c), a, b,
+                             ctypes.byref(stats[t][0]))
+        lib.orc_pass_ao(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c),
+                        n5.ctypes.data_as(ctypes.c_void_p), synth.frame_rand(1, 1), a, b, ctypes.byref(stats[t][1]),
+                        ctypes.byref(stats[t][2]))
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.perf_counter() - t0
+    cpu_rays = sum(s_.rays for ss in stats for s_ in ss)
+    return {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"primary + sun-shadow + AO rays of rows {y0}..{y0 + n_rows} of the same frame ({cpu_rays} rays, {dt:.1f} s), oracle "
+                      f"hierarchical mode, {cores} threads; scene build (tree build + flatten / hierarchy upload) took {sc['t_load']:.2f} s on the same cores"}
+
+
+def teapot_cpu(args):
+    """configs[0]: teapot.vox stand-in, 256x256, one primary ray per pixel, CPU software vdb traversal -- the reference's own
+    CPU-runnable case (its plumbing: vox loader + tree build on the host; the traversal is the oracle's port). No GPU
+    is touched; the product library only parses the file and builds the trees (host code). Same JSON contract."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # this whole workload is the cpu_baseline leg
+    import parity_util
+    from dust_amd import api, synth
+    from dust_amd import scenes as P
+    W = H = 256
+    t0 = time.perf_counter()
+    desc = P.SceneDesc.from_vox(synth.teapot_scene(96))  # dust_vox_load (product host code): parse + tree build + flatten
+    t_load = time.perf_counter() - t0
+    m = desc.instances[0][1].reshape(3, 4).copy()   # the teapot hovers 200 voxels up, as in tests/test_configs.py
+    m[:, 3] += np.array([0.0, 200.0, 0.0], np.float32)
+    desc.instances[0] = (desc.instances[0][0], m.reshape(12))
+    oscene = parity_util.oracle_scene(desc)
+    eye = (60.0, 250.0, 70.0)
+    cam = api.make_camera(eye, api.look_at_rotation(eye, (0.0, 200.0, 0.0)), api.PinholeProjection())
+    oc, osky = O.camera_from(cam), O.sky_from(P.sky_state("default"))
+    g = O.GBuffer(W, H)
+    cores = os.cpu_count() or 1
+    threads = min(cores, H // 2)
+    lib = O.lib()
+    steps = max(1, args.steps)
+    stats = [O.OrcRayStats() for _ in range(threads)]
+
+    def frame():
+        def work(t):
+            stats[t] = O.OrcRayStats()
+            lib.orc_pass_primary(oscene.h, O.ORC_MODE_HIER, ctypes.byref(oc), ctypes.byref(osky), ctypes.byref(g.c), (H * t) // threads,
+                                 (H * (t + 1)) // threads, ctypes.byref(stats[t]))
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+    for _ in range(max(1, args.warmup)):
+        frame()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    dt = time.perf_counter() - t0
+    rays = sum(s.rays for s in stats)
+    hits = sum(s.hits for s in stats)
+    assert rays == W * H and 0 < hits < rays, (rays, hits)
+    v = round(rays * steps / dt / 1e6, 4)
+    out = {"metric": "Mrays/s at 256x256 teapot.vox, 1 primary ray/pixel, CPU software vdb traversal", "value": v, "unit": "Mrays/s",
+           "n_gpus": 0, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "teapot.vox stand-in (synth.teapot_scene), 256x256, 1 primary ray/pixel, CPU only (BASELINE configs[0])",
+                      "frame": [W, H], "parallelism": f"{threads} host threads over row bands", "vox_models": len(desc.models),
+                      "instances": len(desc.instances), "bricks": desc.n_bricks(), "scene_build_s": round(t_load, 4),
+                      "rays_per_step": {"primary": int(rays)}, "hits": int(hits)},
+           "roofline": None,
+           "cpu_baseline": {"value": v, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                            "sample": f"the whole workload: {steps} frames of {rays} primary rays, oracle hierarchical mode, {threads} threads"}}
     print(json.dumps(out))
-    if world > 1:
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks of this node here (the same command line the
+    driver uses), after checking that the node has N devices."""
+    from dust_amd import _lib
+    have = _lib.load().dust_hip_device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool: RCCL needs it
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def main():
+    args = parse()
+    if args.workload == "teapot_cpu":
+        return teapot_cpu(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world
+    be = HipBackend(rank, local_rank, world)
+    dist = be.init_dist() if world > 1 else None
+    out = run_rank(args, be, dist)
+    if out is not None:
+        print(json.dumps(out))
+    if dist is not None:
         dist.destroy_process_group()
 
 

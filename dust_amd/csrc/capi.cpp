@@ -298,7 +298,7 @@ struct Tuning {
   static Tuning from_environment() {
     Tuning t;
     t.debug = num("DUST_HIP_DEBUG", 0);
-    t.block = std::min(512u, std::max(64u, num("DUST_HIP_BLOCK", 512) & ~63u));
+    t.block = std::min(1024u, std::max(64u, num("DUST_HIP_BLOCK", 512) & ~63u));  // (<= the launch bounds of the kernels it is used with)
     t.blocks_per_cu = std::max(1u, num("DUST_HIP_BLOCKS_PER_CU", 2));
     t.reserve_blocks = num("DUST_HIP_RESERVE_BLOCKS", 0) & ~7u;  // whole rounds over the 8 XCDs
     t.no_fuse = std::getenv("DUST_HIP_NO_FUSE") != nullptr;

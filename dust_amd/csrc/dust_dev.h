@@ -163,6 +163,9 @@ struct FrameArgs {
   float inv_width, inv_height, aspect;  // RN(1 / width), RN(1 / height), RN(width / height): camera.glsl's divisions, done once
   uint32_t row_begin, row_end;
   uint32_t tiles_x, tiles_y, tile_row0;  // 8x8 pixel tiles covering [row_begin,row_end)
+  uint32_t tiles_per_band;    // ceil(tiles / 8): the launch's hand-out schedule, filled in at launch (kernels.hip, with_schedule)
+  uint32_t tiles_x_magic;     // floor(2^32 / tiles_x) + 1: __umulhi(tile, magic) == tile / tiles_x
+  uint32_t static_rounds;     // rounds of a band's order that are dealt to its waves; the rest is grabbed
   // Cost-ordered work distribution: every wave records the cycles it spent on each tile (tile_cost); before the next launch
   // of the same pass k_tile_order turns that into tile_order -- per XCD band, most expensive first --, which maps ticket ->
   // tile. Both null on the first frame of a pass (identity order) or when switched off.

@@ -961,27 +961,33 @@ struct Packet {
 };
 
 // Work distribution. The tile list is cut into 8 contiguous bands, one per XCD (block b runs on XCD b % 8, so a band
-// stays in one L2). A wave's first tile in its own band is assigned statically (its index among the band's waves:
-// no 512-deep queue on the counter at kernel start); after that tiles come from the band's atomic counter, whose
-// tickets therefore start at "number of waves in the band", through the workgroup's LDS queue (below). A workgroup
-// drains its own band first, then helps the others. Each counter owns a 256-byte line (sharing one line across XCDs
-// serialised every grab: 0.77 ms -> 0.39 ms per pass when they were separated). Measured and rejected: one device
-// atomic per tile and wave with the NEXT ticket requested before tracing the current packet (+7 %: returns are in order,
-// so the first load of the packet waits for the atomic anyway), per-wave chunks of 2 tiles (+13 %), static striding,
-// 4 sub-queues per band (+2.5 %), queue batches of 8 (even) and 16 (+5 %: tail).
+// stays in one L2). Each band's tiles are handed out in the band's ORDER (k_tile_order: most expensive first, by what the
+// pass's previous launch measured; screen order when nothing was measured yet):
+//   * a wave's first tile is DEALT, not grabbed (`static_rounds` = 1: position i of the band for its wave i -- no 512-deep
+//     queue on the counter at kernel start);
+//   * everything else comes from the band's atomic counter through the workgroup's LDS queue (below): whoever is done first
+//     takes more. A workgroup drains its own band first, then helps the others. Each counter owns a 256-byte line (sharing
+//     one line across XCDs serialised every grab: 0.77 ms -> 0.39 ms per pass when they were separated).
+// Dealing MORE rounds (round r: position r W + i, back and forth over the cost-sorted band -- the classic longest-first deal, no
+// atomic and no queue for three tiles in four) was built in round 3 and lost badly: 4 / 6 / 7 dealt rounds of the castle's 7.9
+// per wave took 0.273 / 0.283 / 0.309 ms against 0.241 grabbed. Last frame's cost classes predict a tile to a quarter octave
+// and say nothing about which waves will share a SIMD; the grab corrects both as it goes. DUST_HIP_STATIC_ROUNDS overrides.
+// Measured and rejected for the grabbed part: one device atomic per tile and wave with the NEXT ticket requested before
+// tracing the current packet (+7 %: returns are in order, so the first load of the packet waits for the atomic anyway),
+// per-wave chunks of 2 tiles (+13 %), static striding without an order, 4 sub-queues per band (+2.5 %), queue batches of 8
+// (even) and 16 (+5 %: tail).
 struct WorkCursor {
-  uint32_t ticket;      // the static first tile (band-relative), kNoTicket once it is used
+  uint32_t round;       // dealt rounds taken so far
 };
-constexpr uint32_t kNoTicket = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t band_static_tickets(uint32_t band) {  // waves whose own band this is
   return ((gridDim.x + 7u - band) >> 3) * (blockDim.x >> 6);
 }
 __device__ __forceinline__ WorkCursor cursor_begin() {
   WorkCursor w;
-  w.ticket = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  w.round = 0;
   return w;
 }
-// After that static first tile a workgroup's waves share a small queue in LDS: {next, end} in one 64-bit word, taken from
+// After the dealt rounds a workgroup's waves share a small queue in LDS: {next, end} in one 64-bit word, taken from
 // with ds_add_rtn_u64. The wave that finds it exactly empty refills it with kGrabBatch consecutive tiles -- one device-scope
 // atomic on the band's counter per batch instead of one per tile (a ~2 us round trip on which each wave used to spend 16 %
 // of its time) -- and the others retry; neighbouring tiles run at the same time on the same CU. -1.5 % to -3 % per kernel.
@@ -1001,39 +1007,45 @@ __device__ __forceinline__ void account_tile(ArgsRef a, uint32_t next_tile) {
     slot[0] = next_tile; slot[1] = now;
   }
 }
-__device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t tile, Packet& p) {
+// `ticket` = band * tiles_per_band + pos: position `pos` of the band's order
+__device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint32_t pos, Packet& p) {
   const uint32_t lane = threadIdx.x & 63u;
+  uint32_t tile = ticket;
   if (a.tile_order) {
     // With the tiles handed out longest first the launch is as long as its most expensive tile takes (it starts at once and
     // ends last: 545 k of the fused kernel's 570 k cycles on the castle), and that tile takes as long as it does because its
     // wave shares a SIMD with three others. The position in the band's order says how expensive the tile was last time:
     // the few at the front get the arbiter's priority, so the critical path runs at nearly a lone wave's speed while the
     // waves that give way have slack.
-    const uint32_t per = (a.tiles_x * a.tiles_y + kRegions - 1u) / kRegions, pos = tile % per;
+    const uint32_t per = a.tiles_per_band;
     const uint32_t rank = pos < (per >> 5) ? 3u : (pos < (per >> 3) ? 2u : (pos < (per >> 1) ? 1u : 0u));
     const uint32_t prio = rank > a.prio_floor ? rank : a.prio_floor;
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
-    tile = a.tile_order[tile];  // ticket -> tile, most expensive tiles of the band first
+    tile = a.tile_order[ticket];  // ticket -> tile, most expensive tiles of the band first
   }
   account_tile(a, tile);
-  const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const uint32_t ty = __umulhi(tile, a.tiles_x_magic), tx = tile - ty * a.tiles_x;  // tile / tiles_x, exact (launch: tiles * tiles_x < 2^32)
   p.px = tx * 8u + (lane & 7u);
   p.py = a.row_begin + ty * 8u + (lane >> 3);
   p.valid = p.px < a.width && p.py < a.row_end;
 }
 __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) {
   const uint32_t total = a.tiles_x * a.tiles_y;
-  const uint32_t per = (total + kRegions - 1u) / kRegions;
+  const uint32_t per = a.tiles_per_band;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t own = blockIdx.x & 7u;
   PROF_ENTER(P_GRAB);
-  if (w.ticket != kNoTicket) {  // the static first tile
-    const uint32_t k = w.ticket, tile = own * per + k;
-    w.ticket = kNoTicket;
-    if (k < per && tile < total) { packet_of_tile(a, tile, p); PROF_LEAVE(P_GRAB); return true; }
+  if (w.round < a.static_rounds) {  // a dealt tile
+    const uint32_t W = band_static_tickets(own);
+    const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const uint32_t r = w.round;
+    w.round = r + 1u;
+    const uint32_t pos = r * W + ((r & 1u) ? W - 1u - i : i);
+    if (pos < per && own * per + pos < total) { packet_of_tile(a, own * per + pos, pos, p); PROF_LEAVE(P_GRAB); return true; }
+    w.round = a.static_rounds;  // (a band shorter than the deal: on to the queue, which is empty for it too)
   }
   unsigned long long* q = block_queue(a);
   volatile unsigned long long* qv = q;
@@ -1043,7 +1055,12 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     if (lane == 0) old = atomicAdd(q, 1ull);
     const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
     const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
-    if (next < end) { packet_of_tile(a, next, p); PROF_LEAVE(P_GRAB); return true; }
+    if (next < end) {  // (the queue holds tickets of ONE band: the high word's band)
+      const uint32_t band = (own + (uint32_t)__builtin_amdgcn_readfirstlane((int)*band_try)) & 7u;
+      packet_of_tile(a, next, next - band * per, p);
+      PROF_LEAVE(P_GRAB);
+      return true;
+    }
     if (end == 0u && next >= kQueueDone) { account_tile(a, 0xFFFFFFFFu); PROF_LEAVE(P_GRAB); return false; }
     if (next != end) { __builtin_amdgcn_s_sleep(4); continue; }  // another wave is refilling
     // exactly empty: this wave refills. Own band first, then the others' (a band stays in one XCD's L2 while it lasts).
@@ -1057,7 +1074,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
       }
       const uint32_t band = (own + bt) & 7u;
       uint32_t k = 0;
-      if (lane == 0) k = band_static_tickets(band) + atomicAdd((uint32_t*)&a.work_counters[band * kCounterStride], kGrabBatch);
+      if (lane == 0) k = a.static_rounds * band_static_tickets(band) + atomicAdd((uint32_t*)&a.work_counters[band * kCounterStride], kGrabBatch);
       k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
       const uint32_t lo = band * per + k;
       uint32_t hi = band * per + (k + kGrabBatch < per ? k + kGrabBatch : per);
@@ -1067,7 +1084,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
           *band_try = bt;
           *qv = ((unsigned long long)hi << 32) | (unsigned long long)(lo + 1u);  // one 8-byte LDS store: the batch goes live
         }
-        packet_of_tile(a, lo, p);
+        packet_of_tile(a, lo, k, p);
         PROF_LEAVE(P_GRAB);
         return true;
       }
@@ -1321,8 +1338,12 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
 // wave that traced a packet's primary rays goes straight on to its shadow and AO rays with depth and normal still
 // in registers (as the quantised values the separate pass would load back). One launch, one LDS staging and one
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
+#ifndef DUST_PAO_THREADS
+#define DUST_PAO_THREADS 512
+#define DUST_PAO_WAVES 4
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(512, 4) k_primary_ao(const FrameArgs) {
+__global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao(const FrameArgs) {
   ArgsRef a0 = launch_args();
   stage_roots(a0);
   uint32_t* cand = wave_cand_list(a0);
@@ -2337,9 +2358,23 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t tot
   return hipGetLastError();
 }
 
+// the launch's hand-out schedule (next_packet): tiles per band, the exact-quotient multiplier for tile / tiles_x, and how many
+// rounds are dealt -- all but roughly the last quarter of a band's tiles, which the waves grab as they finish
+static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t block) {
+  FrameArgs a = in;
+  const uint32_t total = a.tiles_x * a.tiles_y;
+  a.tiles_per_band = (total + kRegions - 1u) / kRegions;
+  a.tiles_x_magic = (uint32_t)((1ull << 32) / (a.tiles_x ? a.tiles_x : 1u)) + 1u;
+  const uint32_t waves = ((grid + kRegions - 1u) / kRegions) * (block / 64u);  // the fullest band's
+  const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;
+  a.static_rounds = rounds >= 1u ? 1u : 0u;  // (see next_packet: dealing more than the first round was measured and lost)
+  if (const char* e = getenv("DUST_HIP_STATIC_ROUNDS")) a.static_rounds = (uint32_t)atoi(e);
+  return a;
+}
 // kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model)
-#define DUST_LAUNCH_MODE(kernel, count, a)                                                          \
+#define DUST_LAUNCH_MODE(kernel, count, a_in)                                                       \
   do {                                                                                              \
+    const FrameArgs a = with_schedule(a_in, grid, block);                                           \
     switch (((count) ? 1 : 0) | ((a).deep ? 2 : 0)) {                                               \
       case 0: hipLaunchKernelGGL(kernel<0>, dim3(grid), dim3(block), lds, s, a); break;             \
       case 1: hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(block), lds, s, a); break;             \
@@ -2351,19 +2386,19 @@ static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
   return (size_t)a.n_lds_models * kN16LdsBytes + (size_t)(block / 64u) * (kMaxCand * 8u + 8u) + 16u + (size_t)a.n_lds_boxes * 32u;  // roots, candidate lists + tile accounts, tile queue, boxes
 }
 
-hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  DUST_LAUNCH_MODE(k_primary, count, a);
+hipError_t launch_primary(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_primary, count, a_in);
   return hipGetLastError();
 }
-hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  DUST_LAUNCH_MODE(k_primary_ao, count, a);
+hipError_t launch_primary_ao(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_primary_ao, count, a_in);
   return hipGetLastError();
 }
-hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  DUST_LAUNCH_MODE(k_ambient_occlusion, count, a);
+hipError_t launch_ambient_occlusion(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_ambient_occlusion, count, a_in);
   return hipGetLastError();
 }
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t s) {
@@ -2378,19 +2413,19 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
   hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderThreads), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  DUST_LAUNCH_MODE(k_final_gather, count, a);
-  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a);
+hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_final_gather, count, a_in);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a_in);
   return hipGetLastError();
 }
 hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = lds_bytes(a, block);
-  DUST_LAUNCH_MODE(k_surfel_trace, count, a);
+hipError_t launch_surfel_trace(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_surfel_trace, count, a_in);
   return hipGetLastError();
 }
 // mode 0: concurrent (racy, as the reference); 1: serial in surfel order (one wavefront); 2: keys for the clustered apply;

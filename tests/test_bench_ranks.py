@@ -1,0 +1,166 @@
+"""bench.py's rank function under gloo, world size 2, on CPU tensors with a recording stand-in for the pipeline: the N > 1 control
+flow (both partitions in one run, band layout and padded gathers, the all-to-all by row slices, the GI exchange choreography,
+the reductions behind the JSON line) executes here before the driver's 8-GPU node is the first to try it. The stand-in renders
+nothing -- it stamps (rank, frame, row) patterns into the bound target so that the assembled frames can be checked -- and the
+product library is not involved: this tests bench.py, not the kernels."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json, types
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+import bench
+from dust_amd import _lib as L, sharding, synth
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+W, H = 64, 40          # 40 rows on 2 ranks: bands of 24 rows (8-aligned), the second one shorter -- the padded case
+workload = os.environ["BENCH_WORKLOAD"]
+
+
+class Stats:
+    def __init__(self, rays=0, hits=0):
+        self.rays, self.hits = rays, hits
+        self.instances_tested = self.upper_descents = self.mid_descents = self.bricks_tested = 0
+
+
+class StubPipe:
+    """records what bench.py asks for; writes a pattern where a frame would go"""
+    def __init__(self):
+        self.target, self.calls, self.last = None, [], {}
+        self.width, self.height = W, H
+        self.n_render = 0
+    def set_noise(self, *a): pass
+    def configure_gi(self, *a): self.calls.append("configure_gi")
+    def clear(self): self.calls.append("clear")
+    def render(self, scene, cam, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
+        r0, r1 = rows if rows[1] else (0, H)
+        self.n_render += 1
+        self.last = {"passes": passes, "rows": (r0, r1), "frame": frame_index}
+        if passes & L.PASS_PRIMARY:
+            # RGBA16F stand-in: channel 0 = frame index, 1 = rank, 2 = row
+            rows_t = torch.arange(r0, r1, dtype=torch.float16).view(-1, 1)
+            self.target[r0:r1, :, 0] = float(frame_index % 1024)
+            self.target[r0:r1, :, 1] = float(rank)
+            self.target[r0:r1, :, 2] = rows_t
+            self.px = (r1 - r0) * W
+    def pass_stats(self, i):
+        px = getattr(self, "px", 0)
+        return Stats(rays=px if i < 4 else 100, hits=px // 2 if i < 4 else 50)
+    def kernel_times(self, mark=True):
+        n = self.n_render
+        self.n_render = 0
+        return [0.25 * n, 0.0, 0.1 * n, 0.05 * n], [n, 0, n, n]
+    def gi_exchange(self, padded_rows):
+        self.ex = types.SimpleNamespace(pool_size=128, width=W, touched_rows=padded_rows)
+        return self.ex
+    def gi_export(self, r0, r1): self.calls.append(("export", r0, r1))
+    def gi_import(self, r0, r1, f): self.calls.append(("import", r0, r1, f))
+
+
+class StubBackend:
+    def __init__(self):
+        self.torch, self.L, self.sharding, self.synth = torch, L, sharding, synth
+        self.rank, self.local_rank, self.world = rank, rank, world
+        self.device = torch.device("cpu")
+        self.pipe = StubPipe()
+    def sync(self): pass
+    def build_scene(self, args):
+        return {"scene": None, "cam": None, "sky": None, "info": {"n_models": 1, "n_instances": 1, "n_voxels": 1}, "n_bricks": 1,
+                "t_load": 0.0, "desc": None, "deep": None}
+    def make_pipeline(self, w, h): return self.pipe
+    def noise(self): return None, None
+    def bind_target(self, pipe, tensor): pipe.target = tensor
+    def alias_exchange(self, ex):
+        return (torch.zeros(ex.pool_size, dtype=torch.int32), torch.zeros(ex.touched_rows * ex.width, dtype=torch.int32),
+                torch.zeros(ex.pool_size * 4, dtype=torch.int32))
+    def check_target(self, pipe, target, rows):
+        assert float(target[rows[0], 0, 1]) == float(rank)
+
+
+args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", str(W), "--height", str(H),
+                    "--workload", workload, "--no-cpu-baseline"])
+bench.SETTLE_STEPS = 2
+be = StubBackend()
+out = bench.run_rank(args, be, dist)
+if rank == 0:
+    json.dumps(out)   # serialisable
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2, out
+    assert out["scaling"] == "strong" and set(out["curves"]) == {"strong", "weak"}, out
+    strong, weak = out["curves"]["strong"], out["curves"]["weak"]
+    assert out["value"] == strong["value"]
+    gi = workload == "gi"
+    # bands: the two ranks' pixels add up to ONE frame; samples: one whole frame each
+    extra = 200 if gi else 0   # the replicated surfel pass counts once
+    classes = 4 if gi else 3
+    assert strong["rays_per_step_all_gpus"] == W * H * classes + extra, strong
+    assert weak["rays_per_step_all_gpus"] == 2 * (W * H * classes + extra), weak
+    assert len(strong["per_rank_kernel_ms"]) == 2 and len(weak["per_rank_kernel_ms"]) == 2
+    assert "bands x2" in strong["parallelism"] and "spp x2" in weak["parallelism"]
+    if gi:
+        assert "clear" in be.pipe.calls and ("export", 0, 24) in be.pipe.calls
+    print("BENCH_RANKS_OK", json.dumps(out)[:200])
+else:
+    assert out is None
+    if workload == "gi":
+        assert ("export", 24, 40) in be.pipe.calls   # the shorter, padded band
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run(workload):
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   BENCH_WORKLOAD=workload)
+        procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT={ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    assert "BENCH_RANKS_OK" in outs[0][0]
+
+
+def test_bench_rank_function_two_ranks_primary_ao():
+    _run("primary_ao")
+
+
+def test_bench_rank_function_two_ranks_gi():
+    _run("gi")
+
+
+def test_bench_gpus_without_devices_says_so():
+    """`python bench.py --gpus 2` on a node with fewer devices: a clear message, not a usage hint (here: no device at all)."""
+    from dust_amd import _lib
+    have = _lib.load().dust_hip_device_count()
+    if have >= 2:
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=120, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0
+    assert f"only {have} HIP device(s) visible" in r.stderr
+
+
+def test_bench_teapot_cpu_line():
+    """configs[0] has a bench line of its own: CPU traversal only, same JSON contract."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "teapot_cpu", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 0 and j["value"] > 0 and j["config"]["rays_per_step"]["primary"] == 256 * 256
