@@ -46,6 +46,7 @@ NAMES = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_s
 # view to settle (it re-measures every 8th launch of a still view, capi.cpp order_tiles) and the clocks ramp up over the first
 # few milliseconds -- a 20-step run after 5 warm-up frames read 11 % low in round 2.
 SETTLE_STEPS = 64
+SETTLE_SECONDS = 0.3   # ... and at least this long, back to back, so that the timed region starts on a GPU at its sustained clocks
 
 
 def parse(argv=None):
@@ -264,13 +265,15 @@ def measure_curve(be, dist, args, sc, pipe, shard):
     if have_rows:
         be.check_target(pipe, targets[0], rows)
 
-    settle = max(args.warmup, SETTLE_STEPS)
-    for i in range(settle):
-        step(1 + i)
-    barrier()
     gc.collect()
-    gc.disable()  # no collector pause between two launches of the timed loop
-    pipe.kernel_times(mark=True)  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE ...
+    gc.disable()  # no collector pause between two launches of the timed loop -- nor between the settle frames and the timed region
+    settle = 0
+    t_settle = time.perf_counter()
+    while settle < max(args.warmup, SETTLE_STEPS) or (time.perf_counter() - t_settle < SETTLE_SECONDS and settle < 20000):
+        step(1 + settle)
+        settle += 1
+    barrier()
+    pipe.mark_kernel_times()  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE (no wait) ...
     t_start = time.perf_counter()
     for i in range(args.steps):
         step(1 + settle + i)

@@ -406,6 +406,10 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_pipeline_kernel_times(self._h, 1 if mark else 0, ms, n))
         return list(ms), list(n)
 
+    def mark_kernel_times(self):
+        """start of a timed region: later kernel_times() calls sum the launches from here on (no wait, nothing read back)"""
+        L.check(self._lib.dust_hip_pipeline_kernel_times(self._h, 1, None, None))
+
     def tile_costs(self, pass_kind=0):
         """cycles per tile of the pass's last launch, shape (tiles_y, tiles_x); None before the first launch"""
         tx, ty = C.c_uint32(), C.c_uint32()

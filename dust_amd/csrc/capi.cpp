@@ -1385,7 +1385,6 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const Tuning& tune = p->tune;
   a.debug = tune.debug;
   for (const DustHipModel* m : s->models) a.deep |= m->dev.n_levels == 3 ? 1u : 0u;
-  if (tune.debug & 32u) a.deep = 0;  // DUST_HIP_DEBUG bit 32: 4096^3 models through the generic lookups of the two-level kernels
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;
   uint32_t bpc = tune.blocks_per_cu;
@@ -1554,6 +1553,10 @@ DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustH
 }
 DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline* p, int mark, float ms_sum[4], uint32_t launches[4]) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  if (mark && !ms_sum && !launches) {  // "from here": no wait, nothing read (a timed region starts right behind it)
+    for (int k = 0; k < 4; ++k) p->ev_mark[k] = p->ev_head[k];
+    return DUST_OK;
+  }
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   for (int k = 0; k < 4; ++k) {

@@ -413,7 +413,7 @@ __device__ __forceinline__ uint64_t find_brick(ModelRef m, int x, int y, int z, 
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
   if (k16 != mc.key) {
     uint32_t mid_index;
-    if (m.n_levels == 2) {
+    if (!DEEP || m.n_levels == 2) {  // (kernels of scenes without a 4096^3 model hold no three-level code at all)
       uint32_t idx = ((uint32_t)(x >> 4) << 8) | ((uint32_t)(y >> 4) << 4) | (uint32_t)(z >> 4);
       if (!n16_child(m.root, m.lds_slot, idx, mid_index)) { cell_log2 = 4; return 0; }
       if (COUNT && count) st.upper_descents += 1;
@@ -1207,39 +1207,48 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
     store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
-  InstanceRef in = a.instances[h.inst];
-  ModelRef m = a.models[in.model];
-  const uint32_t block = resolve_block(m, h.block);
-  const DustHipBlock b = load_block(m.blocks + block);
-  const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
-  const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
-  const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
-  const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
-  const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
-  const V3 nw = xform_dir(in.o2w, no);
-  if (store_illuminance) store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
-  const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
-  const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
-  const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
-  const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
-  const uint32_t pal = m.materials[b.material_ptr + voff];
-  const uint32_t col = m.palette[pal];
-  __builtin_nontemporal_store(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
-                                           div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
-  __builtin_nontemporal_store(h.t, &a.g.depth[pix]);
-  hitT = h.t;
-  normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
-  __builtin_nontemporal_store(normal_packed, &a.g.normal[pix]);
-  __builtin_nontemporal_store((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
-  const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
-  const V3 hpm = xform_point(in.w2o, hpw);
-  DUST_RO(float) P = in.prev;
-  const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
-  const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
-  const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
-  const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
-  const V3 hp = div3(mk(hx, hy, hz), hw);
-  store_half4(a.g.motion, pix, hp.x - hpw.x, hp.y - hpw.y, hp.z - hpw.z, 0.0f);
+  // Hit pixels. The instance and model records are read through SCALAR loads: the pixels of an 8x8 packet hit one or two
+  // instances, so the hit lanes are taken one distinct instance at a time (the first remaining lane's, wave-uniform through
+  // readfirstlane) -- 40 matrix floats and the model's pointers arrive in SGPRs instead of 50 VGPRs per lane.
+  bool todo = true;
+  while (todo) {
+    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.inst);
+    if (h.inst != cur) continue;
+    todo = false;
+    InstanceRef in = a.instances[cur];
+    ModelRef m = a.models[in.model];
+    const uint32_t block = resolve_block(m, h.block);
+    const DustHipBlock b = load_block(m.blocks + block);
+    const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
+    const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
+    const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
+    const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
+    const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
+    const V3 nw = xform_dir(in.o2w, no);
+    if (store_illuminance) store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
+    const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
+    const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
+    const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
+    const uint32_t pal = m.materials[b.material_ptr + voff];
+    const uint32_t col = m.palette[pal];
+    __builtin_nontemporal_store(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
+                                             div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
+    __builtin_nontemporal_store(h.t, &a.g.depth[pix]);
+    hitT = h.t;
+    normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
+    __builtin_nontemporal_store(normal_packed, &a.g.normal[pix]);
+    __builtin_nontemporal_store((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
+    const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
+    const V3 hpm = xform_point(in.w2o, hpw);
+    DUST_RO(float) P = in.prev;
+    const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
+    const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
+    const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
+    const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
+    const V3 hp = div3(mk(hx, hy, hz), hw);
+    store_half4(a.g.motion, pix, hp.x - hpw.x, hp.y - hpw.y, hp.z - hpw.z, 0.0f);
+  }
 }
 
 // ==================================================================== sun shadow + ambient occlusion

@@ -55,6 +55,7 @@ class StubPipe:
     def pass_stats(self, i):
         px = getattr(self, "px", 0)
         return Stats(rays=px if i < 4 else 100, hits=px // 2 if i < 4 else 50)
+    def mark_kernel_times(self): self.n_render = 0
     def kernel_times(self, mark=True):
         n = self.n_render
         self.n_render = 0
@@ -89,6 +90,7 @@ class StubBackend:
 args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", str(W), "--height", str(H),
                     "--workload", workload, "--no-cpu-baseline"])
 bench.SETTLE_STEPS = 2
+bench.SETTLE_SECONDS = 0.0
 be = StubBackend()
 out = bench.run_rank(args, be, dist)
 if rank == 0:
