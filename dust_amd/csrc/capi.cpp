@@ -174,7 +174,15 @@ struct DustHipContext : RefCounted {
   int num_cus = 256;
   size_t max_lds = 64 * 1024;
   DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
+  uint64_t sync_epoch = 1;  // bumped whenever the library has waited for the stream: what was enqueued before is done
 };
+// wait for everything enqueued on the context's stream (and remember that we did: scene commits recycle their pinned staging
+// slots by this, without an event per commit)
+static hipError_t sync_stream(DustHipContext* c) {
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) ++c->sync_epoch;
+  return e;
+}
 static void release(DustHipContext* c) {
   if (!c || c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   (void)hipSetDevice(c->device);
@@ -206,7 +214,7 @@ static void release(const DustHipModel* cm) {
   if (!m || m->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   DustHipContext* c = m->ctx;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);  // launches that read the arrays are done before they go
+  (void)sync_stream(c);  // launches that read the arrays are done before they go
   delete m;
   release(c);
 }
@@ -248,8 +256,8 @@ struct DustHipScene : RefCounted {
   DeviceBuffer image;
   SceneLayout layout;
   size_t image_capacity = 0;  // bytes
-  static constexpr int kStaging = 3;
-  struct Staging { void* host = nullptr; hipEvent_t copied = nullptr; bool in_flight = false; } staging[kStaging];
+  static constexpr int kStaging = 4;
+  struct Staging { void* host = nullptr; uint64_t epoch = 0; } staging[kStaging];  // epoch: the context's sync_epoch when the slot's copy was enqueued
   size_t staging_bytes = 0;
   uint32_t staging_next = 0;
   std::vector<uint8_t> master;   // host master copy of the image (dirty instances are re-derived in place)
@@ -259,10 +267,9 @@ struct DustHipScene : RefCounted {
   bool committed = false;
   const uint8_t* dev(size_t off) const { return static_cast<const uint8_t*>(image.p) + off; }
   void free_staging() {
-    for (Staging& st : staging) {
-      if (st.copied) { (void)hipEventSynchronize(st.copied); (void)hipEventDestroy(st.copied); st.copied = nullptr; }
+    for (Staging& st : staging) {  // (the caller has waited for the stream)
       if (st.host) { (void)hipHostFree(st.host); st.host = nullptr; }
-      st.in_flight = false;
+      st.epoch = 0;
     }
     staging_bytes = 0;
   }
@@ -726,7 +733,7 @@ void dust_hip_context_destroy(DustHipContext* c) { release(c); }  // (models, sc
 DustStatus dust_hip_sync(DustHipContext* c) {
   if (!c) return fail(DUST_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(sync_stream(c));
   return DUST_OK;
 }
 
@@ -911,7 +918,7 @@ DustStatus upload_batch(DustHipModel* m, const uint32_t* xyz, const int32_t* val
   EditState& e = *m->edit;
   if (n > e.batch_capacity) {
     const uint32_t cap = std::max(n, 1024u);
-    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(sync_stream(m->ctx));
     HIP_TRY(e.xyz.alloc(size_t(cap) * 12));
     HIP_TRY(e.values.alloc(size_t(cap) * 4));
     e.batch_capacity = cap;
@@ -973,7 +980,7 @@ DustStatus dust_hip_model_get_voxels(DustHipModel* m, const uint32_t* xyz, int32
     a.n_edits = n;
     HIP_TRY(dust::launch_edit_apply(a, true, m->ctx->stream));
     HIP_TRY(hipMemcpyAsync(values, m->edit->values.p, size_t(n) * 4, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(sync_stream(m->ctx));
     return DUST_OK;
   });
 }
@@ -1115,13 +1122,12 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       s->layout = SceneLayout::make(n, s->models.size(), s->n_lds_models);
       if (s->layout.total > s->image_capacity || !s->image.p) {
         // grow (rare: instances were added). Launches that read the old image are done before it goes.
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(sync_stream(s->ctx));
         s->free_staging();
         s->image_capacity = s->layout.total + s->layout.total / 2 + 4096;
         HIP_TRY(s->image.alloc(s->image_capacity));
         for (DustHipScene::Staging& sg : s->staging) {
           HIP_TRY(hipHostMalloc(&sg.host, s->image_capacity, hipHostMallocDefault));
-          HIP_TRY(hipEventCreateWithFlags(&sg.copied, hipEventDisableTiming));
         }
         s->staging_bytes = s->image_capacity;
       }
@@ -1147,12 +1153,13 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], di[i].wmin[a]); s->world_max[a] = std::max(s->world_max[a], di[i].wmax[a]); }
     // one asynchronous copy of the image, from the next pinned slot, behind whatever frame is in flight on the stream
     DustHipScene::Staging& sg = s->staging[s->staging_next++ % DustHipScene::kStaging];
-    if (sg.in_flight) { HIP_TRY(hipEventSynchronize(sg.copied)); sg.in_flight = false; }  // (three commits ago: long done)
+    // the copy that last read this slot was enqueued four commits ago: done if anything has waited for the stream since (a frame
+    // loop does, to read its result or pace itself) -- otherwise the host is four commits ahead of the GPU, and waits here
+    if (sg.epoch == s->ctx->sync_epoch) HIP_TRY(sync_stream(s->ctx));
     const size_t from = full ? 0 : s->layout.instances;  // transforms only: the models and roots already there stand
     std::memcpy(static_cast<uint8_t*>(sg.host) + from, img + from, s->layout.total - from);
     HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->image.p) + from, static_cast<uint8_t*>(sg.host) + from, s->layout.total - from, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(sg.copied, st));
-    sg.in_flight = true;
+    sg.epoch = s->ctx->sync_epoch;
     ++s->revision;
     s->structure_dirty = false;
     s->committed = true;
@@ -1214,7 +1221,7 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline* p, uint32_t texture, con
   if (!p || !texels || layers == 0 || (texture != 0 && texture != 5))
     return fail(DUST_ERR_INVALID_ARGUMENT, "noise texture must be 0 (scalar R8) or 5 (unitvec3_cosine RGBA8)");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));  // (frames that read the old texture are done before it is replaced)
+  HIP_TRY(sync_stream(p->ctx));  // (frames that read the old texture are done before it is replaced)
   const size_t bytes = size_t(128) * 128 * layers * (texture == 0 ? 1 : 4);
   if (texture == 0) { HIP_TRY(p->noise0.upload(texels, bytes, p->ctx->stream)); p->noise0_layers = layers; }
   else { HIP_TRY(p->noise5.upload(texels, bytes, p->ctx->stream)); p->noise5_layers = layers; }
@@ -1534,7 +1541,7 @@ DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustH
   if (!p || !out || pass > 5) return fail(DUST_ERR_INVALID_ARGUMENT, "bad pass index");
   std::memset(out, 0, sizeof(*out));
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   // pass 0: primary kernel; 1, 2: the two ray classes of the AO kernel (share its time); 3: final gather (+ surfel
   // commit); 4, 5: the two ray classes of the surfel pass (trace + apply kernels)
   const int kernel = pass == 0 ? 0 : (pass <= 2 ? 1 : (pass == 3 ? 2 : 3));
@@ -1558,7 +1565,7 @@ DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline* p, int mark, float ms
     return DUST_OK;
   }
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   for (int k = 0; k < 4; ++k) {
     double sum = 0.0;
     uint32_t n = 0;
@@ -1596,14 +1603,15 @@ DustStatus dust_hip_pipeline_read_plane(DustHipPipeline* p, DustHipPlane plane, 
   if (!p || !dst || int(plane) < 0 || plane >= DUST_PLANE_COUNT) return fail(DUST_ERR_INVALID_ARGUMENT, "bad plane");
   if (dst_bytes < p->planes[plane].bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   HIP_TRY(copy_wait(dst, p->plane(plane), p->planes[plane].bytes, hipMemcpyDeviceToHost, p->ctx->stream));
+  ++p->ctx->sync_epoch;  // (copy_wait waited for the stream)
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capacity, uint32_t surfel_pool_size) {
   if (!p || hash_capacity < 4 || surfel_pool_size == 0) return fail(DUST_ERR_INVALID_ARGUMENT, "bad GI configuration");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   const size_t hash_bytes = (size_t(hash_capacity) + 2) * 12;  // probes run up to 2 past the end (spatial_hash.glsl:154-158)
   HIP_TRY(p->gi_hash.alloc(hash_bytes));
   HIP_TRY(hipMemsetAsync(p->gi_hash.p, 0, hash_bytes, p->ctx->stream));             // standard.rs:348-358 relies on a zeroed allocation
@@ -1638,7 +1646,7 @@ DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_row
     if (gs != DUST_OK) return gs;
   }
   if (!p->gi_touched.p || p->gi_touched_rows != padded_rows) {
-    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    HIP_TRY(sync_stream(p->ctx));
     HIP_TRY(p->gi_touched.alloc(size_t(padded_rows) * p->width * 4));
     HIP_TRY(hipMemsetAsync(p->gi_touched.p, 0, size_t(padded_rows) * p->width * 4, p->ctx->stream));
     HIP_TRY(p->gi_merged.alloc(size_t(p->gi_pool_size) * 16));
@@ -1686,7 +1694,7 @@ DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* d
   const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
   if (dst_bytes < b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   HIP_TRY(copy_wait(dst, b.p, b.bytes, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
 }
@@ -1716,7 +1724,7 @@ DustStatus dust_hip_tone_map(DustHipPipeline* p, const DustHipToneMapParams* tp)
 DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, const float* set_to) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   float* avg = reinterpret_cast<float*>(static_cast<uint32_t*>(p->exposure.p) + 256);
   if (set_to) HIP_TRY(copy_wait(avg, set_to, 4, hipMemcpyHostToDevice, p->ctx->stream));
   if (avg_luminance) HIP_TRY(copy_wait(avg_luminance, avg, 4, hipMemcpyDeviceToHost, p->ctx->stream));
@@ -1772,7 +1780,7 @@ DustStatus dust_hip_pipeline_tile_costs(DustHipPipeline* p, uint32_t pass_kind, 
   if (!cycles || !h.measured) return DUST_OK;
   if (capacity < h.tiles_x * h.tiles_y) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  HIP_TRY(sync_stream(p->ctx));
   HIP_TRY(copy_wait(cycles, h.cost.p, size_t(h.tiles_x) * h.tiles_y * 4, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
 }

@@ -2,6 +2,10 @@
 // drive the Rust crates. Modes:
 //   cpu                      the crates/vdb doctests + a .vox load, no GPU needed
 //   gpu <file.vox> <w> <h> <noise5.bin> <sky.bin> <out_prefix>   offline frame like examples/castle.rs:105-236
+//   commit <file.vox> <w> <h> <noise5.bin> <sky.bin> <frames>   teapot_move_system (castle.rs:287-291): one instance moves every
+//                            frame, the TLAS is rebuilt inside the frame; prints the host time of set_transform + commit
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -114,9 +118,62 @@ static int gpu_frame(int argc, char** argv) {
   return 0;
 }
 
+// A frame loop with one moving instance: set_transform + commit + render per frame, nothing waits. What is timed is the host
+// side of dust_hip_scene_set_transform + dust_hip_scene_commit (the reference rebuilds its TLAS inside the frame's command
+// stream, tlas.rs:37-65; here: re-derive one instance record, one copy into pinned staging, one hipMemcpyAsync + event).
+static int commit_loop(int argc, char** argv) {
+  if (argc < 8) { std::fprintf(stderr, "usage: commit file.vox w h noise5.bin sky.bin frames\n"); return 2; }
+  const auto vox = slurp(argv[2]);
+  const uint32_t w = uint32_t(std::atoi(argv[3])), h = uint32_t(std::atoi(argv[4]));
+  const auto noise5 = slurp(argv[5]);
+  const auto skyb = slurp(argv[6]);
+  const int frames = std::atoi(argv[7]);
+  EXPECT(skyb.size() == sizeof(DustHipSky));
+  DustHipSky sky;
+  std::memcpy(&sky, skyb.data(), sizeof(sky));
+  dust::RenderContext ctx(0);
+  dust::VoxLoader loader(ctx);
+  dust::VoxScene assets = loader.load(vox.data(), vox.size());
+  dust::Scene scene(ctx);
+  scene.spawn_scene(assets);
+  scene.commit();
+  dust::StandardPipeline pipeline(ctx, w, h);
+  pipeline.set_blue_noise(5, noise5.data(), uint32_t(noise5.size() / (128 * 128 * 4)));
+  const double eye[3] = {122.0, 300.61, 54.45}, target[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+  const float eyef[3] = {float(eye[0]), float(eye[1]), float(eye[2])};
+  const DustHipCamera cam = dust::make_camera(eyef, dust::look_at_rotation(eye, target, up), dust::PinholeProjection{});
+  float base[12];
+  std::memcpy(base, assets.instances[0].obj_to_world, sizeof base);
+  double commit_s = 0.0, frame_s = 0.0;
+  const auto t_all = std::chrono::steady_clock::now();
+  for (int f = 0; f < frames; ++f) {
+    // frame f goes to the GPU (~0.25 ms of work) ...
+    const auto t1 = std::chrono::steady_clock::now();
+    EXPECT(pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, uint32_t(1 + f), 4242u + uint32_t(f)));
+    const auto t2 = std::chrono::steady_clock::now();
+    // ... and while it runs, the host moves the instance for frame f + 1 and commits: this must not wait for the frame
+    float m[12];
+    std::memcpy(m, base, sizeof m);
+    m[7] = base[7] + 20.0f * std::sin(0.1f * float(f));  // up and down, like the teapot
+    const auto t3 = std::chrono::steady_clock::now();
+    scene.set_transform(0, m);
+    scene.commit();
+    const auto t4 = std::chrono::steady_clock::now();
+    commit_s += std::chrono::duration<double>(t4 - t3).count();
+    frame_s += std::chrono::duration<double>(t2 - t1).count();
+    if ((f & 1) == 1) ctx.sync();  // pace the loop (two frames in flight at most): an unpaced host outruns the GPU and then waits for queue space
+  }
+  ctx.sync();
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
+  std::printf("commit loop: %d frames, %zu instances; set_transform + commit %.2f us per frame (host), render call %.2f us (host), %.3f ms per frame wall\n",
+              frames, assets.instances.size(), 1e6 * commit_s / frames, 1e6 * frame_s / frames, 1e3 * wall / frames);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   try {
     if (argc >= 2 && std::string(argv[1]) == "gpu") return gpu_frame(argc, argv);
+    if (argc >= 2 && std::string(argv[1]) == "commit") return commit_loop(argc, argv);
     return cpu_tests();
   } catch (const dust::Error& e) {
     std::fprintf(stderr, "dust::Error %d: %s\n", int(e.status), e.what());

@@ -56,6 +56,25 @@ def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path):
     assert np.array_equal(ill, pipe.read_plane(L.PLANE_ILLUMINANCE))
 
 
+@pytest.mark.gpu
+def test_moving_instance_commits_do_not_stall_the_host(exe, tmp_path):
+    """castle.rs:287-291 moves the teapot every frame and tlas.rs:37-65 rebuilds the TLAS in the frame's command stream. Here:
+    dust_hip_scene_set_transform + dust_hip_scene_commit from C++, 300 frames of the full-size castle with a frame in flight --
+    the pair must cost microseconds of host time (it used to be a flush, a stream wait and five hipFree/hipMalloc/hipMemcpy)."""
+    import parity_util as P
+    from dust_amd import synth
+    data, _ = synth.castle_scene()
+    (tmp_path / "castle.vox").write_bytes(data)
+    (tmp_path / "noise5.bin").write_bytes(synth.stbn_unitvec3_cosine(layers=2).tobytes())
+    (tmp_path / "sky.bin").write_bytes(P.sky_state().astype(np.float32).tobytes())
+    out = subprocess.run([exe, "commit", str(tmp_path / "castle.vox"), "1920", "1080", str(tmp_path / "noise5.bin"), str(tmp_path / "sky.bin"), "300"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    print(out.stdout.strip())
+    us = float(out.stdout.split("set_transform + commit")[1].split("us")[0])
+    assert us < 60.0, out.stdout   # measured ~10 us; the old path was ~300 us + a stream wait
+
+
 def test_shared_reciprocal_division_is_ieee_division():
     """kernels.hip div_by (Markstein's sequence on an exactly rounded reciprocal) == IEEE a / b, bit for bit."""
     src = os.path.join(ROOT, "tests", "cpp", "division_identity_test.c")
