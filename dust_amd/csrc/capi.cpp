@@ -26,7 +26,8 @@ namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
+hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t);
+uint32_t final_gather_pool_group();
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs& a, hipStream_t);
@@ -298,6 +299,8 @@ struct Tuning {
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
+  bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
+                                // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
   static uint32_t num(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
@@ -313,6 +316,7 @@ struct Tuning {
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
+    t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
     return t;
   }
 };
@@ -1466,20 +1470,23 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     dust::FrameArgs g = a;
     uint32_t ggrid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
+    bool pool = false;
     if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
       const uint32_t otx = (p->width + 63) / 64, oty = (a.row_end - a.row_begin + 63) / 64;
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
-      g.tiles_x = otx * oty * 64;  // 64 packets of 64 per tile, the empty ones skipped by the kernel
+      pool = tune.ray_lanes;
+      // work items: 64 packets of 64 per tile -- or, as ray lanes, 4096 / group items of `group` entries --, the empty ones skipped by the kernel
+      g.tiles_x = otx * oty * (pool ? 4096u / dust::final_gather_pool_group() : 64u);
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
-    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
+    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, pool, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {

@@ -199,6 +199,15 @@ __device__ __forceinline__ u32x2 pack_radiance(V3 r, float hitdist) {  // nrd.gl
 __device__ __forceinline__ void store_radiance(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {
   __builtin_nontemporal_store(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
 }
+// the same texel from a lane whose neighbours hold unrelated pixels (regrouped gather rays): an ordinary store, so that the
+// 8-byte pieces of a line meet in L2 -- a tile's packets run at about the same time on one XCD -- instead of going out one by one
+__device__ __forceinline__ void store_radiance_scattered(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {
+#ifdef DUST_NT_GATHER
+  __builtin_nontemporal_store(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
+#else
+  *(DUST_GLOBAL_AS u32x2*)(plane + pix * 4) = pack_radiance(r, hitdist);
+#endif
+}
 __device__ __forceinline__ V3 decode_radiance(u32x2 v, float& w);
 __device__ __forceinline__ V3 load_radiance(DUST_RW(uint16_t) plane, size_t pix, float& w) {  // a G-buffer plane
   return decode_radiance(*(const DUST_GLOBAL_AS u32x2*)(plane + pix * 4), w);
@@ -407,8 +416,8 @@ __device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, u
 // which orders bricks exactly like the block index does (both are depth-first).
 // One dependent memory access per call: root in LDS -> mid index -> dense_mask[mid*64 + bit].
 // ray (DEEP variants): the object-space ray o + t d with inv_d = 1 / d, for the occupied-box test of a 16-cell
-template <int MODE>
-__device__ __forceinline__ uint64_t find_brick(ModelRef m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
+template <int MODE, class Model>
+__device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
                                                MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d) {
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
   if (k16 != mc.key) {
@@ -954,6 +963,284 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
   PROF_LEAVE(P_TRACE_RAY);
 }
 
+// ------------------------------------------------------------------ incoherent rays: 64 independent ray lanes per wavefront
+// A packet of gather or surfel rays lasts as long as its longest ray: 15 loop trips for rays that need 2.9 on average, 19 %
+// of the lanes active inside the walk (round 2). Here a wavefront is 64 LANES that each carry one ray through a small state
+// machine -- fetch a ray, scan the candidate list, pop the nearest candidate and enter it, walk one cell per step, shade --
+// and every trip of the wave's loop runs the ONE phase most of its lanes are waiting in (ballot + popcount per state). A lane
+// whose ray is finished is shaded and refilled with the NEXT ray of the wave's work item while its neighbours walk on, so a
+// phase never runs for a handful of lanes while the rest idle, and the item's cull is shared by several packets' worth of rays.
+// What a ray computes is what trace_ray / trace_instance compute for it (walk_begin + walk_step are trace_instance's prologue
+// and loop body, verbatim); only which rays share a wavefront when changes -- never a result
+// (test_gi_does_not_depend_on_visiting_order_or_grouping runs both paths).
+#ifdef DUST_POOL_STATS
+__device__ unsigned long long g_pool_stats[16];  // per phase: trips, lanes served (experiment builds only)
+#endif
+struct WalkState {          // one lane's visit of one instance
+  V3 o, d, inv;             // object-space ray, inv = 1 / d (IEEE division: the intersection shader's reciprocal)
+  float t, tx_stop, near_tol;
+  int ijk[3];
+  uint32_t stepped, cl_main, steps;
+  bool screen;
+  MidCache mc;
+  uint32_t inst;
+  // what a step of a two-level model reads of its record, taken along when the visit starts (a lane's model is its own: read
+  // from the record at every step, these would be vector loads in front of the step's one dependent access)
+  int32_t lds_slot;
+  uint32_t extent;
+  DUST_RO(uint8_t) root;
+  DUST_RO(uint64_t) dense_mask;
+};
+struct ModelLite {  // the two-level part of a DevModel, as find_brick reads it
+  DUST_RO(uint8_t) root;
+  DUST_RO(uint64_t) dense_mask;
+  int32_t lds_slot;
+  static constexpr uint32_t n_levels = 2;
+  DUST_RO(uint8_t) l2;
+  DUST_RO(DevL2Cell) l2_cells;
+};
+// trace_instance's prologue: false when the ray misses the model's bounds
+template <int RT, int MODE>
+__device__ __forceinline__ bool walk_begin(WalkState& w, ModelRef m, uint32_t inst, V3 o, V3 d, float tmin) {
+  w.o = o; w.d = d; w.inst = inst;
+  w.lds_slot = m.lds_slot; w.extent = m.extent; w.root = m.root; w.dense_mask = m.dense_mask;
+  w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  float te, tx;
+  if (!slab_box(o, d, w.inv, m.bmin, m.bmax, te, tx)) return false;
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  float t = fmaxf(te, 0.0f);
+  if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
+  float reach = 0.0f;
+  bool screen = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = oo[a] + dd[a] * t;
+    w.ijk[a] = f2i_clamp(dd[a] < 0.0f ? ceilf(p) - 1.0f : floorf(p), (int)m.bmin[a], (int)m.bmax[a] - 1);
+    reach = fmaxf(reach, fabsf(oo[a]) + fmaxf(fabsf(p), fabsf(oo[a] + dd[a] * tx)));
+  }
+  w.near_tol = 3.0e-7f * (reach + 16.0f);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int b0 = w.ijk[a] & ~3, blo = (int)m.bmin[a], bhi = (int)m.bmax[a] - 1;
+    const float q = (oo[a] + dd[a] * t) - (float)b0;
+    screen = screen | ((q <= 4.0f * w.near_tol) & (b0 - 1 >= blo)) | ((q >= 4.0f - 4.0f * w.near_tol) & (b0 + 4 <= bhi));
+  }
+  w.t = t; w.screen = screen; w.stepped = 0; w.cl_main = 2; w.steps = 0;
+  w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0;
+  w.tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
+  return true;
+}
+// trace_instance's loop body: one cell. Returns true when the visit is over.
+template <int RT, int MODE>
+__device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevModel* mp, float tmin, float tmax, bool any_hit, Hit& best, LaneStats& st) {
+  {
+    const float limit = best.found ? best.t : tmax;
+    if (w.t * (1.0f - 2e-6f) > limit) return true;
+    if (any_hit && best.found) return true;
+    if (++w.steps > 200000u) return true;
+  }
+  const float oo[3] = {w.o.x, w.o.y, w.o.z}, dd[3] = {w.d.x, w.d.y, w.d.z}, inv[3] = {w.inv.x, w.inv.y, w.inv.z};
+  const int E = (int)w.extent;
+  uint32_t key;
+  uint64_t mask;
+  if (DEEP) {
+    mask = find_brick<MODE>(*mp, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv);
+  } else {
+    ModelLite lm;
+    lm.root = w.root; lm.dense_mask = w.dense_mask; lm.lds_slot = w.lds_slot; lm.l2 = nullptr; lm.l2_cells = nullptr;
+    mask = find_brick<MODE>(lm, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv);
+  }
+  if (DEEP && __builtin_expect(w.screen, 0) && w.cl_main >= 4u) {
+    bool s16 = __popc(w.stepped) > 1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      if (!(w.stepped & (1u << a))) {
+        const float r = (oo[a] + dd[a] * w.t) * 0.0625f;
+        s16 = s16 | (fabsf(r - rintf(r)) <= w.near_tol * 0.25f);
+      }
+    w.screen = s16;
+  }
+  const int S = 1 << w.cl_main;
+  float ta[3], tn = INFINITY;
+  int cc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    cc[a] = w.ijk[a] & ~(S - 1);
+    if (dd[a] != 0.0f) {
+      const float plane = (float)(dd[a] > 0.0f ? cc[a] + S : cc[a]);
+      ta[a] = (plane - oo[a]) * inv[a];
+    } else {
+      ta[a] = INFINITY;
+    }
+    tn = fminf(tn, ta[a]);
+  }
+  const bool stuck = !(tn < INFINITY);
+  uint32_t next_stepped = 0;
+  int next_ijk[3];
+  bool outside = false, next_screen = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (ta[a] == tn) {
+      next_stepped |= 1u << a;
+      next_ijk[a] = dd[a] > 0.0f ? cc[a] + S : cc[a] - 1;
+      if (next_ijk[a] < 0 || next_ijk[a] >= E) outside = true;
+    } else {
+      const float p = oo[a] + dd[a] * tn;
+      next_ijk[a] = f2i_clamp(floorf(p), cc[a], cc[a] + S - 1);
+      const float r = p * 0.25f;
+      next_screen = next_screen | (fabsf(r - rintf(r)) <= w.near_tol);
+    }
+  }
+  next_screen = next_screen | (__popc(next_stepped) > 1);
+  if (mask != 0) test_brick<RT, MODE>(mask, w.inst, key, w.ijk[0] & ~3, w.ijk[1] & ~3, w.ijk[2] & ~3, w.o, w.d, w.inv, tmin, tmax, best, st);
+  if (__builtin_expect(w.screen, 0)) {
+    const u32x8 nv = visit_neighbours<RT, MODE>(mp, w.inst, w.o.x, w.o.y, w.o.z, w.d.x, w.d.y, w.d.z, w.inv.x, w.inv.y, w.inv.z, tmin, tmax, w.t,
+                                                 w.ijk[0], w.ijk[1], w.ijk[2], w.stepped, best.t, best.inst, best.block, best.voxel,
+                                                 best.found ? 1u : 0u, w.mc.key, w.mc.mid, w.cl_main,
+                                                 DEEP ? (uint32_t)w.mc.mask4 : 0u, DEEP ? (uint32_t)(w.mc.mask4 >> 32) : 0u);
+    best.t = __uint_as_float(nv[0]); best.inst = nv[1]; best.block = nv[2]; best.voxel = nv[3]; best.found = nv[4] != 0;
+    w.mc.key = (int)nv[5]; w.mc.mid = nv[6];
+    if (COUNT) st.bricks_tested += nv[7];
+  }
+  if (stuck || outside) return true;
+  w.ijk[0] = next_ijk[0]; w.ijk[1] = next_ijk[1]; w.ijk[2] = next_ijk[2];
+  w.stepped = next_stepped;
+  w.screen = next_screen;
+  w.t = fmaxf(w.t, tn);
+  return w.t * (1.0f - 2e-6f) > w.tx_stop;
+}
+
+// The ray source of a work item: entries [begin, end) of some list. fetch() turns an entry into a ray (false: nothing to
+// trace for it, and nothing to shade); shade() consumes the finished ray. Both run on whatever lanes the scheduler hands them.
+enum : uint32_t { LS_IDLE = 0, LS_SCAN, LS_POP, LS_WALK, LS_DONE };
+constexpr uint32_t kScanBatch = 32;  // candidates per scan: one mask word per lane
+#ifndef DUST_REFILL_LANES
+#define DUST_REFILL_LANES 32
+#endif
+constexpr uint32_t kRefillLanes = DUST_REFILL_LANES;  // finished + empty lanes at which a wave stops tracing to shade and refill
+template <int RT, int MODE, class Src>
+__device__ void trace_pool(ArgsRef a_in, Src& src, uint32_t begin, uint32_t end, const uint32_t* cand, uint32_t ncand,
+                           float tmin, float tmax, bool any_hit, LaneStats& st) {
+  ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
+  begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)begin);
+  end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t lower = (1ull << lane) - 1ull;
+  uint32_t next = begin;
+  uint32_t state = LS_IDLE, idx = 0;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv_w = mk(0, 0, 0);
+  float t_scene = INFINITY;
+  uint32_t base = 0, mask = 0;
+  Hit best;
+  best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
+  WalkState w;
+  w.o = w.d = w.inv = mk(0, 0, 0); w.t = w.tx_stop = w.near_tol = 0.0f; w.ijk[0] = w.ijk[1] = w.ijk[2] = 0;
+  w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0; w.inst = 0;
+  for (;;) {
+    const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == LS_WALK)), n_pop = (uint32_t)__popcll(__ballot(state == LS_POP));
+    const uint32_t n_scan = (uint32_t)__popcll(__ballot(state == LS_SCAN)), n_done = (uint32_t)__popcll(__ballot(state == LS_DONE));
+    const uint64_t b_idle = __ballot(state == LS_IDLE);
+    const uint32_t n_fetch = min((uint32_t)__popcll(b_idle), end - next);
+    // Which phase runs this trip. Tracing first: of walk / pop / scan the one with the most lanes waiting (ties go to the
+    // walk, then to what feeds it). Finished rays are shaded -- and their lanes refilled -- only when that buys something:
+    // when half the wave is waiting for it and the item has rays left to hand out, or when nothing is left to trace
+    // (shading is the most expensive phase per trip, and it is as cheap for 64 lanes as for 6).
+    uint32_t pick = LS_WALK, most = n_walk;
+    if (n_pop > most) { pick = LS_POP; most = n_pop; }
+    if (n_scan > most) { pick = LS_SCAN; most = n_scan; }
+    const uint32_t n_free = n_done + (uint32_t)__popcll(b_idle);
+    if (most == 0u || (next < end && n_free >= kRefillLanes)) {
+      if (n_done) { pick = LS_DONE; most = n_done; }
+      else if (n_fetch) { pick = LS_IDLE; most = n_fetch; }
+    }
+    if (most == 0u) break;
+#ifdef DUST_POOL_STATS
+    if (lane == 0) { atomicAdd(&g_pool_stats[pick * 2], 1ull); atomicAdd(&g_pool_stats[pick * 2 + 1], (unsigned long long)most); }
+#endif
+    ArgsRef a = reload_args(a_in);
+    if (pick == LS_WALK) {
+      if (state == LS_WALK) {
+        const DUST_CONST_AS DevVisit& v = a.visits[w.inst];
+        if (walk_step<RT, MODE>(w, &v.m, tmin, tmax, any_hit, best, st)) state = LS_POP;
+      }
+    } else if (pick == LS_POP) {
+      if (state == LS_POP) {
+        // the lane's nearest remaining candidate of this batch, unless the ray is settled in front of it
+        uint32_t mine = 0xFFFFFFFFu;
+        if (mask != 0u) {
+          const uint32_t c = cand[base + (uint32_t)__builtin_ctz(mask)];
+          mask &= mask - 1u;
+          const float t_lo = __uint_as_float(c & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
+          if ((best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo) { mask = 0u; base = ncand; }
+          else mine = c & 0xFFFFu;
+        }
+        if (mine != 0xFFFFFFFFu) {
+          if (COUNT) st.instances_tested += 1;
+          const DUST_CONST_AS DevVisit& v = a.visits[mine];
+          if (walk_begin<RT, MODE>(w, v.m, mine, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin)) state = LS_WALK;
+        } else if (mask == 0u) {
+          state = LS_DONE;
+          if (base + kScanBatch < ncand) {  // sorted by earliest entry: a ray settled in front of the next batch's first candidate is done
+            const float t_lo = __uint_as_float(cand[base + kScanBatch] & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
+            if (!((best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo)) { base += kScanBatch; state = LS_SCAN; }
+          }
+        }
+      }
+    } else if (pick == LS_SCAN) {
+      // one batch of the candidate list against the rays of the lanes that wait for it: the lowest such batch first (a
+      // uniform loop over its boxes -- scalar loads -- with one slab test per lane and box)
+      uint32_t b = state == LS_SCAN ? base : 0xFFFFFFFFu;
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, sh));
+      b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+      const bool me = state == LS_SCAN && base == b;
+      const uint32_t cnt = ncand - b < kScanBatch ? ncand - b : kScanBatch;
+      const bool zero_axis = __any(me && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));
+      uint32_t found = 0;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[b + k]) & 0xFFFFu;
+        const DUST_CONST_AS DevBox& bx = a.boxes[ii];
+        float lo[3], hi[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { lo[q] = bx.lo[q]; hi[q] = bx.hi[q]; }
+        float te, tx;
+        const bool box = zero_axis ? slab_box(o, d, inv_w, lo, hi, te, tx) : slab_box_nonzero(o, inv_w, lo, hi, te, tx);
+        found |= box ? 1u << k : 0u;
+      }
+      if (me) { mask = found; state = LS_POP; }
+    } else if (pick == LS_DONE) {
+      if (state == LS_DONE) {
+        if (COUNT && best.found) st.hits += 1;
+        src.shade(a, idx, o, d, best);
+        state = LS_IDLE;
+      }
+    } else {  // fetch: the idle lanes take the item's next entries, in lane order
+      const uint32_t rank = (uint32_t)__popcll(b_idle & lower);
+      const bool take = state == LS_IDLE && next + rank < end;
+      if (take) {
+        idx = next + rank;
+        best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
+        if (src.fetch(a, idx, o, d)) {
+          if (COUNT) st.rays += 1;
+          // world-space reciprocals feed only the conservative box tests (1e-5 slack): v_rcp_f32's 1 ulp is enough
+          inv_w = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+          t_scene = INFINITY;
+          if (ncand > 8u) {  // when the ray leaves the union of all instance boxes (lets sky-bound rays stop early)
+            float te_s, tx_s;
+            const bool in = slab_box(o, d, inv_w, a.world_min, a.world_max, te_s, tx_s);
+            t_scene = in ? tx_s * (1.0f + 1e-5f) + 1e-3f : -1.0f;
+          }
+          base = 0; mask = 0;
+          state = ncand ? LS_SCAN : LS_DONE;
+        } else {
+          src.skip(a, idx);  // (an entry without a ray: whatever its slot must hold is written now)
+        }
+      }
+      next = min(end, next + (uint32_t)__popcll(b_idle));
+    }
+  }
+}
+
 // ------------------------------------------------------------------ work distribution
 struct Packet {
   uint32_t px, py;
@@ -1347,6 +1634,9 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
 // wave that traced a packet's primary rays goes straight on to its shadow and AO rays with depth and normal still
 // in registers (as the quantised values the separate pass would load back). One launch, one LDS staging and one
 // work queue instead of two; the G-buffer contents are bit-identical to running the two kernels.
+#ifndef DUST_POOL_GROUP
+#define DUST_POOL_GROUP 256  // entries per work item of the ray-lane kernels (k_final_gather_pool, k_surfel_trace_pool)
+#endif
 #ifndef DUST_PAO_THREADS
 #define DUST_PAO_THREADS 512
 #define DUST_PAO_WAVES 4
@@ -1660,7 +1950,56 @@ __global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs)
   if (threadIdx.x == 0) a.gi.order_count[tile] = grand_total;
 }
 
-// final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24
+// final_gather.rchit:35-91 / final_gather.rmiss:12-24 for one finished gather ray of pixel (px, py)
+__device__ __forceinline__ void gather_shade(ArgsRef ar, uint32_t px, uint32_t py, V3 inval, V3 loc, V3 ad, const Hit& h) {
+  const size_t pix = (size_t)py * ar.width + px;
+  if (!h.found) {
+    const V3 sk = sky_radiance(ar.sky, normalize3(ad));
+    store_radiance_scattered(ar.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
+    return;
+  }
+  HashKey key;
+  DevSurfel sf;
+  uint32_t alb;
+  brick_surfel(ar, h, loc, ad, key, sf, alb);
+  V3 rad;
+  uint32_t count;
+  uint32_t entry;
+  hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+  if (ar.gi.touched) ar.gi.touched[px + py * ar.width] = entry;  // multi-GPU: the other ranks repeat this stamp
+  const float prob = 1.0f / (float)(count + 2u);
+  const float noise = div_const((float)ar.noise0[((py + 21u + ar.rand) % 128u) * 128u + ((px + 34u + ar.rand) % 128u)], 255.0f);
+  if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
+    const uint32_t index = px + py * ar.width;
+    ar.gi.pixel_surfel[index] = sf;
+    atomicMax(&ar.gi.slot_owner[index % ar.gi.pool_size], index + 1u);
+  }
+  rad = modulate_by_avg_albedo(rad, alb);
+  store_radiance_scattered(ar.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
+}
+// one packet of gather rays, start to finish, with a cull of its own (final_gather.rgen:14-52 + rough.rint)
+template <int MODE>
+__device__ __forceinline__ void gather_packet(ArgsRef a0, uint32_t px, uint32_t py, bool valid, uint32_t* cand, LaneStats& st) {
+  ArgsRef a = reload_args(a0);
+  V3 inval, loc, ad;
+  const bool live = gather_ray(a, px, py, valid, inval, loc, ad);
+#ifdef DUST_TRACE_DEBUG
+  {
+    const size_t pix = valid ? (size_t)py * a.width + px : 0;
+    const unsigned long long m = __ballot(valid && (uint32_t)pix + 1u == (a.debug >> 12));
+    if ((threadIdx.x & 63u) == 0) g_dbg_mask[threadIdx.x >> 6] = m;
+    __builtin_amdgcn_wave_barrier();
+    DBG_PRINT("FG pixel %u,%u live=%d o=%.9g,%.9g,%.9g d=%.9g,%.9g,%.9g\n", px, py, (int)live, loc.x, loc.y, loc.z, ad.x, ad.y, ad.z);
+  }
+#endif
+  Hit h;
+  const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
+  trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
+  __builtin_amdgcn_wave_barrier();
+  if (live) gather_shade(reload_args(a0), px, py, inval, loc, ad, h);
+}
+
+// final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24, a packet at a time
 template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
   ArgsRef a0 = launch_args();
@@ -1680,46 +2019,83 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
       p.px = pixel % a.width;
       p.py = pixel / a.width;
     }
-    const size_t pix = p.valid ? (size_t)p.py * a.width + p.px : 0;
-    V3 inval, loc, ad;
-    const bool live = gather_ray(a, p.px, p.py, p.valid, inval, loc, ad);
-#ifdef DUST_TRACE_DEBUG
-    {
-      const unsigned long long m = __ballot(p.valid && (uint32_t)pix + 1u == (a.debug >> 12));
-      if ((threadIdx.x & 63u) == 0) g_dbg_mask[threadIdx.x >> 6] = m;
-      __builtin_amdgcn_wave_barrier();
-      DBG_PRINT("FG pixel %u,%u live=%d o=%.9g,%.9g,%.9g d=%.9g,%.9g,%.9g\n", p.px, p.py, (int)live, loc.x, loc.y, loc.z, ad.x, ad.y, ad.z);
+    gather_packet<MODE>(a0, p.px, p.py, p.valid, cand, st);
+  }
+  prof_end();
+  flush_stats<MODE>(a0, 0, st);
+}
+
+// The same pass over ray lanes (trace_pool): a work item is kPoolGroup consecutive entries of a tile's direction-ordered list --
+// several packets' worth of rays that share one cull and are streamed through the wave's 64 lanes.
+constexpr uint32_t kPoolGroup = DUST_POOL_GROUP;
+struct GatherSource {
+  uint32_t tile;
+  __device__ __forceinline__ void pixel_of(ArgsRef a, uint32_t idx, uint32_t& px, uint32_t& py) const {
+    const uint32_t pixel = a.gi.order[(size_t)tile * kOrderSlots + idx];
+    py = pixel / a.width;
+    px = pixel - py * a.width;
+  }
+  __device__ __forceinline__ bool fetch(ArgsRef a, uint32_t idx, V3& o, V3& d) const {
+    uint32_t px, py;
+    pixel_of(a, idx, px, py);
+    V3 inval;
+    return gather_ray(a, px, py, true, inval, o, d);
+  }
+  __device__ __forceinline__ void skip(ArgsRef, uint32_t) const {}
+  __device__ __forceinline__ void shade(ArgsRef a, uint32_t idx, V3 o, V3 d, const Hit& h) const {
+    uint32_t px, py;
+    pixel_of(a, idx, px, py);
+    float w;
+    const V3 inval = load_radiance(a.g.illuminance, (size_t)py * a.width + px, w);  // (what gather_ray read when the ray was made)
+    gather_shade(a, px, py, inval, o, d, h);
+  }
+};
+__device__ __forceinline__ void merge_range(Range3& r, const Range3& q) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(r.lo[k], q.lo[k]); r.hi[k] = fmaxf(r.hi[k], q.hi[k]); }
+}
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_final_gather_pool(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = cursor_begin();
+  Packet p;
+  const uint32_t lane = threadIdx.x & 63u;
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);
+    constexpr uint32_t kGroups = kOrderSlots / kPoolGroup;
+    const uint32_t id = p.px >> 3, tile = id / kGroups, begin = (id % kGroups) * kPoolGroup;
+    const uint32_t n = a.gi.order_count[tile];
+    if (begin >= n) continue;  // this tile has fewer live pixels
+    const uint32_t end = n < begin + kPoolGroup ? n : begin + kPoolGroup;
+    GatherSource src;
+    src.tile = tile;
+    // the item's ray bundle: one pass over its entries, a packet at a time (the rays themselves are made again when a lane
+    // takes them: six floats apiece are cheaper to recompute than to park)
+    Range3 org, dir;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { org.lo[k] = dir.lo[k] = INFINITY; org.hi[k] = dir.hi[k] = -INFINITY; }
+    bool any = false;
+    for (uint32_t j = begin; j < end; j += 64u) {
+      V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+      const bool live = j + lane < end && src.fetch(a, j + lane, o, d);
+      merge_range(org, wave_range(live, o));
+      merge_range(dir, wave_range(live, d));
+      any = any | (__any(live) != 0);
     }
-#endif
-    Hit h;
-    const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
-    trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
-    __builtin_amdgcn_wave_barrier();
-    ArgsRef ar = reload_args(a0);
-    if (!live) continue;
-    if (!h.found) {
-      const V3 sk = sky_radiance(ar.sky, normalize3(ad));
-      store_radiance(ar.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
+    const uint32_t ncand = cull_instances(a, any, org, dir, a.cam.far_, cand);
+    if (ncand > kMaxCand || (a.debug & 12u)) {  // the list overflowed (or a debug order was asked for): packets, each with its own cull
+      for (uint32_t j = begin; j < end; j += 64u) {
+        uint32_t px = 0, py = 0;
+        const bool valid = j + lane < end;
+        if (valid) src.pixel_of(a, j + lane, px, py);
+        gather_packet<MODE>(a0, px, py, valid, cand, st);
+      }
       continue;
     }
-    HashKey key;
-    DevSurfel sf;
-    uint32_t alb;
-    brick_surfel(ar, h, loc, ad, key, sf, alb);
-    V3 rad;
-    uint32_t count;
-    uint32_t entry;
-    hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
-    if (ar.gi.touched) ar.gi.touched[p.px + p.py * ar.width] = entry;  // multi-GPU: the other ranks repeat this stamp
-    const float prob = 1.0f / (float)(count + 2u);
-    const float noise = div_const((float)ar.noise0[((p.py + 21u + ar.rand) % 128u) * 128u + ((p.px + 34u + ar.rand) % 128u)], 255.0f);
-    if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
-      const uint32_t index = p.px + p.py * ar.width;
-      ar.gi.pixel_surfel[index] = sf;
-      atomicMax(&ar.gi.slot_owner[index % ar.gi.pool_size], index + 1u);
-    }
-    rad = modulate_by_avg_albedo(rad, alb);
-    store_radiance(ar.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
+    trace_pool<2, MODE>(a, src, begin, end, cand, ncand, 8.0f, a.cam.far_, false, st);
   }
   prof_end();
   flush_stats<MODE>(a0, 0, st);
@@ -2422,9 +2798,11 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
   hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderThreads), 0, s, a);
   return hipGetLastError();
 }
-hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
+uint32_t final_gather_pool_group() { return kPoolGroup; }
+hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t s) {
   const size_t lds = lds_bytes(a_in, block);
-  DUST_LAUNCH_MODE(k_final_gather, count, a_in);
+  if (pool) DUST_LAUNCH_MODE(k_final_gather_pool, count, a_in);
+  else DUST_LAUNCH_MODE(k_final_gather, count, a_in);
   if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a_in);
   return hipGetLastError();
 }
@@ -2463,6 +2841,7 @@ hipError_t configure_kernels(size_t max_lds) {
       (const void*)k_ambient_occlusion<0>, (const void*)k_ambient_occlusion<1>, (const void*)k_ambient_occlusion<2>, (const void*)k_ambient_occlusion<3>,
       (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>,
       (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
+      (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>,
       (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>};
   for (const void* f : fns) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
@@ -2473,6 +2852,15 @@ hipError_t configure_kernels(size_t max_lds) {
 
 }  // namespace dust
 
+#ifdef DUST_POOL_STATS
+extern "C" int dust_hip_pool_stats(unsigned long long* out) {
+  unsigned long long h[16] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dust::g_pool_stats), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out[i] = h[i];
+  unsigned long long z[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_pool_stats), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef DUST_PROFILE
 // profiling build only (tools/kernel_sections.py): read and clear the section cycle counters
 extern "C" int dust_hip_profile_read(unsigned long long* out, int n) {

@@ -116,7 +116,7 @@ def test_surfel_position_sort_only_regroups(monkeypatch):
 
 
 _SWITCHES = ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
-             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU")
+             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RAY_LANES")
 
 
 def _castle_gi_states(monkeypatch, settings, frames=3):
@@ -154,12 +154,15 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4; every lane on its own instance vs the whole
     wave on one, bit 8) nor of which rays share a wavefront
     (octant-ordered gather packets, position-ordered surfels), which wave traces which tile when (cost-ordered hand-out), where
-    the cull reads its boxes from, or the launch shape. Caught a build whose out-of-line neighbour visit passed the
+    the cull reads its boxes from, the launch shape, or whether gather rays run a packet at a time or as refilled ray lanes
+    (DUST_HIP_RAY_LANES: a lane shades its finished ray and takes the work item's next one while its neighbours walk on).
+    Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
     _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
                                                        {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
-                                                       {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"}],
+                                                       {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"},
+                                                       {"DUST_HIP_RAY_LANES": "1"}, {"DUST_HIP_RAY_LANES": "1", "DUST_HIP_DEBUG": "4"}],
                                           frames=5)
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:

@@ -34,3 +34,12 @@ ctx.sync()
 ms, n = pipe.kernel_times(mark=True)
 names = ("primary(+ao)", "ao", "gather", "surfel")
 print(label or os.environ.get("DUST_HIP_LIB", "default"), " ".join(f"{names[k]} {ms[k] / n[k]:.4f}" for k in range(4) if n[k]), flush=True)
+try:
+    import ctypes
+    lib = L.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    if lib.dust_hip_pool_stats(buf) == 0:
+        names = ["fetch", "scan", "pop", "walk", "done"]
+        print("  pool phases (trips, mean lanes): " + ", ".join(f"{names[i]} {buf[2*i]/frames/1e3:.0f}k x {buf[2*i+1]/max(1,buf[2*i]):.1f}" for i in range(5)))
+except AttributeError:
+    pass
