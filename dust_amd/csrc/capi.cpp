@@ -1386,8 +1386,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.row_begin = fp->row_begin;
   a.row_end = fp->row_end ? fp->row_end : p->height;
   if (a.row_begin >= a.row_end || a.row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
-  a.tiles_x = (p->width + 7) / 8;
-  a.tiles_y = (a.row_end - a.row_begin + 7) / 8;
+  a.tiles_x = (p->width + dust::kTileW - 1) / dust::kTileW;
+  a.tiles_y = (a.row_end - a.row_begin + dust::kTileH - 1) / dust::kTileH;
   a.rand = fp->rand; a.frame_index = fp->frame_index;
   if (p->noise0.p) a.noise0 = static_cast<const uint8_t*>(p->noise0.p) + size_t(fp->frame_index % p->noise0_layers) * 128 * 128;
   if (p->noise5.p) a.noise5 = static_cast<const uint8_t*>(p->noise5.p) + size_t(fp->frame_index % p->noise5_layers) * 128 * 128 * 4;  // noise.rs:50

@@ -35,6 +35,11 @@ namespace dust {
 
 constexpr uint32_t kN16Bytes = 656;      // 512 mask + 128 prefix + 4 base + 12 pad
 constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base is 0)
+#ifndef DUST_TILE_W
+#define DUST_TILE_W 8
+#define DUST_TILE_H 8
+#endif
+constexpr uint32_t kTileW = DUST_TILE_W, kTileH = DUST_TILE_H;  // pixels of one ray packet (kTileW * kTileH == 64 lanes)
 constexpr uint32_t kRegions = 8;          // work bands = XCDs (finer sub-queues per band measured 2.5 % slower: more empty-queue probes at the tail)
 constexpr uint32_t kCounterStride = 64;  // u32s between the per-region work counters (256 B: no two share a cache line)
 constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)

@@ -24,6 +24,12 @@
 #include "dust_dev.h"
 #include "exact_div.hpp"
 
+#ifdef DUST_PLAIN_STORES
+#define DUST_NT_STORE(v, p) (*(p) = (v))
+#else
+#define DUST_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 namespace dust {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
@@ -146,7 +152,7 @@ __device__ __forceinline__ u32x2 pack_half4(float a, float b, float c, float d) 
   return v;
 }
 __device__ __forceinline__ void store_half4(DUST_RW(uint16_t) plane, size_t pix, float a, float b, float c, float d) {
-  __builtin_nontemporal_store(pack_half4(a, b, c, d), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));  // written once, read by a later pass: do not displace the scene in L2
+  DUST_NT_STORE(pack_half4(a, b, c, d), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));  // written once, read by a later pass: do not displace the scene in L2
 }
 
 // ------------------------------------------------------------------ headers/normal.glsl, nrd.glsl
@@ -197,13 +203,13 @@ __device__ __forceinline__ u32x2 pack_radiance(V3 r, float hitdist) {  // nrd.gl
   return pack_half4(Y, Co, Cg, hitdist);
 }
 __device__ __forceinline__ void store_radiance(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {
-  __builtin_nontemporal_store(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
+  DUST_NT_STORE(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
 }
 // the same texel from a lane whose neighbours hold unrelated pixels (regrouped gather rays): an ordinary store, so that the
 // 8-byte pieces of a line meet in L2 -- a tile's packets run at about the same time on one XCD -- instead of going out one by one
 __device__ __forceinline__ void store_radiance_scattered(DUST_RW(uint16_t) plane, size_t pix, V3 r, float hitdist) {
 #ifdef DUST_NT_GATHER
-  __builtin_nontemporal_store(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
+  DUST_NT_STORE(pack_radiance(r, hitdist), (DUST_GLOBAL_AS u32x2*)(plane + pix * 4));
 #else
   *(DUST_GLOBAL_AS u32x2*)(plane + pix * 4) = pack_radiance(r, hitdist);
 #endif
@@ -1315,8 +1321,8 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
   }
   account_tile(a, tile);
   const uint32_t ty = __umulhi(tile, a.tiles_x_magic), tx = tile - ty * a.tiles_x;  // tile / tiles_x, exact (launch: tiles * tiles_x < 2^32)
-  p.px = tx * 8u + (lane & 7u);
-  p.py = a.row_begin + ty * 8u + (lane >> 3);
+  p.px = tx * kTileW + (lane % kTileW);
+  p.py = a.row_begin + ty * kTileH + (lane / kTileW);
   p.valid = p.px < a.width && p.py < a.row_end;
 }
 __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) {
@@ -1489,8 +1495,8 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
     const V3 dir = normalize3(d);
     const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
     store_radiance(a.g.denoised, pix, mk(div_const(s0.x + s1.x, 3.14f), div_const(s0.y + s1.y, 3.14f), div_const(s0.z + s1.z, 3.14f)), 100000.0f);
-    __builtin_nontemporal_store(0xFFFFFFFFu, &a.g.albedo[pix]);
-    __builtin_nontemporal_store(INFINITY, &a.g.depth[pix]);
+    DUST_NT_STORE(0xFFFFFFFFu, &a.g.albedo[pix]);
+    DUST_NT_STORE(INFINITY, &a.g.depth[pix]);
     store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
     return;
   }
@@ -1519,13 +1525,13 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
     const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
     const uint32_t pal = m.materials[b.material_ptr + voff];
     const uint32_t col = m.palette[pal];
-    __builtin_nontemporal_store(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
+    DUST_NT_STORE(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
                                              div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
-    __builtin_nontemporal_store(h.t, &a.g.depth[pix]);
+    DUST_NT_STORE(h.t, &a.g.depth[pix]);
     hitT = h.t;
     normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
-    __builtin_nontemporal_store(normal_packed, &a.g.normal[pix]);
-    __builtin_nontemporal_store((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
+    DUST_NT_STORE(normal_packed, &a.g.normal[pix]);
+    DUST_NT_STORE((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
     const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
     const V3 hpm = xform_point(in.w2o, hpw);
     DUST_RO(float) P = in.prev;
@@ -2011,7 +2017,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
   while (next_packet(a0, wc, p)) {
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     if (a.gi.order) {  // regrouped: packet id -> 64 entries of one tile's octant-ordered pixel list
-      const uint32_t id = p.px >> 3, tile = id / (kOrderSlots / 64u), idx = (id % (kOrderSlots / 64u)) * 64u + (threadIdx.x & 63u);
+      const uint32_t id = p.px / kTileW, tile = id / (kOrderSlots / 64u), idx = (id % (kOrderSlots / 64u)) * 64u + (threadIdx.x & 63u);
       const uint32_t n = a.gi.order_count[tile];
       if ((idx & ~63u) >= n) continue;  // this tile has fewer live pixels
       p.valid = idx < n;
@@ -2066,7 +2072,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather_pool(const FrameArgs) {
   while (next_packet(a0, wc, p)) {
     ArgsRef a = reload_args(a0);
     constexpr uint32_t kGroups = kOrderSlots / kPoolGroup;
-    const uint32_t id = p.px >> 3, tile = id / kGroups, begin = (id % kGroups) * kPoolGroup;
+    const uint32_t id = p.px / kTileW, tile = id / kGroups, begin = (id % kGroups) * kPoolGroup;
     const uint32_t n = a.gi.order_count[tile];
     if (begin >= n) continue;  // this tile has fewer live pixels
     const uint32_t end = n < begin + kPoolGroup ? n : begin + kPoolGroup;
@@ -2202,7 +2208,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
   while (next_packet(a0, wc, p)) {  // tiles_x = 2 * ceil(pool_size / 64), tiles_y = 1
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     const uint32_t groups = (a.gi.pool_size + 63u) / 64u;
-    const uint32_t item = p.px >> 3;
+    const uint32_t item = p.px / kTileW;
     const bool sun_item = item >= groups;
     const uint32_t slot = (sun_item ? item - groups : item) * 64u + (threadIdx.x & 63u);
     const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
