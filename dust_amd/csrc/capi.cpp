@@ -176,18 +176,48 @@ struct DustHipContext : RefCounted {
   size_t max_lds = 64 * 1024;
   DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
   uint64_t sync_epoch = 1;  // bumped whenever the library has waited for the stream: what was enqueued before is done
+  // The surfel pass of a frame runs on a second stream of the context (run_surfel_pass): it is launched in its own frame, behind
+  // that frame's final gather, and only has to be complete before the NEXT final gather reads the hash -- so the next frame's
+  // primary / AO kernel starts beside it and fills the workgroup slots its long tail leaves empty. Nothing is kept back:
+  // what conflicts with it on the main stream (the next gather, a scene commit, anything that touches the GI state) waits
+  // for `ev_side_done` first (join_side); every wait for the context covers both streams (sync_stream).
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_side_done = nullptr;
+  bool side_busy = false;
 };
 // wait for everything enqueued on the context's stream (and remember that we did: scene commits recycle their pinned staging
 // slots by this, without an event per commit)
 static hipError_t sync_stream(DustHipContext* c) {
-  const hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && c->side) { e = hipStreamSynchronize(c->side); c->side_busy = false; }
   if (e == hipSuccess) ++c->sync_epoch;
   return e;
+}
+// main stream: wait (on the device) for the side stream's pass, if one may still be running
+static hipError_t join_side(DustHipContext* c) {
+  if (!c->side_busy) return hipSuccess;
+  c->side_busy = false;
+  return hipStreamWaitEvent(c->stream, c->ev_side_done, 0);
+}
+// side stream: everything enqueued on the main stream so far comes first
+static hipError_t fork_side(DustHipContext* c) {
+  hipError_t e = hipSuccess;
+  if (!c->side) {
+    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  e = hipEventRecord(c->ev_fork, c->stream);
+  return e != hipSuccess ? e : hipStreamWaitEvent(c->side, c->ev_fork, 0);
 }
 static void release(DustHipContext* c) {
   if (!c || c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   c->srgb_lut.release();
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -299,6 +329,8 @@ struct Tuning {
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
+  bool no_side_stream = false;  // DUST_HIP_NO_SIDE_STREAM: the surfel pass on the main stream, in place
+  uint32_t side_share = 0;      // DUST_HIP_SIDE_SHARE: percent of the workgroup slots the surfel pass takes on the second stream (0: by ray counts)
   bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
                                 // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -317,6 +349,9 @@ struct Tuning {
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
     t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
+    t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
+    t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
+    if (t.side_share) t.side_share = std::min(90u, std::max(5u, t.side_share));
     return t;
   }
 };
@@ -370,6 +405,11 @@ struct DustHipPipeline {
   bool stats_valid = false;
   bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
   dust::DevStats* host_stats = nullptr;  // pinned, 8 records: where the counting build's statistics land
+  // How the workgroup slots are split while a surfel pass runs beside the next frame's primary / AO kernels: the pipeline's first
+  // GI frame runs its surfel pass in place and is timed (P: primary / AO kernels, Q: the pass); once those events have completed --
+  // looked at without waiting, some frames later -- the pass's share is 100 Q / (Q + 1.05 P) - 3, which is where the measured optima
+  // of three workloads lie (castle 1080p 50 %, 4K 20 %, the 4096^3 tree 25 %). Until then: a guess from the ray counts.
+  struct { hipEvent_t p0 = nullptr, p1 = nullptr, q0 = nullptr, q1 = nullptr; int state = 0; uint32_t share = 0; } side_cal;
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
@@ -899,7 +939,7 @@ DustStatus make_editable(DustHipModel* m) {
   HIP_TRY(dense_mask.alloc(size_t(4096) * 64 * 8));
   dust::EditArgs a = edit_args(m, *e);  // (expand only writes the grid)
   HIP_TRY(dust::launch_edit_expand(a, static_cast<const DustHipBlock*>(m->blocks.p), static_cast<const uint8_t*>(m->materials.p), m->dev.n_blocks, st));
-  HIP_TRY(hipStreamSynchronize(st));  // every launch that reads the old arrays is done (frames of this context run on `st`)
+  HIP_TRY(sync_stream(m->ctx));  // every launch that reads the old arrays is done (both streams of the context)
   auto swap_all = [&] {
     std::swap(m->blocks.p, blocks.p); std::swap(m->blocks.bytes, blocks.bytes);
     std::swap(m->materials.p, materials.p); std::swap(m->materials.bytes, materials.bytes);
@@ -942,6 +982,7 @@ DustStatus dust_hip_model_set_voxels(DustHipModel* m, const uint32_t* xyz, const
   }
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(join_side(m->ctx));  // (a surfel pass on the second stream still traces the model as it is)
     DustStatus s = make_editable(m);
     if (s != DUST_OK || n == 0) return s;
     // a voxel named more than once takes its LAST value (what a sequence of set calls would leave): keep the last entry
@@ -974,6 +1015,7 @@ DustStatus dust_hip_model_get_voxels(DustHipModel* m, const uint32_t* xyz, int32
       return fail(DUST_ERR_INVALID_ARGUMENT, "voxel coordinate outside the tree extent");
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(join_side(m->ctx));
     DustStatus s = make_editable(m);
     if (s != DUST_OK || n == 0) return s;
     s = upload_batch(m, xyz, nullptr, n, false);
@@ -1155,6 +1197,7 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
     for (size_t i = 0; i < n; ++i)
       for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], di[i].wmin[a]); s->world_max[a] = std::max(s->world_max[a], di[i].wmax[a]); }
+    HIP_TRY(join_side(s->ctx));  // (a surfel pass still tracing the old transforms on the second stream)
     // one asynchronous copy of the image, from the next pinned slot, behind whatever frame is in flight on the stream
     DustHipScene::Staging& sg = s->staging[s->staging_next++ % DustHipScene::kStaging];
     // the copy that last read this slot was enqueued four commits ago: done if anything has waited for the stream since (a frame
@@ -1180,6 +1223,7 @@ static void destroy_pipeline(DustHipPipeline* p) {
     for (auto& side : kind)
       for (auto& e : side) if (e) (void)hipEventDestroy(e);
   if (p->host_stats) (void)hipHostFree(p->host_stats);
+  for (hipEvent_t e : {p->side_cal.p0, p->side_cal.p1, p->side_cal.q0, p->side_cal.q1}) if (e) (void)hipEventDestroy(e);
   delete p;
   release(c);
 }
@@ -1416,7 +1460,34 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
-  const uint32_t grid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
+  // while a surfel pass may be running on the second stream, the primary / AO kernels leave it its share of the slots (persistent
+  // launches hold what they get: whichever came first would otherwise own the GPU until it is done)
+  // The share: the pass's rays against the pixel passes' (pool x 18 surfel-ray costs to 3 rays per pixel, which puts the castle at
+  // 50 % at 1080p and 20 % at 4K -- where round 2's feedback loop settled, without its calibration frame, event probes and waits)
+  uint32_t share = tune.side_share;
+  bool calibrate = false;
+  if (!share) {
+    auto& cal = p->side_cal;
+    if (cal.state == 1 && hipEventQuery(cal.q1) == hipSuccess) {
+      float P = 0.0f, Q = 0.0f;
+      if (hipEventElapsedTime(&P, cal.p0, cal.p1) == hipSuccess && hipEventElapsedTime(&Q, cal.q0, cal.q1) == hipSuccess && P > 0.0f && Q > 0.0f)
+        cal.share = uint32_t(std::min(65.0f, std::max(10.0f, 100.0f * Q / (Q + 1.05f * P) - 3.0f)));
+      cal.state = 2;
+    }
+    (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
+    const bool gi_frame = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_SURFEL);
+    calibrate = cal.state == 0 && gi_frame && !tune.no_side_stream && !count && !sharded && !ctx->side_busy && !(tune.debug & 16u);
+    if (calibrate && !cal.p0)
+      for (hipEvent_t* e : {&cal.p0, &cal.p1, &cal.q0, &cal.q1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
+    if (cal.share) share = cal.share;
+    else {
+      const double surfel = double(p->gi_pool_size) * 18.0, pixel = 3.0 * double(p->width) * double(a.row_end - a.row_begin);
+      share = uint32_t(std::min(60.0, std::max(15.0, 100.0 * surfel / (surfel + pixel))));
+    }
+  }
+  const uint32_t side_slots = ctx->side_busy ? std::max(8u, (resident * share / 100u) & ~7u) : 0u;
+  const uint32_t main_resident = std::max(8u, resident - std::min(resident - 8u, side_slots));
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(main_resident, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
     auto mix = [&k](const void* data, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(data); for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
@@ -1437,6 +1508,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // primary + AO in one launch unless told otherwise (DUST_HIP_NO_FUSE=1 keeps the reference's one-launch-per-pass shape)
   const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !tune.no_fuse;
   p->fused_last = fuse;
+  if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p0, st));
   if (fuse) {
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
@@ -1461,6 +1533,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
+  if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p1, st));
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
     if (sharded) {  // pixels that stamp nothing must read 0 after the all-gather
       a.gi.touched = static_cast<uint32_t*>(p->gi_touched.p);
@@ -1483,6 +1556,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
+    HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
@@ -1490,8 +1564,19 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
-    DustStatus rs = run_surfel_pass(p, a, fp->passes, count, st, resident);
+    // On the context's second stream, behind this frame's final gather (see DustHipContext::side): the pass is a handful of
+    // latency-bound launches around a trace that is as long as its longest ray, and nothing of THIS frame waits for it.
+    const bool aside = !tune.no_side_stream && !count && !sharded && !(tune.debug & 16u) && !calibrate;
+    if (aside) HIP_TRY(fork_side(ctx));
+    else HIP_TRY(join_side(ctx));
+    if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.q0, st));
+    // beside the next frame's kernels it takes a share of the workgroup slots (both are persistent launches: with all slots
+    // taken by the first, the second would simply run after it)
+    const uint32_t side_resident = std::max(8u, (resident * share / 100u) & ~7u);
+    DustStatus rs = run_surfel_pass(p, a, fp->passes, count, aside ? ctx->side : st, aside ? side_resident : resident);
     if (rs != DUST_OK) return rs;
+    if (aside) { HIP_TRY(hipEventRecord(ctx->ev_side_done, ctx->side)); ctx->side_busy = true; }
+    if (calibrate) { HIP_TRY(hipEventRecord(p->side_cal.q1, st)); p->side_cal.state = 1; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
     p->have_history = false;  // the plane now holds an N-frame mean, not the denoiser's history
@@ -1674,6 +1759,7 @@ static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uin
   // stamps and commits the winners
   if (row_begin > row_end || (row_begin == row_end && !import) || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(join_side(p->ctx));
   dust::FrameArgs a{};
   a.width = p->width; a.height = p->height;
   a.inv_width = 1.0f / float(p->width); a.inv_height = 1.0f / float(p->height); a.aspect = float(p->width) / float(p->height);
@@ -1701,6 +1787,7 @@ DustStatus dust_hip_pipeline_read_gi(DustHipPipeline* p, uint32_t which, void* d
   const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
   if (dst_bytes < b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "destination too small");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(join_side(p->ctx));
   HIP_TRY(sync_stream(p->ctx));
   HIP_TRY(copy_wait(dst, b.p, b.bytes, hipMemcpyDeviceToHost, p->ctx->stream));
   return DUST_OK;
@@ -1710,6 +1797,7 @@ DustStatus dust_hip_pipeline_write_gi(DustHipPipeline* p, uint32_t which, const 
   const DeviceBuffer& b = which == 0 ? p->gi_hash : p->gi_pool;
   if (src_bytes != b.bytes) return fail(DUST_ERR_INVALID_ARGUMENT, "saved GI state does not match the configured capacity / pool size");
   HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(join_side(p->ctx));
   HIP_TRY(copy_wait(b.p, src, b.bytes, hipMemcpyHostToDevice, p->ctx->stream));
   return DUST_OK;
 }

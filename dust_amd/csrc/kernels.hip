@@ -1320,7 +1320,8 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     tile = a.tile_order[ticket];  // ticket -> tile, most expensive tiles of the band first
   }
   account_tile(a, tile);
-  const uint32_t ty = __umulhi(tile, a.tiles_x_magic), tx = tile - ty * a.tiles_x;  // tile / tiles_x, exact (launch: tiles * tiles_x < 2^32)
+  // tile / tiles_x: through the multiplier where that is exact (with_schedule); a one-row list of work items has quotient 0
+  const uint32_t ty = a.tiles_x_magic ? __umulhi(tile, a.tiles_x_magic) : (a.tiles_y > 1u ? tile / a.tiles_x : 0u), tx = tile - ty * a.tiles_x;
   p.px = tx * kTileW + (lane % kTileW);
   p.py = a.row_begin + ty * kTileH + (lane / kTileW);
   p.valid = p.px < a.width && p.py < a.row_end;
@@ -2755,7 +2756,9 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   FrameArgs a = in;
   const uint32_t total = a.tiles_x * a.tiles_y;
   a.tiles_per_band = (total + kRegions - 1u) / kRegions;
-  a.tiles_x_magic = (uint32_t)((1ull << 32) / (a.tiles_x ? a.tiles_x : 1u)) + 1u;
+  // floor(2^32 / d) + 1 gives the exact quotient for n * d < 2^32; launches beyond that are one-row lists (tiles_y == 1: quotient 0)
+  const bool exact = a.tiles_y > 1u && (unsigned long long)total * a.tiles_x < (1ull << 32);
+  a.tiles_x_magic = exact ? (uint32_t)((1ull << 32) / a.tiles_x) + 1u : 0u;  // 0: the kernel divides (frames beyond ~11K x 11K) or has one row
   const uint32_t waves = ((grid + kRegions - 1u) / kRegions) * (block / 64u);  // the fullest band's
   const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;
   a.static_rounds = rounds >= 1u ? 1u : 0u;  // (see next_packet: dealing more than the first round was measured and lost)
