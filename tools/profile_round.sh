@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ keeps for a round:
-#   python tools/kernel_sections.py --build && gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
+#   python tools/kernel_sections.py --build && gpurun --timeout 2400 -- "HEAD_STAMP=$(git rev-parse --short HEAD) bash tools/profile_round.sh r03"
 # writes gpurun_out/<tag>_{gpu_tests.log,bench*.log,kernel_stats*.{txt,json},pmc*.txt,sections*.txt,tile_costs.txt,denoise_kernels.txt}.
 # Counter passes run separately from the kernel-trace/stats pass (one counter group per run).
 tag=${1:-r01}
@@ -10,7 +10,7 @@ out=$R/gpurun_out
 mkdir -p "$out"
 cd "$R" || exit 1
 
-python -m pytest tests -m gpu -x -q > "$out/${tag}_gpu_tests.log" 2>&1
+{ echo "# HEAD ${HEAD_STAMP:-unknown}"; python -m pytest tests -m gpu -x -q -p no:cacheprovider; } > "$out/${tag}_gpu_tests.log" 2>&1
 tail -2 "$out/${tag}_gpu_tests.log"
 
 python bench.py > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"
@@ -19,10 +19,11 @@ python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi.log" 2>>
 tail -1 "$out/${tag}_bench_gi.log" | cut -c1-600
 python bench.py --workload deep --steps 30 > "$out/${tag}_bench_deep.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_deep.log" | cut -c1-600
-python bench.py --shard bands > "$out/${tag}_bench_bands.log" 2>> "$out/${tag}_bench.err"
-python bench.py --workload gi --shard bands --no-cpu-baseline > "$out/${tag}_bench_gi_bands.log" 2>> "$out/${tag}_bench.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/${tag}_bench_driver_style.log" 2>> "$out/${tag}_bench.err"   # the driver's command line
+python bench.py --workload teapot_cpu > "$out/${tag}_bench_teapot_cpu.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
-DUST_HIP_NO_OVERLAP=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_RAY_LANES=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ray_lanes.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 
 cd /tmp || exit 1
