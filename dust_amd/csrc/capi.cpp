@@ -1332,6 +1332,8 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
   const Tuning& tune = p->tune;
   const uint32_t block = tune.block;
     dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
+    // on the second stream the pass is the longer of the two sides that share the SIMDs: its waves win the issue arbitration
+    if (st != ctx->stream) b.prio_floor = std::getenv("DUST_HIP_SIDE_PRIO") ? uint32_t(std::atoi(std::getenv("DUST_HIP_SIDE_PRIO"))) : 3u;
     b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
     b.tiles_y = 1;
     take_counters(p, 3, b);
