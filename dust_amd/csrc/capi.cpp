@@ -178,7 +178,7 @@ struct DustHipContext : RefCounted {
   uint64_t sync_epoch = 1;  // bumped whenever the library has waited for the stream: what was enqueued before is done
   // The surfel pass of a frame runs on a second stream of the context (run_surfel_pass): it is launched in its own frame, behind
   // that frame's final gather, and only has to be complete before the NEXT final gather reads the hash -- so the next frame's
-  // primary / AO kernel starts beside it and fills the workgroup slots its long tail leaves empty. Nothing is kept back:
+  // primary / AO kernel runs beside it, each side on its share of the workgroup slots. Nothing is kept back:
   // what conflicts with it on the main stream (the next gather, a scene commit, anything that touches the GI state) waits
   // for `ev_side_done` first (join_side); every wait for the context covers both streams (sync_stream).
   hipStream_t side = nullptr;

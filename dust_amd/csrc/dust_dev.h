@@ -186,7 +186,7 @@ struct FrameArgs {
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
   uint32_t deep;              // the scene holds a 4096^3 model with its per-cell table: launch the DEEP kernel variants
-  uint32_t prio_floor;        // lowest issue priority this launch's waves run at (a pass that runs beside another and is the longer side: 2)
+  uint32_t prio_floor;        // lowest issue priority this launch's waves run at (the surfel pass on the second stream, beside the next frame's kernels: 3)
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in
                               // index order instead of the packet's sorted candidate list, 8: gather / surfel rays take the
                               // wave-uniform candidate walk of the coherent ray types); 0 in production

@@ -292,7 +292,13 @@ void dust_hip_pipeline_destroy(DustHipPipeline*);
 DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const uint8_t* texels, uint32_t layers);
 /* StandardPipeline::render (standard.rs:228-810). Asynchronous on the context's stream.
  * DUST_ERR_NOT_READY while a noise texture a requested pass samples has not been set.
- * Every pass of the frame is enqueued before the call returns (nothing is kept back for a later call). */
+ * Every pass of the frame is enqueued before the call returns (nothing is kept back for a later call). The surfel pass
+ * (DUST_PASS_SURFEL) only has to be complete before the NEXT frame's final gather reads the spatial hash, and it is latency-bound:
+ * it is enqueued on a second stream the context owns, behind this frame's final gather, so that the next frame's primary / AO
+ * kernels run beside it. It reads the scene and writes only the library-owned GI buffers; every library call that conflicts with
+ * it (the next final gather, dust_hip_scene_commit, model edits, the GI state accessors) waits for it on the device, and
+ * dust_hip_sync and every synchronous read-back wait for both streams -- a caller that orders its own work on the context's
+ * stream (e.g. a collective that reads a bound plane) needs nothing more. DUST_HIP_NO_SIDE_STREAM=1 keeps the pass in place. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
 /* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
