@@ -66,6 +66,10 @@ def parse(argv=None):
                     help="N > 1, how finished frames leave their GPU: slices = one all-to-all, rank j assembles row slice j of every "
                          "frame (default; every xGMI link in use); rotate / fixed = RCCL gather of whole frames onto rank k %% N / rank 0 "
                          "(bound by each peer's single link to the root). Row bands are always gathered (default root: rotating)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames of the sequence on the GPU at once, each on a stream, context and G-buffer of its own (0 = auto: 4 for "
+                         "row bands on N > 1 GPUs, where a rank's launch is as long as its most expensive tile and most of the GPU would "
+                         "idle behind it; 1 otherwise). GI workloads run one frame at a time (every frame reads the previous one's hash)")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
@@ -106,14 +110,20 @@ class HipBackend:
         # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
         # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
         # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
-        self.stream = torch.cuda.Stream(device=local_rank)
-        torch.cuda.set_stream(self.stream)
-        assert self.stream.cuda_stream != 0
         if world > 1:
             # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
             # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1
             os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
-        self.ctx = api.Context(device=local_rank, timing=True, stream=ctypes.c_void_p(self.stream.cuda_stream))
+        self.streams = []
+        self.stream, self.ctx = self._stream_and_context()
+        torch.cuda.set_stream(self.stream)
+
+    def _stream_and_context(self):
+        stream = self.torch.cuda.Stream(device=self.local_rank)
+        assert stream.cuda_stream != 0
+        self.streams.append(stream)
+        # (kernel times from event pairs around every 4th frame's launches: a record costs the stream ~6 us, 5 % of this frame)
+        return stream, self.api.Context(device=self.local_rank, timing=True, sparse_timing=True, stream=ctypes.c_void_p(stream.cuda_stream))
 
     def init_dist(self):
         import torch.distributed as dist
@@ -122,9 +132,29 @@ class HipBackend:
         return dist
 
     def sync(self):
+        # poll first: an interrupt-driven wait wakes tens to hundreds of microseconds after the GPU is done, which is percents of a
+        # 20-step timed region; hipStreamQuery in a loop sees the end within a couple of microseconds
+        for st in self.streams:
+            while not st.query():
+                pass
         self.torch.cuda.synchronize()
 
-    def build_scene(self, args):
+    def open_lane(self, args, first):
+        """One frame in flight: a stream, a context on it, the scene uploaded to that context, a pipeline (G-buffer). The first lane is
+        the backend's own stream and context; `first` (its scene dict) spares the others the parse."""
+        lane = Lane()
+        if first is None:
+            lane.stream, lane.ctx = self.stream, self.ctx
+            lane.sc = self.build_scene(args)
+        else:
+            lane.stream, lane.ctx = self._stream_and_context()
+            lane.sc = dict(first)
+            lane.sc["scene"] = self.P.hip_scene(lane.ctx, first["desc"])
+        lane.pipe = self.api.StandardPipeline(lane.ctx, args.width, args.height)
+        lane.enter = lambda: self.torch.cuda.stream(lane.stream)
+        return lane
+
+    def build_scene(self, args, ctx=None):
         """-> dict(scene, cam, sky, info, n_bricks, t_load, desc, deep=(blocks, mats, pal, xf) or None)"""
         import numpy as np
         api, synth, P = self.api, self.synth, self.P
@@ -156,9 +186,6 @@ class HipBackend:
                    cam=api.make_camera(eye, api.look_at_rotation(eye, target), api.PinholeProjection()))
         return out
 
-    def make_pipeline(self, w, h):
-        return self.api.StandardPipeline(self.ctx, w, h)
-
     def noise(self):
         return self.synth.stbn_scalar(), self.synth.stbn_unitvec3_cosine()
 
@@ -167,6 +194,9 @@ class HipBackend:
 
     def alias_exchange(self, ex):
         return self.sharding.alias_exchange_buffers(ex)
+
+    def sky_struct(self, sky):
+        return self.api.sky_struct(sky)
 
     def check_target(self, pipe, target, rows):
         """untimed self-check of the plumbing the gather relies on: the bound torch tensor is where the frame went
@@ -177,20 +207,31 @@ class HipBackend:
         assert bool((own != 0).any()) and torch.equal(target[rows[0]:rows[1]].cpu().view(torch.int16), own)
 
 
-def measure_curve(be, dist, args, sc, pipe, shard):
+class Lane:
+    """a frame in flight: stream, context, scene copy and pipeline (see HipBackend.open_lane)"""
+    pass
+
+
+def measure_curve(be, dist, args, lanes, shard):
     """One timed region: the untimed counting frame, the settle + warm-up frames, K timed steps bracketed by barriers.
     shard: "bands" (one frame in world row bands) or "samples" (one frame per rank). Returns a dict (same on every rank after
     the reductions) with the whole job's rays per step, the max-over-ranks time and every rank's kernel times."""
     torch, L, sharding, synth = be.torch, be.L, be.sharding, be.synth
     rank, world = be.rank, be.world
     W, H = args.width, args.height
-    scene, cam, sky = sc["scene"], sc["cam"], sc["sky"]
+    sc, pipe = lanes[0].sc, lanes[0].pipe
+    cam, sky = sc["cam"], be.sky_struct(sc["sky"])  # (converted once: the frame loop's host time per step is what a band-sized step is made of)
     gi_mode = args.workload in ("gi", "deep")
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
     if gi_mode:  # diffuse GI through the surfel-fed spatial hash
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
     bands = shard == "bands"
     per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
+    emulate = os.environ.get("DUST_BENCH_EMULATE_BAND")  # "r/N" on ONE GPU: this rank renders band r of N, nothing is gathered --
+    if emulate and bands and world == 1:                 # what a rank of an N-GPU strong-scaling run does between collectives
+        er, en = (int(v) for v in emulate.split("/"))
+        per_rows, rows, send = sharding.band_layout(er, en, H)
+        send = (send[0], en * per_rows)  # (sizes the padded render target as the N-rank run would)
     have_rows = rows[0] < rows[1]                                        # a rank past the end of the frame renders no pixels
     gi_bands = gi_mode and bands and world > 1   # (one GPU: the band is the frame, nothing to exchange, the racy apply is fine)
     if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
@@ -206,18 +247,36 @@ def measure_curve(be, dist, args, sc, pipe, shard):
     # --assemble rotate / fixed gather whole frames onto rank k % N / rank 0 instead (bands always gather: a band is a slice).
     assemble = args.assemble if not bands else ("rotate" if args.assemble == "slices" else args.assemble)
     slices = assemble == "slices" and world > 1
-    tgt_rows = world * per_rows if bands else (-(-H // world) * world if slices else H)
-    targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device=be.device) for _ in range(2)]
+    tgt_rows = max(world * per_rows, send[1]) if bands else (-(-H // world) * world if slices else H)
+    # Slots: step k renders into target k % S on lane (k % S) % D -- two targets per pipeline at least, so that a gather never
+    # reads what the next frame of the same pipeline writes; with D > 1 frames in flight every lane has its own stream, and a
+    # rank whose launch is held up by one expensive tile fills the rest of the GPU with the next frames' tiles.
+    D = len(lanes)
+    S = max(2, D)
+    fixed_targets = S == D  # every lane renders into one target of its own: bound once, not per step
+    targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device=be.device) for _ in range(S)]
     if slices:
         send = (0, tgt_rows)
     # step k's exchange overlaps step k+1's rendering
-    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[1]], rotate=assemble == "rotate", slices=slices)
+    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[0] + (per_rows if bands else send[1] - send[0])], depth=S, rotate=assemble == "rotate", slices=slices)
     pix_stats = []
+    if fixed_targets:
+        for s_, lane in enumerate(lanes):
+            be.bind_target(lane.pipe, targets[s_])
 
     def step(k, count=False):
+        lane = lanes[(k % S) % D]
+        if world > 1 and D > 1:
+            with lane.enter():  # the collective below is ordered against the lane's stream
+                step_on(lane.pipe, lane.sc["scene"], k, count)
+        else:
+            step_on(lane.pipe, lane.sc["scene"], k, count)
+
+    def step_on(pipe, scene, k, count):
         cs = L.PASS_COUNT_STATS if count else 0
-        gather.wait_slot(k % 2)  # the gather that last read this target is done
-        be.bind_target(pipe, targets[k % 2])
+        gather.wait_slot(k % S)  # the gather that last read this target is done
+        if not fixed_targets:
+            be.bind_target(pipe, targets[k % S])
         if gi_bands:
             frame_index = 1 + k  # every rank works on the same frame
             rnd = synth.frame_rand(1, frame_index)
@@ -242,7 +301,7 @@ def measure_curve(be, dist, args, sc, pipe, shard):
             frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
             pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         if world > 1:
-            gather.submit_view(targets[k % 2][send[0]:send[1]])  # asynchronous gather, straight from the target
+            gather.submit_view(targets[k % S][send[0]:send[1]])  # asynchronous gather, straight from the target
 
     def barrier():
         gather.finish()
@@ -273,7 +332,8 @@ def measure_curve(be, dist, args, sc, pipe, shard):
         step(1 + settle)
         settle += 1
     barrier()
-    pipe.mark_kernel_times()  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE (no wait) ...
+    for lane in lanes:
+        lane.pipe.mark_kernel_times()  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE (no wait) ...
     t_start = time.perf_counter()
     for i in range(args.steps):
         step(1 + settle + i)
@@ -282,7 +342,10 @@ def measure_curve(be, dist, args, sc, pipe, shard):
     gc.enable()
     # ... TO HERE: the timed region's own launches, on the launch stream, read back after it (a ring of 256 pairs per pass
     # kind: with more steps than that, the last 256); nothing was synchronised per step
-    ev_ms, ev_n = pipe.kernel_times(mark=True)
+    ev_ms, ev_n = [0.0] * 4, [0] * 4
+    for lane in lanes:
+        lm, ln = lane.pipe.kernel_times(mark=True)
+        ev_ms, ev_n = [a_ + b_ for a_, b_ in zip(ev_ms, lm)], [a_ + b_ for a_, b_ in zip(ev_n, ln)]
     ms = [(ev_ms[k] / ev_n[k]) if ev_n[k] else 0.0 for k in range(4)]
     if not gi_mode:
         ms[2] = ms[3] = 0.0
@@ -303,7 +366,7 @@ def measure_curve(be, dist, args, sc, pipe, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle}
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D}
 
 
 def run_rank(args, be, dist):
@@ -312,12 +375,19 @@ def run_rank(args, be, dist):
     W, H = args.width, args.height
     gi_mode = args.workload in ("gi", "deep")
     deep = args.workload == "deep"
-    sc = be.build_scene(args)
-    pipe = be.make_pipeline(W, H)
     noise0, noise5 = be.noise()
-    pipe.set_noise(5, noise5)
-    if gi_mode:
-        pipe.set_noise(0, noise0)
+    lanes = []
+
+    def lanes_for(n):
+        while len(lanes) < n:
+            lane = be.open_lane(args, lanes[0].sc if lanes else None)
+            lane.pipe.set_noise(5, noise5)
+            if gi_mode:
+                lane.pipe.set_noise(0, noise0)
+            lanes.append(lane)
+        return lanes[:n]
+
+    sc, pipe = lanes_for(1)[0].sc, lanes[0].pipe
 
     if world == 1:
         wanted = ["bands" if args.shard in ("both", "bands") else "samples"]   # one GPU: the two partitions are the same frame
@@ -328,7 +398,8 @@ def run_rank(args, be, dist):
         if len(curves) and gi_mode:  # a second curve starts from a fresh hash, like the first
             pipe.configure_gi(*(getattr(pipe, "_gi", None) or (32 * 1024 * 1024, 720 * 480)))
             pipe.clear()
-        curves[shard] = measure_curve(be, dist, args, sc, pipe, shard)
+        in_flight = 1 if gi_mode else (args.frames_in_flight or (4 if (world > 1 and shard == "bands") else 1))
+        curves[shard] = measure_curve(be, dist, args, lanes_for(in_flight), shard)
     main_curve = curves[wanted[0]]
     if rank != 0:
         return None
@@ -376,7 +447,10 @@ def run_rank(args, be, dist):
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
-                "kernel_ms_source": f"HIP events on the launch stream around every launch of the timed region ({main_curve['launches']} launches averaged)",
+                "kernel_ms_source": f"HIP events on the launch stream around the launches of every 4th frame of the timed region ({main_curve['launches']} launches "
+                                    "averaged; an event record costs the stream ~6 us, so bracketing every launch would take 5 % off the rate it measures)"
+                                    + (f"; {main_curve['frames_in_flight']} frames in flight on streams of their own: a launch's duration includes the time it "
+                                       "shares the GPU with its neighbours'" if main_curve["frames_in_flight"] > 1 else ""),
                 "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if fused else
                                    {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
                 "per_rank_kernel_ms": [{"primary_ao" if fused else "primary": round(v[0], 4),
@@ -418,10 +492,11 @@ def run_rank(args, be, dist):
                    "frame": [W, H], "spp_per_step": 1 if bands_main else world, "parallelism": parallelism(main_curve),
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": sc["n_bricks"], "scene_build_s": round(sc["t_load"], 3), "untimed_steps_before_timing": main_curve["settle"],
+                   "frames_in_flight": main_curve["frames_in_flight"],
                    "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(main_curve["rays_per_step"])},
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
-                                  "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c),
+                                  "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"],
                                   "per_rank_kernel_ms": [[round(x, 4) for x in v] for v in c["per_rank"]]} for c in curves.values()},
         "roofline": roofline,
         "cpu_baseline": cpu,

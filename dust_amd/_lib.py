@@ -30,6 +30,7 @@ PASS_COUNT_STATS = 1 << 16
 PASS_GI_ORDERED = 1 << 17
 PASS_GI_SHARDED = 1 << 18
 CONTEXT_TIMING = 1
+CONTEXT_TIMING_SPARSE = 2
 
 PLANE_ILLUMINANCE, PLANE_DENOISED, PLANE_ALBEDO, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOTION, PLANE_VOXEL_ID, PLANE_ACCUM, PLANE_OUTPUT = range(9)
 PLANE_BYTES_PER_PIXEL = (8, 8, 4, 4, 4, 8, 4, 16, 8)

@@ -255,9 +255,10 @@ class Sunlight:
 
 
 class Context:
-    def __init__(self, device=-1, timing=True, stream=None, lds_root_bytes=0):
+    def __init__(self, device=-1, timing=True, stream=None, lds_root_bytes=0, sparse_timing=False):
         self._lib = L.load()
-        cfg = L.Config(C.sizeof(L.Config), device, stream, lds_root_bytes, L.CONTEXT_TIMING if timing else 0)
+        flags = (L.CONTEXT_TIMING if timing else 0) | (L.CONTEXT_TIMING_SPARSE if timing and sparse_timing else 0)
+        cfg = L.Config(C.sizeof(L.Config), device, stream, lds_root_bytes, flags)
         self._h = C.c_void_p()
         L.check(self._lib.dust_hip_context_create(C.byref(cfg), C.byref(self._h)))
 
@@ -357,6 +358,13 @@ class Scene:
         L.check(self._lib.dust_hip_scene_commit(self._h))
 
 
+def sky_struct(sky):
+    """56 baked sky floats -> DustHipSky"""
+    s = L.Sky()
+    s.state[:] = np.asarray(sky, np.float32).reshape(56).tolist()
+    return s
+
+
 class StandardPipeline:
     """StandardPipeline (crates/render/src/pipeline/standard.rs:51-60, :222-240) + its GBuffer (:881-917)."""
 
@@ -383,8 +391,8 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_pipeline_set_noise(self._h, texture, _ptr(t), layers))
 
     def render(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
-        s = L.Sky()
-        s.state[:] = np.asarray(sky, np.float32).reshape(56).tolist()
+        """sky: 56 floats, or a DustHipSky made once with api.sky_struct() (a frame loop: the conversion is most of this call's host time)"""
+        s = sky if isinstance(sky, L.Sky) else sky_struct(sky)
         fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1])
         L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
 

@@ -172,6 +172,7 @@ struct DustHipContext : RefCounted {
   bool own_stream = false;
   uint32_t lds_root_bytes = 64 * 1024;
   bool timing = false;
+  uint32_t timing_stride = 1;  // DUST_HIP_CONTEXT_TIMING_SPARSE: event pairs around the launches of every 4th frame only
   int num_cus = 256;
   size_t max_lds = 64 * 1024;
   DeviceBuffer srgb_lut;  // edit.hip: avg_albedo's linear->sRGB curve per (voxel count, colour sum), built on first use
@@ -404,6 +405,8 @@ struct DustHipPipeline {
   bool ev_valid[4] = {false, false, false, false};  // primary, ao
   bool stats_valid = false;
   bool fused_last = false;  // the last frame ran primary + AO as one kernel: its time is reported under pass 0
+  uint32_t frame_counter = 0;
+  bool timed_frame = false;  // this frame's launches are bracketed by event pairs (see dust_hip_render_frame)
   dust::DevStats* host_stats = nullptr;  // pinned, 8 records: where the counting build's statistics land
   // How the workgroup slots are split while a surfel pass runs beside the next frame's primary / AO kernels: the pipeline's first
   // GI frame runs its surfel pass in place and is timed (P: primary / AO kernels, Q: the pass); once those events have completed --
@@ -759,6 +762,7 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   if (cfg && cfg->lds_root_bytes) c->lds_root_bytes = cfg->lds_root_bytes;
   c->timing = cfg && (cfg->flags & DUST_HIP_CONTEXT_TIMING);
+  c->timing_stride = (cfg && (cfg->flags & DUST_HIP_CONTEXT_TIMING_SPARSE)) ? 4u : 1u;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1343,7 +1347,7 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
     b.gi.sort_keys = sk[0];
     b.gi.sort_vals = sv[0];
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
     if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
       HIP_TRY(dust::launch_surfel_keys(b, st));
       bool in_b = false;
@@ -1369,7 +1373,7 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       b.gi.apply_vals = sv[in_b ? 1 : 0];
       HIP_TRY(dust::launch_surfel_apply(b, 3, st));
     }
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
+    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   return DUST_OK;
 }
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
@@ -1462,6 +1466,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
+  // An event pair around a launch costs the stream ~6 us per record (a marker packet the next dispatch waits behind): 5 % of a
+  // 0.23 ms frame. A context that only wants averages over a run of frames (bench.py) times every 4th frame's launches.
+  p->timed_frame = ctx->timing && (p->frame_counter++ % ctx->timing_stride) == 0;
   // while a surfel pass may be running on the second stream, the primary / AO kernels leave it its share of the slots (persistent
   // launches hold what they get: whichever came first would otherwise own the GPU until it is done)
   // The share: the pass's rays against the pixel passes' (pool x 18 surfel-ray costs to 3 rays per pixel, which puts the castle at
@@ -1515,25 +1522,25 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
     HIP_TRY(dust::launch_primary_ao(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
+    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
     HIP_TRY(dust::launch_primary(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; }
+    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
     take_counters(p, 1, a);
     { DustStatus os = order_tiles(p, 1, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(1), st));
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(1), st));
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
+    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
   if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p1, st));
   if (fp->passes & DUST_PASS_FINAL_GATHER) {
@@ -1561,9 +1568,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
-    if (ctx->timing) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
     HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, pool, st));
-    if (ctx->timing) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
+    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
     // On the context's second stream, behind this frame's final gather (see DustHipContext::side): the pass is a handful of

@@ -174,6 +174,8 @@ typedef struct DustHipConfig {
   uint32_t flags;           /* DUST_HIP_CONTEXT_* */
 } DustHipConfig;
 #define DUST_HIP_CONTEXT_TIMING 1u /* record hipEvents around every pass (dust_hip_pipeline_pass_stats) */
+#define DUST_HIP_CONTEXT_TIMING_SPARSE 2u /* with TIMING: around the launches of every 4th frame only (dust_hip_pipeline_kernel_times then
+                                             averages over those): an event record costs the stream ~6 us, 5 % of a 0.23 ms frame */
 
 /* RenderPlugin::build -> device creation (crates/render/src/lib.rs:58-134) */
 DustStatus dust_hip_context_create(const DustHipConfig*, DustHipContext** out);

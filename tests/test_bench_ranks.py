@@ -72,13 +72,19 @@ class StubBackend:
         self.torch, self.L, self.sharding, self.synth = torch, L, sharding, synth
         self.rank, self.local_rank, self.world = rank, rank, world
         self.device = torch.device("cpu")
-        self.pipe = StubPipe()
+        self.pipes = []
     def sync(self): pass
-    def build_scene(self, args):
-        return {"scene": None, "cam": None, "sky": None, "info": {"n_models": 1, "n_instances": 1, "n_voxels": 1}, "n_bricks": 1,
-                "t_load": 0.0, "desc": None, "deep": None}
-    def make_pipeline(self, w, h): return self.pipe
+    def open_lane(self, args, first):
+        import contextlib
+        lane = bench.Lane()
+        lane.sc = {"scene": None, "cam": None, "sky": None, "info": {"n_models": 1, "n_instances": 1, "n_voxels": 1}, "n_bricks": 1,
+                   "t_load": 0.0, "desc": None, "deep": None}
+        lane.pipe = StubPipe()
+        lane.enter = contextlib.nullcontext
+        self.pipes.append(lane.pipe)
+        return lane
     def noise(self): return None, None
+    def sky_struct(self, sky): return sky
     def bind_target(self, pipe, tensor): pipe.target = tensor
     def alias_exchange(self, ex):
         return (torch.zeros(ex.pool_size, dtype=torch.int32), torch.zeros(ex.touched_rows * ex.width, dtype=torch.int32),
@@ -107,13 +113,16 @@ if rank == 0:
     assert weak["rays_per_step_all_gpus"] == 2 * (W * H * classes + extra), weak
     assert len(strong["per_rank_kernel_ms"]) == 2 and len(weak["per_rank_kernel_ms"]) == 2
     assert "bands x2" in strong["parallelism"] and "spp x2" in weak["parallelism"]
+    calls = [c for p_ in be.pipes for c in p_.calls]
+    assert out["curves"]["strong"]["frames_in_flight"] == (1 if gi else 4) and out["curves"]["weak"]["frames_in_flight"] == 1
+    assert len(be.pipes) == (1 if gi else 4)      # row bands of a non-GI workload: four frames in flight, a pipeline each
     if gi:
-        assert "clear" in be.pipe.calls and ("export", 0, 24) in be.pipe.calls
+        assert "clear" in calls and ("export", 0, 24) in calls
     print("BENCH_RANKS_OK", json.dumps(out)[:200])
 else:
     assert out is None
     if workload == "gi":
-        assert ("export", 24, 40) in be.pipe.calls   # the shorter, padded band
+        assert ("export", 24, 40) in be.pipes[0].calls   # the shorter, padded band
 dist.barrier()
 dist.destroy_process_group()
 '''
