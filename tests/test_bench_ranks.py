@@ -175,3 +175,32 @@ def test_bench_teapot_cpu_line():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
     assert j["n_gpus"] == 0 and j["value"] > 0 and j["config"]["rays_per_step"]["primary"] == 256 * 256
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_line_on_the_gpu_keeps_the_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` as the driver runs it: one JSON line with the contract's keys, `roofline` and
+    `cpu_baseline`, and numbers that are consistent with each other."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--cpu-rows", "64"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 8 and j["warmup"] == 2 and j["unit"] == "Mrays/s" and j["vs_baseline"] is None
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0.0 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    assert 0.0 < rf["kernel_ms"] <= j["ms_per_step"] * 1.05          # a launch cannot take longer than the step that holds it
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3
+    rays = j["config"]["rays_per_step_all_gpus"]
+    assert abs(j["value"] - rays / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 2e-3
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
