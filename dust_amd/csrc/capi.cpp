@@ -1583,8 +1583,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     // taken by the first, the second would simply run after it)
     const uint32_t side_resident = std::max(8u, (resident * share / 100u) & ~7u);
     DustStatus rs = run_surfel_pass(p, a, fp->passes, count, aside ? ctx->side : st, aside ? side_resident : resident);
+    // (whatever of the pass was enqueued -- all of it, or what came before a failed launch -- is waited for by the next user of the GI state)
+    if (aside) { ctx->side_busy = true; const hipError_t re = hipEventRecord(ctx->ev_side_done, ctx->side); if (rs == DUST_OK && re != hipSuccess) rs = hip_fail(re, "hipEventRecord(ev_side_done)"); }
     if (rs != DUST_OK) return rs;
-    if (aside) { HIP_TRY(hipEventRecord(ctx->ev_side_done, ctx->side)); ctx->side_busy = true; }
     if (calibrate) { HIP_TRY(hipEventRecord(p->side_cal.q1, st)); p->side_cal.state = 1; }
   }
   if (fp->passes & DUST_PASS_ACCUMULATE) {
