@@ -417,6 +417,18 @@ __device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, u
   return true;
 }
 
+constexpr uint32_t kDirectCell = 0x100u;  // find_brick's cell_log2 flag: a 16-cell whose bricks the walk tests one by one
+#ifndef DUST_DIRECT_BRICKS
+#define DUST_DIRECT_BRICKS 4
+#endif
+constexpr uint32_t kDirectBricks = DUST_DIRECT_BRICKS;  // ... when it holds at most this many
+// ... and when the packet's rays are neighbours (ray types 0 and 1: camera, sun and AO rays), which then meet their sparse cells on
+// the same trips: 2.30 -> 1.91 ms for the 4096^3 tree's primary + AO kernel. The gather and surfel rays of a packet each meet
+// theirs on a trip of their own, every one of which then lasts as long as the longer direct test: 1.84 -> 2.13 ms. Not for them.
+#ifndef DUST_WHOLE_CELLS_MAX_RT
+#define DUST_WHOLE_CELLS_MAX_RT 1
+#endif
+template <int RT> constexpr bool kWholeCells = RT <= DUST_WHOLE_CELLS_MAX_RT;
 // Deepest occupied cell containing voxel (x,y,z). Returns the brick's 64-bit occupancy (0 = no brick),
 // cell_log2 = size of the cell that was found empty (2 when a brick exists), key = mid_index*64 + child bit,
 // which orders bricks exactly like the block index does (both are depth-first).
@@ -424,7 +436,9 @@ __device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, u
 // ray (DEEP variants): the object-space ray o + t d with inv_d = 1 / d, for the occupied-box test of a 16-cell
 template <int MODE, class Model>
 __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
-                                               MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d) {
+                                               MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d, bool whole_cells = false) {
+  // count: the call comes from the walk itself (its traversal is tallied), not from a neighbour visit.
+  // whole_cells: hand a sparse 16-cell back whole (below) -- the walks of the camera, sun and AO rays ask for that
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
   if (k16 != mc.key) {
     uint32_t mid_index;
@@ -458,6 +472,12 @@ __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int
         }
         mid_index = cell.x;
         mc.mask4 = ((uint64_t)cell.w << 32) | cell.z;
+#ifndef DUST_NO_DIRECT_CELLS
+        // A 16-cell with a handful of bricks (at 1 % occupancy: one in 72 % of the occupied cells, two in 22 %) is not walked
+        // 4-cell by 4-cell: the walk gets the whole cell back (kDirectCell), tests each of its bricks whose grown box the ray
+        // meets (test_cell_bricks) and leaves the 16-cell in one step.
+        if (whole_cells && __popcll(mc.mask4) <= (int)kDirectBricks) { mc.key = k16; mc.mid = mid_index; cell_log2 = 4u | kDirectCell; return 0; }
+#endif
       } else {
         if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return 0; }
         if (COUNT && count) st.upper_descents += 1;
@@ -469,7 +489,15 @@ __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int
   const uint32_t bit = ((uint32_t)((x >> 2) & 3) << 4) | ((uint32_t)((y >> 2) & 3) << 2) | (uint32_t)((z >> 2) & 3);
   key = mc.mid * 64u + bit;
   cell_log2 = 2;
-  if (DEEP && !((mc.mask4 >> bit) & 1ull)) return 0;  // empty 4-cell, known without a load
+  if (DEEP && !((mc.mask4 >> bit) & 1ull)) {  // empty 4-cell, known without a load
+#ifndef DUST_NO_OCTANT_SKIP
+    // ... and if the seven 4-cells that share its octant of the 16-cell are empty as well (bits {0,1} x {0,4} x {0,16} above the
+    // octant's corner: at 1 % occupancy a 16-cell holds one or two bricks, so 92 % of the octants are), the walk leaves the
+    // 8-cell in one step. Two shifts and a compare on a mask that is in registers already.
+    if (!(mc.mask4 & (0x0000000000330033ull << (bit & 0x2Au)))) cell_log2 = 3;
+#endif
+    return 0;
+  }
   const uint64_t mask = m.dense_mask[key];
   if (COUNT && count && mask != 0) st.mid_descents += 1;
   return mask;
@@ -510,6 +538,32 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
     if (inst > best.inst || (inst == best.inst && key >= best.block)) return;
   }
   best.found = true; best.t = t; best.inst = inst; best.block = key; best.voxel = vox;
+}
+
+// DEEP variants: every brick of the sparse 16-cell around ijk (mc holds its mid index and child mask) that the ray can touch.
+// The 0.05-voxel growth of the brick's box is far more than the walk's tolerance delta <= 1e-2 (same argument as the
+// occupied-box test in find_brick), so this is a superset of what the 4-cell walk and its neighbour visits would have tested
+// inside the cell; bricks that start beyond the best hit so far are skipped before their mask is loaded.
+template <int RT, int MODE>
+__device__ __forceinline__ void test_cell_bricks(ModelRef m, uint32_t inst, const MidCache& mc, int x, int y, int z, V3 o, V3 d, V3 inv_d,
+                                                 float tmin, float tmax, Hit& best, LaneStats& st) {
+  uint64_t mm = mc.mask4;
+  const int gx = x & ~15, gy = y & ~15, gz = z & ~15;
+  while (mm != 0) {
+    const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+    mm &= mm - 1ull;
+    const int bx = gx + (int)((bit >> 4) & 3u) * 4, by = gy + (int)((bit >> 2) & 3u) * 4, bz = gz + (int)(bit & 3u) * 4;
+    const float lo[3] = {(float)bx - 0.05f, (float)by - 0.05f, (float)bz - 0.05f};
+    const float hi[3] = {(float)bx + 4.05f, (float)by + 4.05f, (float)bz + 4.05f};
+    float te, tx;
+    if (!slab_box(o, d, inv_d, lo, hi, te, tx)) continue;
+    if (te * (1.0f - 2e-6f) > (best.found ? best.t : tmax)) continue;
+    const uint32_t key = mc.mid * 64u + bit;
+    const uint64_t mask = m.dense_mask[key];
+    if (mask == 0) continue;
+    if (COUNT) st.mid_descents += 1;
+    test_brick<RT, MODE>(mask, inst, key, bx, by, bz, o, d, inv_d, tmin, tmax, best, st);
+  }
 }
 
 // The cold part of the conservative walk (see trace_instance): the entry point of the cell at ijk may lie within delta
@@ -643,7 +697,9 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     // "test, visit neighbours, advance"; the load's latency is covered by ~100 instructions of the wave's own arithmetic.
     uint32_t key;
     PROF_ENTER(P_FIND);
-    const uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d);
+    const uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d, kWholeCells<RT>);
+    bool direct = false;
+    if (DEEP && (cl_main & kDirectCell)) { cl_main = 4; direct = true; }
     PROF_LEAVE(P_FIND);
     // The screen was raised for brick planes (multiples of 4). If the cell turns out to be an empty 16-cell or larger -- or, DEEP,
     // a 16-cell whose occupied box the ray misses by 0.05 voxel, five times the largest delta -- nothing inside it can be hit,
@@ -703,6 +759,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       PROF_COUNT_LANES(P_L_EMPTY16, !have && cl_main > 2);
       PROF_ENTER(P_BRICK);
       if (have) test_brick<RT, MODE>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
+      if (DEEP && direct) test_cell_bricks<RT, MODE>(m, inst, mc, ijk[0], ijk[1], ijk[2], o, d, inv_d, tmin, tmax, best, st);
       PROF_LEAVE(P_BRICK);
     }
     // Is the entry point within delta of further brick planes? `screen` (worked out when the walk stepped into this
@@ -1050,7 +1107,11 @@ __device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevM
   uint32_t key;
   uint64_t mask;
   if (DEEP) {
-    mask = find_brick<MODE>(*mp, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv);
+    mask = find_brick<MODE>(*mp, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv, kWholeCells<RT>);
+    if (w.cl_main & kDirectCell) {
+      w.cl_main = 4;
+      test_cell_bricks<RT, MODE>(*mp, w.inst, w.mc, w.ijk[0], w.ijk[1], w.ijk[2], w.o, w.d, w.inv, tmin, tmax, best, st);
+    }
   } else {
     ModelLite lm;
     lm.root = w.root; lm.dense_mask = w.dense_mask; lm.lds_slot = w.lds_slot; lm.l2 = nullptr; lm.l2_cells = nullptr;
