@@ -47,6 +47,7 @@ NAMES = ("primary", "sun_shadow", "ambient_occlusion", "final_gather", "surfel_s
 # few milliseconds -- a 20-step run after 5 warm-up frames read 11 % low in round 2.
 SETTLE_STEPS = 64
 SETTLE_SECONDS = 0.3   # ... and at least this long, back to back, so that the timed region starts on a GPU at its sustained clocks
+SETTLE_MAX_STEPS = 20000
 
 
 def parse(argv=None):
@@ -326,9 +327,22 @@ def measure_curve(be, dist, args, lanes, shard):
 
     gc.collect()
     gc.disable()  # no collector pause between two launches of the timed loop -- nor between the settle frames and the timed region
+    # Settle frames. Every step holds a collective when world > 1, so every rank must run the SAME number of them: a count from
+    # a rank's own clock would leave the ranks a few steps apart and the job hung in its gather. The fixed part first; then the
+    # ranks agree (max) on how many more make up SETTLE_SECONDS at the rate the slowest of them measured.
     settle = 0
     t_settle = time.perf_counter()
-    while settle < max(args.warmup, SETTLE_STEPS) or (time.perf_counter() - t_settle < SETTLE_SECONDS and settle < 20000):
+    while settle < max(args.warmup, SETTLE_STEPS):
+        step(1 + settle)
+        settle += 1
+    barrier()
+    spent = time.perf_counter() - t_settle
+    more = 0 if spent >= SETTLE_SECONDS else min(SETTLE_MAX_STEPS, int((SETTLE_SECONDS - spent) / max(spent / max(settle, 1), 1e-6)) + 1)
+    if world > 1:
+        agreed = torch.tensor([more], dtype=torch.int64, device=be.device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+        more = int(agreed.item())
+    for _ in range(more):
         step(1 + settle)
         settle += 1
     barrier()
@@ -497,6 +511,7 @@ def run_rank(args, be, dist):
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
                                   "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"],
+                                  "settle_steps": c["settle"],
                                   "per_rank_kernel_ms": [[round(x, 4) for x in v] for v in c["per_rank"]]} for c in curves.values()},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -96,7 +96,10 @@ class StubBackend:
 args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", str(W), "--height", str(H),
                     "--workload", workload, "--no-cpu-baseline"])
 bench.SETTLE_STEPS = 2
-bench.SETTLE_SECONDS = 0.0
+# the ranks' own clocks disagree about how many more settle frames are due (rank 0: as many as allowed, rank 1: none); every step
+# holds a collective, so they must settle on one count or the job hangs
+bench.SETTLE_SECONDS = 30.0 if rank == 0 else 0.0
+bench.SETTLE_MAX_STEPS = 5
 be = StubBackend()
 out = bench.run_rank(args, be, dist)
 if rank == 0:
@@ -116,6 +119,7 @@ if rank == 0:
     calls = [c for p_ in be.pipes for c in p_.calls]
     assert out["curves"]["strong"]["frames_in_flight"] == (1 if gi else 4) and out["curves"]["weak"]["frames_in_flight"] == 1
     assert len(be.pipes) == (1 if gi else 4)      # row bands of a non-GI workload: four frames in flight, a pipeline each
+    assert strong["settle_steps"] == weak["settle_steps"] == 2 + 5, (strong, weak)
     if gi:
         assert "clear" in calls and ("export", 0, 24) in calls
     print("BENCH_RANKS_OK", json.dumps(out)[:200])
