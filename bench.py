@@ -254,6 +254,8 @@ def measure_curve(be, dist, args, lanes, shard):
     # rank whose launch is held up by one expensive tile fills the rest of the GPU with the next frames' tiles.
     D = len(lanes)
     S = max(2, D)
+    for lane in lanes:
+        lane.pipe.set_frames_in_flight(D)  # D launches side by side, each on 1/D of the workgroup slots
     fixed_targets = S == D  # every lane renders into one target of its own: bound once, not per step
     targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device=be.device) for _ in range(S)]
     if slices:

@@ -170,6 +170,7 @@ SYMBOLS = {
     "dust_hip_tone_map": (C.c_int, [_P, C.POINTER(ToneMapParams)]),
     "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
+    "dust_hip_pipeline_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
     "dust_hip_pipeline_set_denoiser": (C.c_int, [_P, C.POINTER(DenoiseParams)]),
     "dust_hip_pipeline_restart_denoiser": (C.c_int, [_P]),
     "dust_hip_device_eval": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),

@@ -440,6 +440,10 @@ class StandardPipeline:
     def clear(self):
         L.check(self._lib.dust_hip_pipeline_clear(self._h))
 
+    def set_frames_in_flight(self, n):
+        """the caller keeps n frames in flight on this device (a pipeline and a context each): launches take 1/n of the workgroup slots"""
+        L.check(self._lib.dust_hip_pipeline_set_frames_in_flight(self._h, n))
+
     def set_denoiser(self, max_accumulated_frames=30, disocclusion_threshold=0.01, antilag_sigma_scale=2.0, antilag_power=0.8,
                      max_blur_radius=15.0):
         """ReblurSettings (nrd.rs:768-785) for DUST_PASS_DENOISE"""

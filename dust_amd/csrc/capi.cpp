@@ -360,6 +360,7 @@ struct Tuning {
 struct DustHipPipeline {
   DustHipContext* ctx = nullptr;  // retained
   Tuning tune;
+  uint32_t frames_in_flight = 1;  // dust_hip_pipeline_set_frames_in_flight
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   void* bound[DUST_PLANE_COUNT] = {};  // caller-owned storage a plane was redirected to (dust_hip_pipeline_bind_plane), or null
@@ -1496,7 +1497,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   }
   const uint32_t side_slots = ctx->side_busy ? std::max(8u, (resident * share / 100u) & ~7u) : 0u;
   const uint32_t main_resident = std::max(8u, resident - std::min(resident - 8u, side_slots));
-  const uint32_t grid = std::max(8u, std::min<uint32_t>(main_resident, (total_tiles + 7) / 8));
+  // (a caller with several frames in flight, each on a pipeline of its own: this launch takes its share of the slots -- whole
+  // rounds over the 8 XCDs -- and leaves the rest to the others, dust_hip_pipeline_set_frames_in_flight)
+  const uint32_t frame_slots = p->frames_in_flight > 1 ? std::max(8u, (main_resident / p->frames_in_flight) & ~7u) : main_resident;
+  const uint32_t grid = std::max(8u, std::min<uint32_t>(frame_slots, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
     auto mix = [&k](const void* data, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(data); for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
@@ -1902,6 +1906,12 @@ DustStatus dust_hip_pipeline_set_denoiser(DustHipPipeline* p, const DustHipDenoi
 DustStatus dust_hip_pipeline_restart_denoiser(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   p->have_history = false;  // DenoiserEvent::Restart (nrd.rs:749-755): the next frame starts a new accumulation
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_set_frames_in_flight(DustHipPipeline* p, uint32_t n) {
+  if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
+  if (n < 1 || n > 16) return fail(DUST_ERR_INVALID_ARGUMENT, "frames in flight: 1..16");
+  p->frames_in_flight = n;
   return DUST_OK;
 }
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {

@@ -326,6 +326,8 @@ class StandardPipeline {
     check(dust_hip_pipeline_set_denoiser(h_, &dp));
   }
   void restart_denoiser() { check(dust_hip_pipeline_restart_denoiser(h_)); }
+  // the host's frames in flight (rhyolite_bevy/src/lib.rs:58): launches then share the device instead of queueing
+  void set_frames_in_flight(uint32_t n) { check(dust_hip_pipeline_set_frames_in_flight(h_, n)); }
   void bind_plane(DustHipPlane plane, void* device_ptr, size_t bytes) { check(dust_hip_pipeline_bind_plane(h_, plane, device_ptr, bytes)); }
   template <class T>
   std::vector<T> read_plane(DustHipPlane plane) {

@@ -39,6 +39,7 @@ class StubPipe:
         self.width, self.height = W, H
         self.n_render = 0
     def set_noise(self, *a): pass
+    def set_frames_in_flight(self, n): self.calls.append(("in_flight", n))
     def configure_gi(self, *a): self.calls.append("configure_gi")
     def clear(self): self.calls.append("clear")
     def render(self, scene, cam, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
@@ -120,6 +121,7 @@ if rank == 0:
     assert out["curves"]["strong"]["frames_in_flight"] == (1 if gi else 4) and out["curves"]["weak"]["frames_in_flight"] == 1
     assert len(be.pipes) == (1 if gi else 4)      # row bands of a non-GI workload: four frames in flight, a pipeline each
     assert strong["settle_steps"] == weak["settle_steps"] == 2 + 5, (strong, weak)
+    assert ("in_flight", 1 if gi else 4) in calls
     if gi:
         assert "clear" in calls and ("export", 0, 24) in calls
     print("BENCH_RANKS_OK", json.dumps(out)[:200])

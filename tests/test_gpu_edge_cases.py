@@ -137,3 +137,29 @@ def test_model_edit_behind_a_surfel_pass_in_flight():
 
     for x, y in zip(run(True), run(False)):
         assert np.array_equal(x, y)
+
+
+def test_frames_in_flight_changes_no_result():
+    """dust_hip_pipeline_set_frames_in_flight only sizes the launches: two pipelines of two contexts rendering side by side on a
+    quarter of the slots each produce the planes of a launch that had the device to itself; out-of-range values are refused."""
+    desc = P.small_scene(seed=11, n_models=3, n_instances=9)
+    cam, sky = P.camera_for((100.0, 70.0, -90.0)), P.sky_state()
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    pipe = _pipe(ctx, 200, 120)
+    pipe.render(scene, cam, sky, PA, frame_index=1, rand=21)
+    want = _planes(pipe)
+    ctxs = [api.Context(device=0) for _ in range(2)]
+    scenes = [P.hip_scene(c, desc) for c in ctxs]
+    pipes = [_pipe(c, 200, 120) for c in ctxs]
+    for p_ in pipes:
+        p_.set_frames_in_flight(4)
+    for f in range(3):
+        for p_, s_ in zip(pipes, scenes):
+            p_.render(s_, cam, sky, PA, frame_index=1, rand=21)
+    for p_ in pipes:
+        for x, y in zip(want, _planes(p_)):
+            assert np.array_equal(x, y)
+    for bad in (0, 17):
+        with pytest.raises(Exception):
+            pipe.set_frames_in_flight(bad)
