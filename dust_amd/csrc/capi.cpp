@@ -372,6 +372,7 @@ struct DustHipPipeline {
   struct TileHistory {
     DeviceBuffer cost, order;
     uint32_t tiles_x = 0, tiles_y = 0, capacity = 0, age = 0;
+    uint32_t refresh = 8;    // launches between two measurements of a view that stands still (kOrderRefresh, doubling up to kOrderRefreshMax)
     uint64_t view = 0;       // view_key() of the launch the costs / the order were taken under
     bool recorded = false;   // cost[] holds the previous launch's measurements
     bool ordered = false;    // order[] is a valid permutation of this tile grid
@@ -1291,7 +1292,9 @@ extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_
 // While the view stands still (same camera, scene revision, sun and rows) the costs do too: the order is kept and re-measured
 // only every kOrderRefresh launches, which takes k_tile_order (~8 us) and the cost recording out of most frames; a moving view
 // measures and re-orders on every launch.
-constexpr uint32_t kOrderRefresh = 8;
+// An order that a re-measurement of the same view has just confirmed is trusted for twice as long, up to 64 launches (the GI
+// kernels' costs drift as the hash fills: they keep being looked at).
+constexpr uint32_t kOrderRefresh = 8, kOrderRefreshMax = 64;
 static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a, hipStream_t st) {
   a.tile_order = nullptr; a.tile_cost = nullptr;
   if (p->tune.no_tile_order) return DUST_OK;
@@ -1316,9 +1319,11 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
   }
   if (h.ordered) a.tile_order = static_cast<const uint32_t*>(h.order.p);
   const bool still = h.ordered && h.view == p->view_key;
-  if (!still || h.age + 1 >= kOrderRefresh) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
+  if (!still) h.refresh = kOrderRefresh;
+  if (!still || h.age + 1 >= h.refresh) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
     a.tile_cost = static_cast<uint32_t*>(h.cost.p);
     h.recorded = true; h.measured = true;
+    if (still) h.refresh = std::min(kOrderRefreshMax, h.refresh * 2u);
   }
   h.view = p->view_key;
   return DUST_OK;

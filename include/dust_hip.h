@@ -315,7 +315,7 @@ DustStatus dust_hip_pipeline_kernel_times(DustHipPipeline*, int mark, float ms_s
 /* Work distribution feedback. The traversal kernels are persistent launches whose tiles (8 x 8 pixel packets; 64-entry chunks of
  * the regrouped gather and surfel lists) cost very different amounts; a launch records the shader-clock cycles each tile took,
  * and the next launch of the same pass hands its tiles out most expensive first (per XCD band), so that the launch does not end on a
- * few late, slow tiles. While camera, scene, sun and row band stay as they were the order is kept and re-measured every 8th launch
+ * few late, slow tiles. While camera, scene, sun and row band stay as they were the order is kept and re-measured every 8th launch at first, then every 16th, 32nd, 64th
  * only. The order never changes a result. This reads the map of the pass's last MEASURED launch (a profiling heat map):
  * pass_kind 0 primary (or fused primary + AO), 1 AO, 2 final gather, 3 surfel trace; cycles may be NULL to query the grid only
  * (tiles_x x tiles_y, 0 x 0 before the first launch). DUST_HIP_NO_TILE_ORDER=1 switches the feedback off. */
