@@ -436,7 +436,9 @@ template <int RT> constexpr bool kWholeCells = RT <= DUST_WHOLE_CELLS_MAX_RT;
 // ray (DEEP variants): the object-space ray o + t d with inv_d = 1 / d, for the occupied-box test of a 16-cell
 template <int MODE, class Model>
 __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int z, uint32_t& cell_log2, uint32_t& key,
-                                               MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d, bool whole_cells = false) {
+                                               MidCache& mc, LaneStats& st, bool count, V3 ray_o, V3 ray_d, V3 ray_inv_d, bool whole_cells = false,
+                                               bool zero_axis = true) {
+  // zero_axis (wave-uniform): some ray of the wave may have a zero direction component -- the occupied-box test then takes the general slab test
   // count: the call comes from the walk itself (its traversal is tallied), not from a neighbour visit.
   // whole_cells: hand a sparse 16-cell back whole (below) -- the walks of the camera, sun and AO rays ask for that
   const int k16 = ((x >> 4) << 16) | ((y >> 4) << 8) | (z >> 4);
@@ -468,16 +470,18 @@ __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int
           const float hi[3] = {bx + 4.0f * (float)(((cell.y >> 6) & 3u) + 1u) + 0.05f, by + 4.0f * (float)(((cell.y >> 8) & 3u) + 1u) + 0.05f,
                                bz + 4.0f * (float)(((cell.y >> 10) & 3u) + 1u) + 0.05f};
           float te, tx;
-          if (!slab_box(ray_o, ray_d, ray_inv_d, lo, hi, te, tx)) { cell_log2 = 4; return 0; }
+          if (!(zero_axis ? slab_box(ray_o, ray_d, ray_inv_d, lo, hi, te, tx) : slab_box_nonzero(ray_o, ray_inv_d, lo, hi, te, tx))) { cell_log2 = 4; return 0; }
         }
         mid_index = cell.x;
-        mc.mask4 = ((uint64_t)cell.w << 32) | cell.z;
 #ifndef DUST_NO_DIRECT_CELLS
         // A 16-cell with a handful of bricks (at 1 % occupancy: one in 72 % of the occupied cells, two in 22 %) is not walked
         // 4-cell by 4-cell: the walk gets the whole cell back (kDirectCell), tests each of its bricks whose grown box the ray
         // meets (test_cell_bricks) and leaves the 16-cell in one step.
-        if (whole_cells && __popcll(mc.mask4) <= (int)kDirectBricks) { mc.key = k16; mc.mid = mid_index; cell_log2 = 4u | kDirectCell; return 0; }
+        // (key = the cell's mid node, return value = its child mask; the walk's cache is left as it is)
+        const uint64_t cm = ((uint64_t)cell.w << 32) | cell.z;
+        if (whole_cells && __popcll(cm) <= (int)kDirectBricks) { key = mid_index; cell_log2 = 4u | kDirectCell; return cm; }
 #endif
+        mc.mask4 = ((uint64_t)cell.w << 32) | cell.z;
       } else {
         if (!n16_child(m.l2 + (size_t)l2 * kN16Bytes, -1, idx2, mid_index)) { cell_log2 = 4; return 0; }
         if (COUNT && count) st.upper_descents += 1;
@@ -540,14 +544,14 @@ __device__ __forceinline__ void test_brick(uint64_t mask, uint32_t inst, uint32_
   best.found = true; best.t = t; best.inst = inst; best.block = key; best.voxel = vox;
 }
 
-// DEEP variants: every brick of the sparse 16-cell around ijk (mc holds its mid index and child mask) that the ray can touch.
+// DEEP variants: every brick of the sparse 16-cell around ijk (mid node `mid`, child mask `child_mask`) that the ray can touch.
 // The 0.05-voxel growth of the brick's box is far more than the walk's tolerance delta <= 1e-2 (same argument as the
 // occupied-box test in find_brick), so this is a superset of what the 4-cell walk and its neighbour visits would have tested
 // inside the cell; bricks that start beyond the best hit so far are skipped before their mask is loaded.
 template <int RT, int MODE>
-__device__ __forceinline__ void test_cell_bricks(ModelRef m, uint32_t inst, const MidCache& mc, int x, int y, int z, V3 o, V3 d, V3 inv_d,
-                                                 float tmin, float tmax, Hit& best, LaneStats& st) {
-  uint64_t mm = mc.mask4;
+__device__ __forceinline__ void test_cell_bricks(ModelRef m, uint32_t inst, uint32_t mid, uint64_t child_mask, int x, int y, int z, V3 o, V3 d, V3 inv_d,
+                                                 float tmin, float tmax, Hit& best, LaneStats& st, bool zero_axis) {
+  uint64_t mm = child_mask;
   const int gx = x & ~15, gy = y & ~15, gz = z & ~15;
   while (mm != 0) {
     const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
@@ -556,9 +560,9 @@ __device__ __forceinline__ void test_cell_bricks(ModelRef m, uint32_t inst, cons
     const float lo[3] = {(float)bx - 0.05f, (float)by - 0.05f, (float)bz - 0.05f};
     const float hi[3] = {(float)bx + 4.05f, (float)by + 4.05f, (float)bz + 4.05f};
     float te, tx;
-    if (!slab_box(o, d, inv_d, lo, hi, te, tx)) continue;
+    if (!(zero_axis ? slab_box(o, d, inv_d, lo, hi, te, tx) : slab_box_nonzero(o, inv_d, lo, hi, te, tx))) continue;
     if (te * (1.0f - 2e-6f) > (best.found ? best.t : tmax)) continue;
-    const uint32_t key = mc.mid * 64u + bit;
+    const uint32_t key = mid * 64u + bit;
     const uint64_t mask = m.dense_mask[key];
     if (mask == 0) continue;
     if (COUNT) st.mid_descents += 1;
@@ -595,30 +599,35 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
   const int ijk[3] = {i0, i1, i2};
   uint32_t near_neg = 0, near_pos = 0;  // bit a: entry point within delta of the cell's low / high plane on axis a
   uint32_t unstepped_near = 0;
-  const int G = DEEP && cell_log2 >= 4u ? 16 : 4;  // (the two-level kernels keep the constant: the refinement below is the DEEP variants')
+  // DEEP: the walk's cell may be a whole 16-cell that holds nothing untested (empty, missed by more than any delta, or tested brick
+  // by brick). Bricks INSIDE it need no visit; a neighbour cell lies outside it iff one of its axes crosses a face of the 16-cell --
+  // a stepped axis (the ray came in through that face) or an unstepped one whose near plane is a multiple of 16. The planes
+  // themselves are still brick planes (multiples of 4): an entry point on the 16-cell's z face within delta of x = 900 has the
+  // brick across BOTH planes to test, although x = 900 is no face of the 16-cell (tools/stress_parity.py STRESS_DEEP, seed 20833).
+  const bool whole16 = DEEP && cell_log2 >= 4u;
+  uint32_t leaves16 = stepped;  // axes on which the other side is outside the 16-cell
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const int blo = (int)m.bmin[a], bhi = (int)m.bmax[a] - 1;  // voxel range that holds bricks (tight bounds, multiples of 4)
     const float p = oo[a] + dd[a] * t;
     const float delta = 1e-6f * ((fabsf(oo[a]) + fabsf(p)) + 16.0f);
-    // The cell the walk is in: a brick cell, or an empty 16-cell (or a larger one, or a 16-cell whose bricks the ray misses
-    // by more than any delta: DEEP) -- nothing inside THAT can be hit, so only its own faces have bricks behind them.
-    const int b0 = ijk[a] & ~(G - 1);
+    const int b0 = ijk[a] & ~3;
     const float q = p - (float)b0;
     // a plane only matters if bricks can exist on its far side
-    if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo) near_neg |= 1u << a; } else if (b0 + G <= bhi) near_pos |= 1u << a; }
-    else if (q <= delta) { if (b0 - 1 >= blo) { near_neg |= 1u << a; unstepped_near |= 1u << a; } }
-    else if (q >= (float)G - delta) { if (b0 + G <= bhi) { near_pos |= 1u << a; unstepped_near |= 1u << a; } }
+    if (stepped & (1u << a)) { if (dd[a] > 0.0f) { if (b0 - 1 >= blo) near_neg |= 1u << a; } else if (b0 + 4 <= bhi) near_pos |= 1u << a; }
+    else if (q <= delta) { if (b0 - 1 >= blo) { near_neg |= 1u << a; unstepped_near |= 1u << a; if ((b0 & 15) == 0) leaves16 |= 1u << a; } }
+    else if (q >= 4.0f - delta) { if (b0 + 4 <= bhi) { near_pos |= 1u << a; unstepped_near |= 1u << a; if (((b0 + 4) & 15) == 0) leaves16 |= 1u << a; } }
   }
   const uint32_t nearm = near_neg | near_pos;
   if (unstepped_near != 0 || __popc(stepped & nearm) > 1) {
 #pragma unroll 1
     for (uint32_t sub = 1; sub < 8; ++sub) {  // one visit per non-empty subset of the near axes
       if ((sub & ~nearm) != 0 || (stepped != 0 && sub == stepped)) continue;  // sub == stepped: the cell we came from
+      if (whole16 && (sub & leaves16) == 0) continue;                         // a cell of the 16-cell the walk is in: nothing untested there
       int c[3] = {ijk[0], ijk[1], ijk[2]};
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-        if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~(G - 1)) - 1 : (ijk[a] & ~(G - 1)) + G;
+        if (sub & (1u << a)) c[a] = (near_neg & (1u << a)) ? (ijk[a] & ~3) - 1 : (ijk[a] & ~3) + 4;
       uint32_t cl2, key;
       const uint64_t mask = find_brick<MODE>(m, c[0], c[1], c[2], cl2, key, mc, st, false, o, d, inv_d);
       if (mask != 0) test_brick<RT, MODE>(mask, inst, key, c[0] & ~3, c[1] & ~3, c[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
@@ -681,6 +690,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   uint32_t cl_main = 2;
   MidCache mc;
   mc.key = -1; mc.mid = 0; mc.mask4 = 0;
+  const bool zero_axis = DEEP && __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this visit)
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
@@ -697,24 +707,46 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     // "test, visit neighbours, advance"; the load's latency is covered by ~100 instructions of the wave's own arithmetic.
     uint32_t key;
     PROF_ENTER(P_FIND);
-    const uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d, kWholeCells<RT>);
+    uint64_t mask = find_brick<MODE>(m, ijk[0], ijk[1], ijk[2], cl_main, key, mc, st, true, o, d, inv_d, kWholeCells<RT>, zero_axis);
     bool direct = false;
-    if (DEEP && (cl_main & kDirectCell)) { cl_main = 4; direct = true; }
+    uint32_t cell_mid = 0;
+    uint64_t cell_mask = 0;
+    if (DEEP && (cl_main & kDirectCell)) { cl_main = 4; direct = true; cell_mid = key; cell_mask = mask; mask = 0; }
     PROF_LEAVE(P_FIND);
-    // The screen was raised for brick planes (multiples of 4). If the cell turns out to be an empty 16-cell or larger -- or, DEEP,
-    // a 16-cell whose occupied box the ray misses by 0.05 voxel, five times the largest delta -- nothing inside it can be hit,
-    // and only planes that are ITS faces (multiples of 16) can have bricks behind them: look again at that granularity.
-    // (On the 4096^3 stress tree three quarters of the steps cross such cells and one wave trip in seven made the call; in the
-    // two-level kernels the call is rare and the extra test cost the surfel pass 3 %: DEEP variants only.)
+    // DEEP, screen raised, and the cell is a whole 16-cell with nothing untested in it (empty, missed, or about to be tested brick
+    // by brick): the bricks inside it need no neighbour visit -- but a brick ACROSS the face the ray came in through does, whatever
+    // plane its other axes are near (round 2's kernels looked again at 16-plane granularity only and lost one such brick in 4 000
+    // random deep scenes: tools/stress_parity.py STRESS_DEEP=1, seed 20833). That brick lies in the 16-cell the walk has just
+    // left, whose child mask is what the cache holds -- all zeroes if that cell was itself empty, missed or tested whole (below):
+    // the call is made only if the mask has a brick there, or for the rarer shapes (ties, two near planes, a near 16-plane).
     if (DEEP && __builtin_expect(screen, 0) && cl_main >= 4u) {
-      bool s16 = __popc(stepped) > 1;
+      bool near16 = false, across_needed = true, sided = true;
+      uint32_t near4 = 0;
+      int c[3] = {ijk[0], ijk[1], ijk[2]};
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-        if (!(stepped & (1u << a))) {
-          const float r = (oo[a] + dd[a] * t) * 0.0625f;
-          s16 = s16 | (fabsf(r - rintf(r)) <= near_tol * 0.25f);
+      for (int a = 0; a < 3; ++a) {
+        if (stepped & (1u << a)) {
+          c[a] = dd[a] > 0.0f ? (ijk[a] & ~15) - 1 : (ijk[a] & ~15) + 16;  // back across the face
+        } else {
+          const float pa = oo[a] + dd[a] * t;
+          const float r4 = pa * 0.25f, r16 = pa * 0.0625f;
+          near16 = near16 | (fabsf(r16 - rintf(r16)) <= near_tol * 0.25f);
+          if (fabsf(r4 - rintf(r4)) <= near_tol) {
+            near4 += 1u;
+            const float q = pa - (float)(ijk[a] & ~3);
+            if (q <= 8.0f * near_tol) c[a] = (ijk[a] & ~3) - 1;
+            else if (q >= 4.0f - 8.0f * near_tol) c[a] = (ijk[a] & ~3) + 4;
+            else sided = false;  // (the integer cell and the point disagree about the side: let the exact code look)
+          }
         }
-      screen = s16;
+      }
+      if (stepped == 0u || near4 == 0u) across_needed = false;  // nothing lies across an entered face and near another plane
+      else if (__popc(stepped) == 1 && near4 == 1u && sided) {
+        const int kd = ((c[0] >> 4) << 16) | ((c[1] >> 4) << 8) | (c[2] >> 4);
+        const uint32_t bd = ((uint32_t)((c[0] >> 2) & 3) << 4) | ((uint32_t)((c[1] >> 2) & 3) << 2) | (uint32_t)((c[2] >> 2) & 3);
+        if (kd == mc.key && !((mc.mask4 >> bd) & 1ull)) across_needed = false;
+      }
+      screen = (__popc(stepped) > 1) | near16 | across_needed;
     }
     // leave the cell of size 2^cl_main that contains ijk
     PROF_ENTER(P_ADVANCE);
@@ -759,7 +791,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       PROF_COUNT_LANES(P_L_EMPTY16, !have && cl_main > 2);
       PROF_ENTER(P_BRICK);
       if (have) test_brick<RT, MODE>(mask, inst, key, ijk[0] & ~3, ijk[1] & ~3, ijk[2] & ~3, o, d, inv_d, tmin, tmax, best, st);
-      if (DEEP && direct) test_cell_bricks<RT, MODE>(m, inst, mc, ijk[0], ijk[1], ijk[2], o, d, inv_d, tmin, tmax, best, st);
+      if (DEEP && direct) test_cell_bricks<RT, MODE>(m, inst, cell_mid, cell_mask, ijk[0], ijk[1], ijk[2], o, d, inv_d, tmin, tmax, best, st, zero_axis);
       PROF_LEAVE(P_BRICK);
     }
     // Is the entry point within delta of further brick planes? `screen` (worked out when the walk stepped into this
@@ -778,6 +810,11 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     }
     PROF_LEAVE(P_SCREEN);
     if (stuck || outside) return;
+    // DEEP: a 16-cell left behind with nothing untested in it (empty; missed by 0.05 voxel, so no brick of it comes within delta of
+    // the ray anywhere; or tested whole, so every brick the ray can touch has had its test) goes into the cache with an all-zero
+    // child mask: the next cell's neighbour logic -- the inline test above and visit_neighbours' own lookups -- settles a cell
+    // of it without a load or a call.
+    if (DEEP && cl_main == 4u) { mc.key = ((ijk[0] >> 4) << 16) | ((ijk[1] >> 4) << 8) | (ijk[2] >> 4); mc.mask4 = 0ull; }
     ijk[0] = next_ijk[0]; ijk[1] = next_ijk[1]; ijk[2] = next_ijk[2];
     stepped = next_stepped;
     screen = next_screen;
@@ -1108,24 +1145,15 @@ __device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevM
   uint64_t mask;
   if (DEEP) {
     mask = find_brick<MODE>(*mp, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv, kWholeCells<RT>);
-    if (w.cl_main & kDirectCell) {
+    if (w.cl_main & kDirectCell) {  // (key, mask) = the cell's mid node and child mask
       w.cl_main = 4;
-      test_cell_bricks<RT, MODE>(*mp, w.inst, w.mc, w.ijk[0], w.ijk[1], w.ijk[2], w.o, w.d, w.inv, tmin, tmax, best, st);
+      test_cell_bricks<RT, MODE>(*mp, w.inst, key, mask, w.ijk[0], w.ijk[1], w.ijk[2], w.o, w.d, w.inv, tmin, tmax, best, st, true);
+      mask = 0;
     }
   } else {
     ModelLite lm;
     lm.root = w.root; lm.dense_mask = w.dense_mask; lm.lds_slot = w.lds_slot; lm.l2 = nullptr; lm.l2_cells = nullptr;
     mask = find_brick<MODE>(lm, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv);
-  }
-  if (DEEP && __builtin_expect(w.screen, 0) && w.cl_main >= 4u) {
-    bool s16 = __popc(w.stepped) > 1;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      if (!(w.stepped & (1u << a))) {
-        const float r = (oo[a] + dd[a] * w.t) * 0.0625f;
-        s16 = s16 | (fabsf(r - rintf(r)) <= w.near_tol * 0.25f);
-      }
-    w.screen = s16;
   }
   const int S = 1 << w.cl_main;
   float ta[3], tn = INFINITY;
@@ -2303,6 +2331,9 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
       trace_ray<3, MODE>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
       if (COUNT) add_stats(sun_item ? st_sun : st_cos, cur);
       __builtin_amdgcn_wave_barrier();
+#ifdef DUST_SURFEL_DEBUG  // (never shipped) every surfel ray with its result, for tools/diag/deep_mismatch.py to hand to the oracle one by one
+      if (act) printf("SF %u %d %.9g %.9g %.9g %.9g %.9g %.9g %d %.9g %u %u\n", i, (int)sun_item, org.x, org.y, org.z, dir.x, dir.y, dir.z, (int)h.found, h.t, h.inst, h.block);
+#endif
     }
     ArgsRef ar = reload_args(a0);
     if (sun_item) {  // surfel/nee.rmiss:15-27

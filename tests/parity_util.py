@@ -59,6 +59,35 @@ def small_scene(seed=1, n_models=3, n_instances=5, size=(48, 40, 56)):
     return SceneDesc(models, pal, instances)
 
 
+def clustered_deep_model(seed=7, n_cells=20000, cell_lo=96, cell_hi=160, max_bricks=12):
+    """A 4096^3 model (hierarchy (4,4,2,2)) whose occupied 16-cells -- n_cells of them, drawn inside [cell_lo, cell_hi)^3 in 16-cell
+    units -- hold 1 to max_bricks bricks each: the DEEP kernels test the bricks of a cell with up to four one by one and walk the
+    others 4-cell by 4-cell, and a ray meets both kinds. Returns (blocks, materials, palette) in Tree::iter_leaf order."""
+    rng = np.random.default_rng(seed)
+    cells = np.unique(rng.integers(cell_lo, cell_hi, (n_cells, 3)), axis=0)
+    per = rng.integers(1, max_bricks + 1, len(cells))
+    bricks = []
+    for c, n in zip(cells, per):
+        sub = rng.choice(64, int(n), replace=False)
+        bricks.append(np.stack([c[0] * 4 + (sub >> 4), c[1] * 4 + ((sub >> 2) & 3), c[2] * 4 + (sub & 3)], axis=1))
+    b = np.concatenate(bricks).astype(np.uint64)
+    key = np.zeros(len(b), np.uint64)
+    for shift, bits in ((6, 4), (2, 4), (0, 2)):          # depth first, x slowest at every level
+        lv = [(b[:, a] >> np.uint64(shift)) & np.uint64((1 << bits) - 1) for a in range(3)]
+        key = (key << np.uint64(3 * bits)) | (lv[0] << np.uint64(2 * bits)) | (lv[1] << np.uint64(bits)) | lv[2]
+    b = b[np.argsort(key, kind="stable")]
+    mask = rng.integers(1, 1 << 63, len(b), dtype=np.uint64) | (rng.integers(0, 2, len(b), dtype=np.uint64) << np.uint64(63))
+    sparse = rng.random(len(b)) < 0.25                    # a quarter of the bricks nearly empty: rays pass through them
+    mask[sparse] &= rng.integers(1, 1 << 63, int(sparse.sum()), dtype=np.uint64) & rng.integers(1, 1 << 63, int(sparse.sum()), dtype=np.uint64)
+    mask[mask == 0] = 1
+    blocks = np.zeros(len(b), api.BLOCK_DTYPE)
+    blocks["x"], blocks["y"], blocks["z"], blocks["mask"] = b[:, 0] * 4, b[:, 1] * 4, b[:, 2] * 4, mask
+    counts = np.array([bin(int(m)).count("1") for m in mask], np.uint32)
+    blocks["material_ptr"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
+    mats = rng.integers(0, 255, int(counts.sum()), dtype=np.uint8)
+    return blocks, mats, synth.make_palette(5)
+
+
 def oracle_scene(desc: SceneDesc):
     s = O.Scene()
     for b, m in desc.models:

@@ -104,35 +104,9 @@ def test_config5_deep_tree_gpu_parity():
         assert np.isfinite(g.depth).mean() > 0.05
 
 
-def clustered_deep_desc(seed=7, n_cells=20000):
-    """A 4096^3 model whose occupied 16-cells hold 1 to 12 bricks each, inside the 1024^3 region around the centre: the DEEP
-    kernels test the bricks of a cell with up to four one by one and walk the others 4-cell by 4-cell, and a ray meets both kinds."""
-    from dust_amd.api import BLOCK_DTYPE
-    rng = np.random.default_rng(seed)
-    cells = np.unique(rng.integers(96, 160, (n_cells, 3)), axis=0)
-    per = rng.integers(1, 13, len(cells))
-    bricks = []
-    for c, n in zip(cells, per):
-        sub = rng.choice(64, int(n), replace=False)
-        bricks.append(np.stack([c[0] * 4 + (sub >> 4), c[1] * 4 + ((sub >> 2) & 3), c[2] * 4 + (sub & 3)], axis=1))
-    b = np.concatenate(bricks).astype(np.uint64)
-    key = np.zeros(len(b), np.uint64)
-    for shift, bits in ((6, 4), (2, 4), (0, 2)):          # Tree::iter_leaf order: depth first, x slowest at every level
-        lv = [(b[:, a] >> np.uint64(shift)) & np.uint64((1 << bits) - 1) for a in range(3)]
-        key = (key << np.uint64(3 * bits)) | (lv[0] << np.uint64(2 * bits)) | (lv[1] << np.uint64(bits)) | lv[2]
-    b = b[np.argsort(key, kind="stable")]
-    mask = rng.integers(1, 1 << 63, len(b), dtype=np.uint64) | (rng.integers(0, 2, len(b), dtype=np.uint64) << np.uint64(63))
-    blocks = np.zeros(len(b), BLOCK_DTYPE)
-    blocks["x"], blocks["y"], blocks["z"], blocks["mask"] = b[:, 0] * 4, b[:, 1] * 4, b[:, 2] * 4, mask
-    counts = np.array([bin(int(m)).count("1") for m in mask], np.uint32)
-    blocks["material_ptr"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
-    mats = rng.integers(0, 255, int(counts.sum()), dtype=np.uint8)
-    return blocks, mats, synth.make_palette(5)
-
-
 @pytest.mark.gpu
 def test_config5_deep_tree_sparse_and_dense_cells():
-    blocks, mats, pal = clustered_deep_desc()
+    blocks, mats, pal = P.clustered_deep_model()
     ctx = api.Context(device=0)
     model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
     scene = api.Scene(ctx)

@@ -17,10 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run_slice(n, first, big):
+def _run_slice(n, first, big, deep=False):
     env = dict(os.environ)
     if big:
         env["STRESS_BIG"] = "1"
+    if deep:
+        env["STRESS_DEEP"] = "1"
     bt = os.path.join(ROOT, "tools", "diag", "libsegv_bt.so")
     if os.path.exists(bt):
         env["LD_PRELOAD"] = bt + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
@@ -36,3 +38,9 @@ def test_random_scenes_match_oracle():
 
 def test_random_big_scenes_match_oracle():
     _run_slice(80, 5300, big=True)   # includes seed 5331
+
+
+def test_random_deep_trees_match_oracle():
+    """4096^3 models: clusters of 16-cells holding 1 to 40 bricks (the DEEP kernels' whole-cell test, octant steps and 4-cell walk
+    in one frame), some with a 256^3 model beside them."""
+    _run_slice(100, 5000, big=False, deep=True)

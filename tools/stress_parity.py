@@ -3,7 +3,7 @@
 Many small random scenes -- overlapping instances on aligned and half-voxel-shifted lattices, axis rotations and mirrors,
 cameras inside and outside, axis-parallel views -- through all five passes for a few frames each; integer planes, hit
 distances and GI state must match the oracle bit for bit, radiance within 1e-3.
-usage: stress_parity.py [n_scenes] [first_seed]"""
+usage: stress_parity.py [n_scenes] [first_seed] [position of first_seed in the sweep to reproduce]      STRESS_BIG=1: larger scenes; STRESS_DEEP=1: 4096^3 models (run_deep)"""
 import os
 import sys
 import time
@@ -16,15 +16,15 @@ import oracle_lib as O  # noqa: E402
 import parity_util as P  # noqa: E402
 from dust_amd import _lib as L, api, synth  # noqa: E402
 
-def run(n_scenes, seed0, big=False, verbose=True):
-    """Returns the seeds whose frames did not match."""
+def run(n_scenes, seed0, big=False, verbose=True, k0=0):
+    """Returns the seeds whose frames did not match. (k0: position of seed0 in the sweep that is being reproduced -- some choices go by position)"""
     ctx = api.Context(device=0)
     n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
     sky = P.sky_state()
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
     failed = []
-    for k in range(n_scenes):
-        seed = seed0 + k
+    for k in range(k0, k0 + n_scenes):
+        seed = seed0 + k - k0
         rng = np.random.default_rng(seed)
         desc = P.small_scene(seed=seed, n_models=int(rng.integers(1, 6 if big else 4)), n_instances=int(rng.integers(1, 25 if big else 9)),
                              size=tuple(int(v) for v in rng.integers(12, 110 if big else 40, 3)))
@@ -83,10 +83,83 @@ def run(n_scenes, seed0, big=False, verbose=True):
     return failed
 
 
+def run_deep(n_scenes, seed0, verbose=True, k0=0):
+    """The same sweep over 4096^3 models (three-level hierarchy): clusters of 16-cells with 1 to 12 bricks each (the DEEP kernels'
+    whole-cell test and their 4-cell / octant walk in one frame), every third scene with a 256^3 model beside it (two-level
+    models in a DEEP launch), cameras inside, outside and on cell planes."""
+    ctx = api.Context(device=0)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    failed = []
+    for k in range(k0, k0 + n_scenes):
+        seed = seed0 + k - k0
+        rng = np.random.default_rng(seed)
+        half = int(rng.integers(2, 24))                     # the cluster's half width in 16-cells
+        c0 = int(rng.integers(half, 256 - half))
+        fill = float(rng.choice([0.02, 0.1, 0.4]))
+        n_cells = max(4, int(fill * (2 * half) ** 3))
+        blocks, mats, pal = P.clustered_deep_model(seed=seed, n_cells=min(n_cells, 30000), cell_lo=c0 - half, cell_hi=c0 + half,
+                                                   max_bricks=int(rng.choice([2, 6, 12, 40])))
+        centre = 16.0 * c0
+        xf = np.eye(3, 4, dtype=np.float32)
+        xf[:, 3] = -centre
+        model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
+        scene, oscene = api.Scene(ctx), O.Scene()
+        oscene.add_model(blocks, mats, pal, extent=4096)
+        scene.add_instance(model, xf.reshape(12))
+        oscene.add_instance(0, xf.reshape(12))
+        keep = [model]
+        if k % 3 == 0:
+            small = P.small_scene(seed=seed, n_models=1, n_instances=2, size=(40, 40, 40))
+            m2 = api.Model(ctx, small.models[0][0], small.models[0][1], pal)
+            keep.append(m2)
+            oscene.add_model(small.models[0][0], small.models[0][1], pal)
+            for _, t in small.instances:
+                scene.add_instance(m2, t)
+                oscene.add_instance(1, t)
+        scene.commit()
+        oscene.commit()
+        reach = 16.0 * half
+        eye = rng.uniform(-1.5 * reach, 1.5 * reach, 3)
+        if k % 4 == 0:
+            eye = np.round(eye / 16.0) * 16.0   # on 16-cell planes
+        if abs(eye[0]) + abs(eye[2]) < 1e-3:
+            eye[0] = 3.0
+        cam = P.camera_for(tuple(float(v) for v in eye), target=tuple(float(v) for v in rng.uniform(-0.3 * reach, 0.3 * reach, 3)))
+        w, h = int(rng.integers(40, 140)), int(rng.integers(24, 90))
+        cap, pool = int(rng.choice([509, 4093, 1 << 14])), int(rng.choice([97, 777, 2048]))
+        pipe = api.StandardPipeline(ctx, w, h)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(cap, pool)
+        gi = O.GI(cap, pool)
+        f = 0
+        try:
+            for f in range(1, 3):
+                rnd = synth.frame_rand(seed, f)
+                pipe.render(scene, cam, sky, passes | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
+                g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f)
+                res = P.compare_gbuffers(g, P.read_hip_gbuffer(pipe))
+                P.assert_parity(res)
+                assert res.get("illuminance_rel_l2", 0.0) <= 1e-3 and res.get("denoised_rel_l2", 0.0) <= 1e-3, res
+                oh, op = gi.hash(), gi.pool()
+                hh, hp = pipe.read_gi()
+                assert np.array_equal(oh["fingerprint"], hh[:, 0]), "hash fingerprints"
+                assert np.array_equal(oh["sample_count"], hh[:, 2] >> 16), "hash sample counts"
+                assert np.array_equal(op["direction"], hp["direction"]), "surfel pool"
+        except AssertionError as e:
+            failed.append(seed)
+            if verbose:
+                print(f"deep seed {seed}: MISMATCH frame {f} ({w}x{h}, {len(blocks)} bricks, eye {eye}): {str(e)[:300]}", flush=True)
+    return failed
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0 = time.time()
-    bad = run(n, first, big=os.environ.get("STRESS_BIG") == "1")
+    k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    bad = run_deep(n, first, k0=k0) if os.environ.get("STRESS_DEEP") == "1" else run(n, first, big=os.environ.get("STRESS_BIG") == "1", k0=k0)
     print(f"{n} scenes, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
