@@ -104,6 +104,16 @@ def run_deep(n_scenes, seed0, verbose=True, k0=0):
         centre = 16.0 * c0
         xf = np.eye(3, 4, dtype=np.float32)
         xf[:, 3] = -centre
+        if k % 5 == 1:   # the deep instance rotated, scaled and shifted by fractions: object-space rays with no zero or shared components
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            qw, qx, qy, qz = q
+            R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                          [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                          [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+            A = R * rng.uniform(0.6, 1.6, 3)[None, :]
+            xf[:, :3] = A.astype(np.float32)
+            xf[:, 3] = (-(A @ np.full(3, centre)) + rng.uniform(-3, 3, 3)).astype(np.float32)   # the cluster's centre stays near the origin
         model = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
         scene, oscene = api.Scene(ctx), O.Scene()
         oscene.add_model(blocks, mats, pal, extent=4096)
