@@ -290,7 +290,7 @@ def measure_curve(be, dist, args, lanes, shard):
                 be.sync()
                 pix_stats[:] = [pipe.pass_stats(i) for i in range(4)] if have_rows else []
             sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
-                                      (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: None),
+                                      (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: pipe.gi_export(H, H)),  # (no rows: zeroes into the merge)
                                       (lambda: pipe.gi_import(rows[0], rows[1], frame_index)) if have_rows else
                                       (lambda: pipe.gi_import(H, H, frame_index)))  # empty own range: every stamp is another band's
             # the replicated surfel pass must leave the SAME hash on every GPU: deterministic apply, not the racy one

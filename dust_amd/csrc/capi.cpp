@@ -1774,9 +1774,9 @@ DustStatus dust_hip_pipeline_gi_exchange(DustHipPipeline* p, uint32_t padded_row
 }
 static DustStatus gi_exchange_launch(DustHipPipeline* p, uint32_t row_begin, uint32_t row_end, uint32_t frame_index, bool import) {
   if (!p || !p->gi_touched.p) return fail(DUST_ERR_NOT_READY, "call dust_hip_pipeline_gi_exchange first");
-  // an EMPTY range is fine for the import: a rank whose band lies past the end of the frame still repeats the others'
-  // stamps and commits the winners
-  if (row_begin > row_end || (row_begin == row_end && !import) || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
+  // an EMPTY range is fine: a rank whose band lies past the end of the frame still repeats the others' stamps and commits the
+  // winners (import), and must contribute zeroes -- not last frame's all-reduced sum -- to the merge (export)
+  if (row_begin > row_end || row_end > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
   HIP_TRY(hipSetDevice(p->ctx->device));
   HIP_TRY(join_side(p->ctx));
   dust::FrameArgs a{};

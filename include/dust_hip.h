@@ -353,7 +353,10 @@ DustStatus dust_hip_pipeline_write_gi(DustHipPipeline*, uint32_t which, const vo
  *   6. dust_hip_render_frame(SURFEL [| ACCUMULATE] | DUST_PASS_GI_SHARDED, rows as in 1 for ACCUMULATE)
  * With DUST_PASS_GI_ORDERED in step 6 every rank's hash and pool stay bit-identical to the single-GPU run.
  * dust_hip_pipeline_gi_exchange allocates (once) and returns the three device buffers the collectives run on;
- * padded_rows >= height is the row count of `touched` (world_size x band_rows). */
+ * padded_rows >= height is the row count of `touched` (world_size x band_rows).
+ * A rank whose band lies past the end of the frame (small frames on many GPUs) skips steps 1 and the ACCUMULATE of 6 but still takes
+ * part in every collective: it exports and imports the EMPTY range (height, height) -- its `merged` must be zeroed by the export,
+ * or it would add the previous frame's all-reduced sum to this frame's. */
 typedef struct DustHipGiExchange {
   uint32_t struct_size;
   uint32_t pool_size;      /* surfel slots */

@@ -181,7 +181,7 @@ def assert_parity(res):
         assert res.get(k, 0.0) <= 1e-3, f"{k} = {res[k]} exceeds 1e-3 ({res})"  # north_star tolerance
 
 
-def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n5, seed=3):
+def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n5, seed=3, gi_sizes=None):
     """SURVEY 8e option i with the collectives done by hand: `world` pipelines on one GPU play the ranks (row bands for the
     pixel passes, the exchange of dust_hip_pipeline_gi_exchange, replicated ordered surfel pass); asserts that every rank's
     spatial hash, surfel pool and own illuminance band equal the single-pipeline run bit for bit. Returns the reference hash."""
@@ -202,6 +202,8 @@ def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n
         p = api.StandardPipeline(ctx, w, h)
         p.set_noise(0, n0)
         p.set_noise(5, n5)
+        if gi_sizes:
+            p.configure_gi(*gi_sizes)
         return p
 
     ref, ranks = make(), [make() for _ in range(world)]
@@ -224,14 +226,15 @@ def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n
             h2d(e.slot_owner, owner)
             h2d(e.touched, touched)
         for r, p in enumerate(ranks):
-            if bands[r][0] < bands[r][1]:
-                p.gi_export(*bands[r])
+            p.gi_export(*bands[r]) if bands[r][0] < bands[r][1] else p.gi_export(h, h)   # (a rank without rows: zeroes into the merge)
         ctx.sync()
         merged = np.sum([d2h(e.merged, e.pool_size * 4) for e in exs], axis=0, dtype=np.int64).astype(np.int32)  # all-reduce SUM
         for r, (p, e) in enumerate(zip(ranks, exs)):
             h2d(e.merged, merged)
             if bands[r][0] < bands[r][1]:
                 p.gi_import(bands[r][0], bands[r][1], frame)
+            else:
+                p.gi_import(h, h, frame)   # a rank past the end of the frame: every stamp is another band's (as bench.py does)
             p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
         ctx.sync()
     h_ref, s_ref = ref.read_gi()

@@ -126,3 +126,19 @@ def test_torch_aliases_the_exchange_buffers():
     owner.copy_(torch.arange(64, dtype=torch.int32, device="cuda"))
     torch.cuda.synchronize()
     assert np.array_equal(_d2h(hip, ex.slot_owner, 64), np.arange(64, dtype=np.int32))
+
+
+@pytest.mark.parametrize("w,h,world", [(88, 40, 4), (113, 80, 9), (136, 18, 5)])
+def test_ranks_without_rows_take_part_in_the_exchange(w, h, world):
+    """Small frames on many GPUs: the 8-row-aligned bands run out before the ranks do. A rank without rows renders no pixels but is in
+    every collective -- it must export zeroes (its `merged` still holds last frame's all-reduced sum otherwise, which is what
+    tools/stress_sharded.py found) and import the others' stamps. Every rank's hash and pool equal the single-pipeline run."""
+    from dust_amd import sharding
+    per = sharding.gi_band_rows(world, h)
+    assert any(min(h, r * per) >= min(h, (r + 1) * per) for r in range(world))
+    desc = P.small_scene(seed=31, n_models=2, n_instances=6)
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    hsh = P.sharded_gi_vs_single_device(ctx, scene, P.camera_for((90.0, 60.0, -80.0)), P.sky_state(), w, h, world, 4, n0, n5, seed=9, gi_sizes=(4093, 777))
+    assert int((hsh[:, 0] != 0).sum()) >= 5   # (the hash really was fed)
