@@ -2849,7 +2849,9 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   const uint32_t total = a.tiles_x * a.tiles_y;
   a.tiles_per_band = (total + kRegions - 1u) / kRegions;
   // floor(2^32 / d) + 1 gives the exact quotient for n * d < 2^32; launches beyond that are one-row lists (tiles_y == 1: quotient 0)
-  const bool exact = a.tiles_y > 1u && (unsigned long long)total * a.tiles_x < (1ull << 32);
+  // (and not for one COLUMN of tiles: 2^32 / 1 + 1 does not fit the multiplier -- as 1 it sent every tile of a frame up to 8 pixels
+  // wide to the first tile row; tools/stress_host.py bands, seed 111)
+  const bool exact = a.tiles_y > 1u && a.tiles_x > 1u && (unsigned long long)total * a.tiles_x < (1ull << 32);
   a.tiles_x_magic = exact ? (uint32_t)((1ull << 32) / a.tiles_x) + 1u : 0u;  // 0: the kernel divides (frames beyond ~11K x 11K) or has one row
   const uint32_t waves = ((grid + kRegions - 1u) / kRegions) * (block / 64u);  // the fullest band's
   const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;

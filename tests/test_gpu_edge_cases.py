@@ -44,7 +44,7 @@ def test_empty_scene_renders_sky():
     P.assert_parity(res)
 
 
-@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (9, 17)])
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (9, 17), (8, 137), (5, 40)])   # (the last two: ONE column of tiles, several rows of them)
 def test_frames_smaller_than_a_packet(w, h):
     desc = P.small_scene(seed=4, n_models=2, n_instances=4)
     ctx = api.Context(device=0)

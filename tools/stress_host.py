@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Randomised sweeps of the host runtime on one GPU (no oracle: the library against itself).
+  bands   : a frame rendered as random row bands (any cut points, any order, random frames-in-flight setting) equals the frame rendered whole
+  commits : random sequences of add_instance / set_transform / commit / render with nothing waited for in between; at random points the
+            frame must equal the frame of a FRESH scene built from the instance list as it stands (the staging ring, the image
+            reallocation when the scene grows, the dirty-range copy, the second stream)
+usage: stress_host.py bands|commits [n] [first_seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from dust_amd import _lib as L, api, synth, scenes as S
+
+PA = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+GI = PA | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+PLANES = (L.PLANE_DEPTH, L.PLANE_VOXEL_ID, L.PLANE_ALBEDO, L.PLANE_NORMAL, L.PLANE_ILLUMINANCE, L.PLANE_DENOISED, L.PLANE_MOTION)
+
+
+def small_models(ctx, rng, pal, n):
+    out = []
+    for _ in range(n):
+        size = tuple(int(v) for v in rng.integers(10, 50, 3))
+        solid = rng.random(size) < 0.1
+        x, y, z = np.nonzero(solid)
+        xyzi = np.stack([x, y, z, rng.integers(0, 255, x.size)], axis=1).astype(np.uint8)
+        if not len(xyzi):
+            xyzi = np.array([[1, 1, 1, 3]], np.uint8)
+        out.append(api.Model(ctx, *api.flatten_model(xyzi, size, pal), pal))
+    return out
+
+
+def rand_xf(rng):
+    rots = [np.eye(3), np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]]), np.array([[-1, 0, 0], [0, 1, 0], [0, 0, -1]]), np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]])]
+    m = np.zeros((3, 4), np.float32)
+    m[:, :3] = rots[int(rng.integers(0, 4))]
+    m[:, 3] = rng.uniform(-60, 60, 3)
+    return m
+
+
+def planes(pipe):
+    return [pipe.read_plane(p) for p in PLANES]
+
+
+def pipe_for(ctx, w, h, n0, n5):
+    p = api.StandardPipeline(ctx, w, h)
+    p.set_noise(0, n0); p.set_noise(5, n5)
+    p.configure_gi(4093, 777)
+    return p
+
+
+def bands(n, first):
+    ctx = api.Context(device=0)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = S.sky_state()
+    bad = []
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        pal = synth.make_palette(seed)
+        models = small_models(ctx, rng, pal, int(rng.integers(1, 4)))
+        scene = api.Scene(ctx)
+        for _ in range(int(rng.integers(1, 12))):
+            scene.add_instance(models[int(rng.integers(0, len(models)))], rand_xf(rng).reshape(12))
+        scene.commit()
+        w, h = int(rng.integers(8, 300)), int(rng.integers(8, 200))
+        eye = tuple(float(v) for v in rng.uniform(-100, 100, 3))
+        cam = S.camera_for(eye if abs(eye[0]) + abs(eye[2]) > 1e-3 else (1.0, eye[1], eye[2]))
+        whole = pipe_for(ctx, w, h, n0, n5)
+        whole.render(scene, cam, sky, PA, frame_index=1, rand=seed)
+        want = planes(whole)
+        cuts = sorted(set([0, h] + [int(v) for v in rng.integers(1, h, int(rng.integers(1, 9)))]))
+        order = list(range(len(cuts) - 1))
+        rng.shuffle(order)
+        part = pipe_for(ctx, w, h, n0, n5)
+        part.set_frames_in_flight(int(rng.integers(1, 9)))
+        for i in order:
+            part.render(scene, cam, sky, PA, frame_index=1, rand=seed, rows=(cuts[i], cuts[i + 1]))
+        got = planes(part)
+        diff = [pl for pl, a, b in zip(PLANES, want, got) if not np.array_equal(a, b)]
+        if diff:
+            bad.append(seed)
+            print(f"seed {seed}: {w}x{h} cuts {cuts} order {order}: planes {diff} differ", flush=True)
+    return bad
+
+
+def mat4(o2w):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :] = np.asarray(o2w, np.float32).reshape(3, 4)
+    return m.T.reshape(16)
+
+
+def commits(n, first):
+    ctx = api.Context(device=0)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = S.sky_state()
+    bad = []
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        pal = synth.make_palette(seed)
+        models = small_models(ctx, rng, pal, int(rng.integers(1, 4)))
+        scene = api.Scene(ctx)
+        inst = []   # [model index, current transform, previous transform]
+        w, h = int(rng.integers(32, 160)), int(rng.integers(24, 100))
+        cam = S.camera_for(tuple(float(v) for v in rng.uniform(60, 140, 3)))
+        gi = bool(rng.integers(0, 2))
+        passes = GI if gi else PA
+        pipe = pipe_for(ctx, w, h, n0, n5)
+        frame = 0
+        ok = True
+        for step in range(int(rng.integers(10, 60))):
+            op = int(rng.integers(0, 10))
+            if op < 3 or not inst:
+                mi = int(rng.integers(0, len(models)))
+                t = rand_xf(rng)
+                scene.add_instance(models[mi], t.reshape(12))
+                inst.append([mi, t, t])
+            elif op < 8:
+                j = int(rng.integers(0, len(inst)))
+                t = inst[j][1].copy()
+                t[:, 3] += rng.uniform(-3, 3, 3).astype(np.float32)
+                scene.set_transform(j, t.reshape(12), mat4(inst[j][1]))
+                inst[j][2], inst[j][1] = inst[j][1], t
+            else:
+                scene.commit()
+                frame += 1
+                pipe.render(scene, cam, sky, passes, frame_index=frame, rand=seed + frame)
+                if rng.integers(0, 3) == 0 and not gi:   # (a GI frame depends on the frames before it: compared at the end only)
+                    fresh = api.Scene(ctx)
+                    for mi, t, tp in inst:
+                        fresh.add_instance(models[mi], t.reshape(12), mat4(tp))
+                    fresh.commit()
+                    ref = pipe_for(ctx, w, h, n0, n5)
+                    ref.render(fresh, cam, sky, passes, frame_index=frame, rand=seed + frame)
+                    a, b = planes(ref), planes(pipe)
+                    hit = np.isfinite(a[0])
+                    # (the pixel passes leave img_illuminance_denoised of a HIT pixel alone -- miss.rmiss writes it --, so the kept pipeline
+                    # still holds there what an earlier frame's sky left: compared where this frame wrote it)
+                    diff = [pl for pl, x, y in zip(PLANES, a, b) if not (np.array_equal(x[~hit], y[~hit]) if pl == L.PLANE_DENOISED else np.array_equal(x[hit], y[hit]))]
+                    diff += ["depth"] if not np.array_equal(a[0], b[0]) else []
+                    if diff:
+                        ok = False
+                        d1 = (a[1] != b[1]) & hit
+                        ys, xs = np.nonzero(d1)
+                        ex = [(int(x), int(y), hex(int(a[1][y, x])), hex(int(b[1][y, x]))) for y, x in list(zip(ys, xs))[:3]]
+                        print(f"seed {seed} step {step} frame {frame}: {len(inst)} instances, planes {diff} differ from a fresh scene's; voxel_id (fresh, kept) {ex}, {int(d1.sum())} px", flush=True)
+                        break
+        if not ok:
+            bad.append(seed)
+    return bad
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    t0 = time.time()
+    bad = {"bands": bands, "commits": commits}[what](n, first)
+    print(f"{what}: {n} cases, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
