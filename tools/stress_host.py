@@ -4,7 +4,8 @@
   commits : random sequences of add_instance / set_transform / commit / render with nothing waited for in between; at random points the
             frame must equal the frame of a FRESH scene built from the instance list as it stands (the staging ring, the image
             reallocation when the scene grows, the dirty-range copy, the second stream)
-usage: stress_host.py bands|commits [n] [first_seed]"""
+  threads : several host threads, a context each, on one device at the same time
+usage: stress_host.py bands|commits|threads [n] [first_seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -148,11 +149,56 @@ def commits(n, first):
     return bad
 
 
+def threads(n, first):
+    """n rounds of 6 host threads, each with a context, scene and pipeline of its own on the same device, creating, rendering and
+    destroying at the same time (contexts are externally synchronised one by one; the library's process-wide state must not care):
+    every thread's frames equal the ones a single thread renders afterwards."""
+    import threading
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = S.sky_state()
+    bad = []
+    for seed in range(first, first + n):
+        results, errors = {}, []
+
+        def work(tid, keep):
+            try:
+                rng = np.random.default_rng(seed * 100 + tid)
+                ctx = api.Context(device=0)
+                pal = synth.make_palette(tid)
+                models = small_models(ctx, rng, pal, 2)
+                scene = api.Scene(ctx)
+                for _ in range(int(rng.integers(1, 10))):
+                    scene.add_instance(models[int(rng.integers(0, 2))], rand_xf(rng).reshape(12))
+                scene.commit()
+                w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
+                cam = S.camera_for(tuple(float(v) for v in rng.uniform(60, 140, 3)))
+                pipe = pipe_for(ctx, w, h, n0, n5)
+                for f in range(1, 5):
+                    pipe.render(scene, cam, sky, GI, frame_index=f, rand=seed + f)
+                hh, sp = pipe.read_gi()
+                keep[tid] = planes(pipe) + [hh, sp.view(np.uint32).copy()]
+            except Exception as e:   # noqa: BLE001
+                errors.append((tid, repr(e)))
+
+        par, ser = {}, {}
+        ts = [threading.Thread(target=work, args=(t, par)) for t in range(6)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for t in range(6):
+            work(t, ser)
+        if errors:
+            bad.append(seed); print(f"seed {seed}: errors {errors[:3]}", flush=True); continue
+        for t in range(6):
+            if not all(np.array_equal(a, b) for a, b in zip(par[t], ser[t])):
+                bad.append(seed); print(f"seed {seed}: thread {t} differs from the single-threaded run", flush=True); break
+    return bad
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     t0 = time.time()
-    bad = {"bands": bands, "commits": commits}[what](n, first)
+    bad = {"bands": bands, "commits": commits, "threads": threads}[what](n, first)
     print(f"{what}: {n} cases, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)

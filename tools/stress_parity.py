@@ -3,7 +3,8 @@
 Many small random scenes -- overlapping instances on aligned and half-voxel-shifted lattices, axis rotations and mirrors,
 cameras inside and outside, axis-parallel views -- through all five passes for a few frames each; integer planes, hit
 distances and GI state must match the oracle bit for bit, radiance within 1e-3.
-usage: stress_parity.py [n_scenes] [first_seed] [position of first_seed in the sweep to reproduce]      STRESS_BIG=1: larger scenes; STRESS_DEEP=1: 4096^3 models (run_deep)"""
+usage: stress_parity.py [n_scenes] [first_seed] [position of first_seed in the sweep to reproduce]      STRESS_BIG=1: larger scenes; STRESS_FULL=1: one 256^3 model filled to its faces; STRESS_MANY=1: 90-160 models, 150-900 instances; STRESS_SWITCHES=1: a random combination of the
+library's diagnostic switches per scene; STRESS_DEEP=1: 4096^3 models (run_deep)"""
 import os
 import sys
 import time
@@ -23,11 +24,38 @@ def run(n_scenes, seed0, big=False, verbose=True, k0=0):
     sky = P.sky_state()
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
     failed = []
+    many, switches = os.environ.get("STRESS_MANY") == "1", os.environ.get("STRESS_SWITCHES") == "1"
     for k in range(k0, k0 + n_scenes):
         seed = seed0 + k - k0
         rng = np.random.default_rng(seed)
-        desc = P.small_scene(seed=seed, n_models=int(rng.integers(1, 6 if big else 4)), n_instances=int(rng.integers(1, 25 if big else 9)),
-                             size=tuple(int(v) for v in rng.integers(12, 110 if big else 40, 3)))
+        if switches:   # a random combination of the library's diagnostic switches (read when a pipeline is created), a context of its own
+            for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES"):
+                os.environ.pop("DUST_HIP_" + name, None)
+                if rng.random() < 0.3:
+                    os.environ["DUST_HIP_" + name] = "1"
+            os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([64, 128, 256, 512])))
+            os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
+            ctx = api.Context(device=0, lds_root_bytes=int(rng.choice([0, 640, 1280, 64 * 1024])))
+        if os.environ.get("STRESS_FULL") == "1":   # one model that fills its 256^3 tree to the faces and corners, 1 to 3 instances
+            sz = (256, 256, 256)
+            pts = rng.integers(0, 256, (int(rng.integers(2000, 20000)), 3))
+            pts = np.concatenate([pts, rng.integers(0, 256, (600, 3)) * np.array([1, 1, 0]) + np.array([0, 0, 255]), rng.integers(0, 256, (600, 3)) * np.array([0, 1, 1]),
+                                  np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]])])
+            xyzi = np.concatenate([pts, rng.integers(0, 255, (len(pts), 1))], axis=1).astype(np.uint8)
+            pal = synth.make_palette(seed)
+            inst = []
+            for i in range(int(rng.integers(1, 4))):
+                m = np.zeros((3, 4), np.float32)
+                m[:, :3] = np.eye(3) if i % 2 == 0 else np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]])
+                m[:, 3] = rng.integers(-160, -90, 3) + i * 37.5
+                inst.append((0, m.reshape(12)))
+            desc = P.SceneDesc([api.flatten_model(xyzi, sz, pal)], pal, inst)
+        elif many:       # more models than LDS holds roots of, more instances than a packet's candidate list holds
+            desc = P.small_scene(seed=seed, n_models=int(rng.integers(90, 160)), n_instances=int(rng.integers(150, 900)),
+                                 size=tuple(int(v) for v in rng.integers(8, 20, 3)))
+        else:
+            desc = P.small_scene(seed=seed, n_models=int(rng.integers(1, 6 if big else 4)), n_instances=int(rng.integers(1, 25 if big else 9)),
+                                 size=tuple(int(v) for v in rng.integers(12, 110 if big else 40, 3)))
         if k % 3 == 0:   # stack instances on top of each other: equal-t ties between instances
             desc.instances = [(m, t.copy()) for m, t in desc.instances]
             for j in range(1, len(desc.instances)):
@@ -46,7 +74,7 @@ def run(n_scenes, seed0, big=False, verbose=True, k0=0):
                 t[:, :3] = A
                 t[:, 3] = rng.uniform(-50, 50, 3).astype(np.float32)
         scene, oscene = P.hip_scene(ctx, desc), P.oracle_scene(desc)
-        eye = rng.uniform(-90, 90, 3)
+        eye = rng.uniform(-90, 90, 3) * (2.5 if os.environ.get("STRESS_FULL") == "1" else 1.0)
         if k % 5 == 0:
             eye = np.round(eye / 4.0) * 4.0   # on the lattice
         if k % 7 == 0:
