@@ -41,6 +41,7 @@ def run(n_scenes, seed0, big=False, verbose=True, k0=0):
             pts = rng.integers(0, 256, (int(rng.integers(2000, 20000)), 3))
             pts = np.concatenate([pts, rng.integers(0, 256, (600, 3)) * np.array([1, 1, 0]) + np.array([0, 0, 255]), rng.integers(0, 256, (600, 3)) * np.array([0, 1, 1]),
                                   np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]])])
+            pts = np.unique(pts, axis=0)   # (the loader refuses a voxel listed twice)
             xyzi = np.concatenate([pts, rng.integers(0, 255, (len(pts), 1))], axis=1).astype(np.uint8)
             pal = synth.make_palette(seed)
             inst = []
