@@ -94,6 +94,25 @@ def run(n_scenes, seed0, big=False, verbose=True, k0=0):
         try:
             for f in range(1, 4):
                 rnd = synth.frame_rand(seed, f)
+                if f > 1 and k % 6 == 2 and not many:   # instances move between frames (castle.rs:287-291): transforms through
+                    oscene = O.Scene()                     # dust_hip_scene_set_transform + commit, motion vectors against the previous frame's
+                    for b, m in desc.models:
+                        oscene.add_model(b, m, desc.palette)
+                    moved = []
+                    for j, (mid, t) in enumerate(desc.instances):
+                        t = np.array(t, np.float32).reshape(3, 4)
+                        cur = t.copy()
+                        if rng.random() < 0.6:
+                            cur[:, 3] += rng.uniform(-2.5, 2.5, 3).astype(np.float32)
+                        prev = np.eye(4, dtype=np.float32)
+                        prev[:3, :] = t
+                        prev = prev.T.reshape(16)   # column-major mat4 of last frame's transform
+                        scene.set_transform(j, cur.reshape(12), prev)
+                        oscene.add_instance(mid, cur.reshape(12), prev)
+                        moved.append((mid, cur.reshape(12)))
+                    desc.instances = moved
+                    scene.commit()
+                    oscene.commit()
                 pipe.render(scene, cam, sky, passes | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
                 g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f)
                 res = P.compare_gbuffers(g, P.read_hip_gbuffer(pipe))
