@@ -17,6 +17,18 @@ import oracle_lib as O  # noqa: E402
 import parity_util as P  # noqa: E402
 from dust_amd import _lib as L, api, synth  # noqa: E402
 
+def random_switches(rng):
+    """a random combination of the library's diagnostic switches (read when a pipeline is created) and a context of its own with a
+    random LDS budget for staged roots"""
+    for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES"):
+        os.environ.pop("DUST_HIP_" + name, None)
+        if rng.random() < 0.3:
+            os.environ["DUST_HIP_" + name] = "1"
+    os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([64, 128, 256, 512])))
+    os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
+    return api.Context(device=0, lds_root_bytes=int(rng.choice([0, 640, 1280, 64 * 1024])))
+
+
 def run(n_scenes, seed0, big=False, verbose=True, k0=0):
     """Returns the seeds whose frames did not match. (k0: position of seed0 in the sweep that is being reproduced -- some choices go by position)"""
     ctx = api.Context(device=0)
@@ -28,14 +40,8 @@ def run(n_scenes, seed0, big=False, verbose=True, k0=0):
     for k in range(k0, k0 + n_scenes):
         seed = seed0 + k - k0
         rng = np.random.default_rng(seed)
-        if switches:   # a random combination of the library's diagnostic switches (read when a pipeline is created), a context of its own
-            for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES"):
-                os.environ.pop("DUST_HIP_" + name, None)
-                if rng.random() < 0.3:
-                    os.environ["DUST_HIP_" + name] = "1"
-            os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([64, 128, 256, 512])))
-            os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
-            ctx = api.Context(device=0, lds_root_bytes=int(rng.choice([0, 640, 1280, 64 * 1024])))
+        if switches:
+            ctx = random_switches(rng)
         if os.environ.get("STRESS_FULL") == "1":   # one model that fills its 256^3 tree to the faces and corners, 1 to 3 instances
             sz = (256, 256, 256)
             pts = rng.integers(0, 256, (int(rng.integers(2000, 20000)), 3))
@@ -143,6 +149,8 @@ def run_deep(n_scenes, seed0, verbose=True, k0=0):
     for k in range(k0, k0 + n_scenes):
         seed = seed0 + k - k0
         rng = np.random.default_rng(seed)
+        if os.environ.get("STRESS_SWITCHES") == "1":
+            ctx = random_switches(np.random.default_rng(seed ^ 0x5A5A))
         half = int(rng.integers(2, 24))                     # the cluster's half width in 16-cells
         c0 = int(rng.integers(half, 256 - half))
         fill = float(rng.choice([0.02, 0.1, 0.4]))

@@ -20,6 +20,13 @@ for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     desc = P.small_scene(seed=seed, n_models=int(rng.integers(1, 4)), n_instances=int(rng.integers(1, 9)), size=tuple(int(v) for v in rng.integers(12, 60, 3)))
     scene = P.hip_scene(ctx, desc)
+    if seed % 4 == 0:   # a 4096^3 model beside them: the DEEP kernel variants under the same choreography
+        blocks, mats, pal = P.clustered_deep_model(seed=seed, n_cells=400, cell_lo=124, cell_hi=132, max_bricks=6)
+        deep = api.Model(ctx, blocks, mats, pal, tree_extent_log2=12)
+        xf = np.eye(3, 4, dtype=np.float32)
+        xf[:, 3] = -2048.0
+        scene.add_instance(deep, xf.reshape(12))
+        scene.commit()
     eye = tuple(float(v) for v in rng.uniform(-90, 90, 3))
     if abs(eye[0]) + abs(eye[2]) < 1e-3:
         eye = (1.0, eye[1], eye[2])
