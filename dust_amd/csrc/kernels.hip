@@ -691,6 +691,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   MidCache mc;
   mc.key = -1; mc.mid = 0; mc.mask4 = 0;
   const bool zero_axis = DEEP && __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this visit)
+  bool prev_whole = false;  // DEEP: the cell the walk has just left was a whole 16-cell (or larger) with nothing untested in it
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
@@ -717,8 +718,9 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     // by brick): the bricks inside it need no neighbour visit -- but a brick ACROSS the face the ray came in through does, whatever
     // plane its other axes are near (round 2's kernels looked again at 16-plane granularity only and lost one such brick in 4 000
     // random deep scenes: tools/stress_parity.py STRESS_DEEP=1, seed 20833). That brick lies in the 16-cell the walk has just
-    // left, whose child mask is what the cache holds -- all zeroes if that cell was itself empty, missed or tested whole (below):
-    // the call is made only if the mask has a brick there, or for the rarer shapes (ties, two near planes, a near 16-plane).
+    // left: if that was itself a whole cell with nothing untested (prev_whole, below) there is nothing to do; else its child mask
+    // is what the cache holds, and the call is made only if the mask has a brick there -- or for the rarer shapes (ties, two
+    // near planes, a near 16-plane).
     if (DEEP && __builtin_expect(screen, 0) && cl_main >= 4u) {
       bool near16 = false, across_needed = true, sided = true;
       uint32_t near4 = 0;
@@ -729,13 +731,14 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
           c[a] = dd[a] > 0.0f ? (ijk[a] & ~15) - 1 : (ijk[a] & ~15) + 16;  // back across the face
         } else {
           const float pa = oo[a] + dd[a] * t;
-          const float r4 = pa * 0.25f, r16 = pa * 0.0625f;
-          near16 = near16 | (fabsf(r16 - rintf(r16)) <= near_tol * 0.25f);
+          const float r4 = pa * 0.25f;
           if (fabsf(r4 - rintf(r4)) <= near_tol) {
             near4 += 1u;
-            const float q = pa - (float)(ijk[a] & ~3);
-            if (q <= 8.0f * near_tol) c[a] = (ijk[a] & ~3) - 1;
-            else if (q >= 4.0f - 8.0f * near_tol) c[a] = (ijk[a] & ~3) + 4;
+            const int b0 = ijk[a] & ~3;
+            const float q = pa - (float)b0;
+            // (a near plane that is a 16-cell's face has neighbours outside the cell on its own: the exact code looks)
+            if (q <= 8.0f * near_tol) { c[a] = b0 - 1; near16 = near16 | ((b0 & 15) == 0); }
+            else if (q >= 4.0f - 8.0f * near_tol) { c[a] = b0 + 4; near16 = near16 | (((b0 + 4) & 15) == 0); }
             else sided = false;  // (the integer cell and the point disagree about the side: let the exact code look)
           }
         }
@@ -744,9 +747,9 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
       else if (__popc(stepped) == 1 && near4 == 1u && sided) {
         const int kd = ((c[0] >> 4) << 16) | ((c[1] >> 4) << 8) | (c[2] >> 4);
         const uint32_t bd = ((uint32_t)((c[0] >> 2) & 3) << 4) | ((uint32_t)((c[1] >> 2) & 3) << 2) | (uint32_t)((c[2] >> 2) & 3);
-        if (kd == mc.key && !((mc.mask4 >> bd) & 1ull)) across_needed = false;
+        if (prev_whole || (kd == mc.key && !((mc.mask4 >> bd) & 1ull))) across_needed = false;
       }
-      screen = (__popc(stepped) > 1) | near16 | across_needed;
+      screen = (__popc(stepped) > 1) | near16 | !sided | across_needed;
     }
     // leave the cell of size 2^cl_main that contains ijk
     PROF_ENTER(P_ADVANCE);
@@ -810,11 +813,10 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
     }
     PROF_LEAVE(P_SCREEN);
     if (stuck || outside) return;
-    // DEEP: a 16-cell left behind with nothing untested in it (empty; missed by 0.05 voxel, so no brick of it comes within delta of
-    // the ray anywhere; or tested whole, so every brick the ray can touch has had its test) goes into the cache with an all-zero
-    // child mask: the next cell's neighbour logic -- the inline test above and visit_neighbours' own lookups -- settles a cell
-    // of it without a load or a call.
-    if (DEEP && cl_main == 4u) { mc.key = ((ijk[0] >> 4) << 16) | ((ijk[1] >> 4) << 8) | (ijk[2] >> 4); mc.mask4 = 0ull; }
+    // DEEP: was the cell left behind a whole 16-cell (or larger) with nothing untested in it -- empty; missed by 0.05 voxel, so no
+    // brick of it comes within delta of the ray anywhere; or tested whole, so every brick the ray can touch has had its test?
+    // Then the next cell's neighbour across the entered face, which lies inside it, needs no visit (the inline test above).
+    if (DEEP) prev_whole = cl_main >= 4u;
     ijk[0] = next_ijk[0]; ijk[1] = next_ijk[1]; ijk[2] = next_ijk[2];
     stepped = next_stepped;
     screen = next_screen;
