@@ -25,6 +25,12 @@ python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-bas
 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_RAY_LANES=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ray_lanes.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
+# what ONE rank of an N-GPU row-band run does between collectives (four frames in flight, launches on a quarter of the slots each): every band of N = 2, 4, 8
+: > "$out/${tag}_bench_bands_emulated.log"
+for n in 2 4 8; do for r in $(seq 0 $((n - 1))); do
+  DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
+    python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/$n', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight'], 'rays_per_step': j['config']['rays_per_step_all_gpus']}))" >> "$out/${tag}_bench_bands_emulated.log"
+done; done
 
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
