@@ -71,6 +71,9 @@ def parse(argv=None):
                     help="frames of the sequence on the GPU at once, each on a stream, context and G-buffer of its own (0 = auto: 4 for "
                          "row bands on N > 1 GPUs, where a rank's launch is as long as its most expensive tile and most of the GPU would "
                          "idle behind it; 1 otherwise). GI workloads run one frame at a time (every frame reads the previous one's hash)")
+    ap.add_argument("--band-cuts", choices=["cost", "rows"], default="cost",
+                    help="row bands of a non-GI workload: cost = bands of about equal measured cost (one untimed whole-frame launch records every "
+                         "tile's cycles, rank 0's map decides); rows = equal row counts")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
@@ -229,10 +232,24 @@ def measure_curve(be, dist, args, lanes, shard):
     bands = shard == "bands"
     per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
     emulate = os.environ.get("DUST_BENCH_EMULATE_BAND")  # "r/N" on ONE GPU: this rank renders band r of N, nothing is gathered --
-    if emulate and bands and world == 1:                 # what a rank of an N-GPU strong-scaling run does between collectives
-        er, en = (int(v) for v in emulate.split("/"))
+    emulate = emulate if (emulate and bands and world == 1) else None   # what a rank of an N-GPU strong-scaling run does between collectives
+    er, en = (int(v) for v in emulate.split("/")) if emulate else (rank, world)
+    if emulate:
         per_rows, rows, send = sharding.band_layout(er, en, H)
         send = (send[0], en * per_rows)  # (sizes the padded render target as the N-rank run would)
+    band_cuts = None
+    if bands and not gi_mode and en > 1 and args.band_cuts == "cost":
+        # Bands of equal COST instead of equal rows (a frame is done when its slowest band is: the castle's top half takes 0.122 ms,
+        # its bottom half 0.096). One untimed whole-frame launch records every tile's cycles; rank 0's map decides the cuts for all.
+        pipe.render(sc["scene"], cam, sky, passes, frame_index=1, rand=synth.frame_rand(1, 1))
+        be.sync()
+        costs = pipe.tile_costs(0)
+        band_cuts = sharding.balanced_cuts(None if costs is None else costs.sum(axis=1), en, H)
+        if world > 1:
+            agreed = torch.tensor(band_cuts, dtype=torch.int64, device=be.device)
+            dist.broadcast(agreed, src=0)
+            band_cuts = [int(v) for v in agreed.tolist()]
+        per_rows, rows, send = sharding.layout_from_cuts(er, band_cuts, H)
     have_rows = rows[0] < rows[1]                                        # a rank past the end of the frame renders no pixels
     gi_bands = gi_mode and bands and world > 1   # (one GPU: the band is the frame, nothing to exchange, the racy apply is fine)
     if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
@@ -248,7 +265,7 @@ def measure_curve(be, dist, args, lanes, shard):
     # --assemble rotate / fixed gather whole frames onto rank k % N / rank 0 instead (bands always gather: a band is a slice).
     assemble = args.assemble if not bands else ("rotate" if args.assemble == "slices" else args.assemble)
     slices = assemble == "slices" and world > 1
-    tgt_rows = max(world * per_rows, send[1]) if bands else (-(-H // world) * world if slices else H)
+    tgt_rows = max(world * per_rows, send[1], (H + per_rows) if band_cuts else 0) if bands else (-(-H // world) * world if slices else H)
     # Slots: step k renders into target k % S on lane (k % S) % D -- two targets per pipeline at least, so that a gather never
     # reads what the next frame of the same pipeline writes; with D > 1 frames in flight every lane has its own stream, and a
     # rank whose launch is held up by one expensive tile fills the rest of the GPU with the next frames' tiles.
@@ -382,7 +399,7 @@ def measure_curve(be, dist, args, lanes, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D}
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts}
 
 
 def run_rank(args, be, dist):
@@ -488,7 +505,8 @@ def run_rank(args, be, dist):
     def parallelism(c):
         root_txt = "k % N for step k (rotating root)" if c["assemble"] == "rotate" and world > 1 else "0"
         if c["shard"] == "bands":
-            return (f"bands x{world}: one frame in {world} row bands of {c['per_rows']} rows"
+            return ((f"bands x{world}: one frame in {world} row bands of about equal measured cost, cut at rows {c['band_cuts']}" if c.get("band_cuts") else
+                     f"bands x{world}: one frame in {world} row bands of {c['per_rows']} rows")
                     + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
                        "winning surfels, deterministic apply), surfel pass replicated" if gi_mode and world > 1 else "")
                     + (", RCCL gather of the (equal-size, padded) bands to rank " + root_txt if world > 1 else ""))
@@ -513,7 +531,7 @@ def run_rank(args, be, dist):
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
                                   "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"],
-                                  "settle_steps": c["settle"],
+                                  "settle_steps": c["settle"], **({"band_rows": c["band_cuts"]} if c.get("band_cuts") else {}),
                                   "per_rank_kernel_ms": [[round(x, 4) for x in v] for v in c["per_rank"]]} for c in curves.values()},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -29,6 +29,39 @@ def band_layout(rank: int, world: int, height: int, align: int = 8):
     return per, (r0, r1), (rank * per, (rank + 1) * per)
 
 
+def balanced_cuts(strip_cost, world: int, height: int, align: int = 8):
+    """Row cuts [0, c1, ..., height] of `world` bands with about the same COST each, from the cost of every `align`-row strip of the
+    frame (the per-tile cycle map of a whole-frame launch, summed over x: dust_hip_pipeline_tile_costs). Equal rows make bands whose
+    launches differ by a third (the castle's top half 0.122 ms, its bottom half 0.096): the frame is done when the slowest is.
+    Greedy prefix cuts at strip boundaries; a band may be empty when there are fewer strips than bands. Falls back to equal rows
+    when the map is unusable."""
+    import numpy as np
+    n = -(-height // align)
+    c = np.asarray(strip_cost, np.float64).reshape(-1) if strip_cost is not None else np.zeros(0)
+    if len(c) != n or not np.isfinite(c).all() or c.sum() <= 0:
+        per = -(-(-(-height // world)) // align) * align
+        return [min(height, r * per) for r in range(world)] + [height]
+    c = c + c.sum() * 1e-3 / n   # (strips nobody timed still take a moment)
+    prefix = np.concatenate([[0.0], np.cumsum(c)])
+    cuts = [0]
+    for r in range(1, world):
+        k = int(np.searchsorted(prefix, prefix[-1] * r / world))            # first strip boundary at or past the r-th share
+        if k > 0 and prefix[-1] * r / world - prefix[k - 1] < prefix[k] - prefix[-1] * r / world:
+            k -= 1                                                           # (the nearer boundary)
+        cuts.append(min(height, max(cuts[-1], k * align)))
+    return cuts + [height]
+
+
+def layout_from_cuts(rank: int, cuts, height: int, align: int = 8):
+    """band_layout for bands of unequal height: (per_rows, (r0, r1), (s0, s1)) with per_rows the tallest band (a multiple of `align`)
+    and the send slice [r0, r0 + per_rows) -- the band and whatever follows it in the rank's render target, which must therefore
+    have at least max(r0) + per_rows rows. Every rank sends per_rows rows; the root keeps the first r1 - r0 of each."""
+    per = max(cuts[r + 1] - cuts[r] for r in range(len(cuts) - 1))
+    per = max(align, -(-per // align) * align)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    return per, (r0, r1), (r0, r0 + per)
+
+
 def sample_frame_index(step: int, rank: int, world: int, first: int = 1) -> int:
     """frame_index of the sample rank `rank` renders in step `step` (frame_index starts at 1, standard.rs:252)."""
     return first + step * world + rank

@@ -46,7 +46,9 @@ class StubPipe:
         r0, r1 = rows if rows[1] else (0, H)
         self.n_render += 1
         self.last = {"passes": passes, "rows": (r0, r1), "frame": frame_index}
-        if passes & L.PASS_PRIMARY:
+        if passes & L.PASS_PRIMARY and self.target is None:
+            self.px = (r1 - r0) * W   # (a frame into the pipeline's own plane: the cost-measuring launch before the targets exist)
+        elif passes & L.PASS_PRIMARY:
             # RGBA16F stand-in: channel 0 = frame index, 1 = rank, 2 = row
             rows_t = torch.arange(r0, r1, dtype=torch.float16).view(-1, 1)
             self.target[r0:r1, :, 0] = float(frame_index % 1024)
@@ -57,6 +59,10 @@ class StubPipe:
         px = getattr(self, "px", 0)
         return Stats(rays=px if i < 4 else 100, hits=px // 2 if i < 4 else 50)
     def mark_kernel_times(self): self.n_render = 0
+    def tile_costs(self, kind=0):
+        c = np.ones((H // 8, W // 8), np.uint32)
+        c[:2] = 5 + rank   # the top strips cost more -- and each rank's own measurement differs: rank 0's decides
+        return c
     def kernel_times(self, mark=True):
         n = self.n_render
         self.n_render = 0
@@ -122,6 +128,9 @@ if rank == 0:
     assert len(be.pipes) == (1 if gi else 4)      # row bands of a non-GI workload: four frames in flight, a pipeline each
     assert strong["settle_steps"] == weak["settle_steps"] == 2 + 5, (strong, weak)
     assert ("in_flight", 1 if gi else 4) in calls
+    if not gi:
+        assert strong["band_rows"] == [0, 8, 40], strong   # 5 strips costing 5,5,1,1,1 (rank 0's map; rank 1 measured 6,6,1,1,1): the boundary nearest to half the cost is after the first
+        assert "equal measured cost" in strong["parallelism"]
     if gi:
         assert "clear" in calls and ("export", 0, 24) in calls
     print("BENCH_RANKS_OK", json.dumps(out)[:200])

@@ -200,3 +200,31 @@ def test_two_rank_gloo_gather():
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert "distributed ok" in outs[0][0]
+
+
+def test_cost_balanced_band_cuts():
+    """sharding.balanced_cuts: bands of about equal measured cost (bench.py --band-cuts cost). Cuts are monotone, 8-row aligned, cover
+    the frame; never worse than equal rows on the maximum band cost by more than one strip; unusable maps fall back to equal rows."""
+    import numpy as np
+    from dust_amd import sharding
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        h = int(rng.integers(8, 1200))
+        n = -(-h // 8)
+        world = int(rng.choice([2, 3, 4, 8]))
+        cost = rng.gamma(0.7, 1.0, n) * (1.0 + 4.0 * (rng.random(n) < 0.15))   # skewed, a few heavy strips
+        cuts = sharding.balanced_cuts(cost, world, h)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == h
+        assert all(a <= b for a, b in zip(cuts, cuts[1:])) and all(c % 8 == 0 or c == h for c in cuts)   # (a band past the frame's end is empty at h)
+        band = lambda a, b: float(cost[a // 8:-(-b // 8)].sum())   # noqa: E731
+        worst = max(band(a, b) for a, b in zip(cuts, cuts[1:]))
+        per = -(-(-(-h // world)) // 8) * 8
+        equal = [min(h, r * per) for r in range(world)] + [h]
+        worst_equal = max(band(a, b) for a, b in zip(equal, equal[1:]))
+        assert worst <= worst_equal + cost.max() + 1e-9
+        lay = [sharding.layout_from_cuts(r, cuts, h) for r in range(world)]
+        pers = {l[0] for l in lay}
+        assert len(pers) == 1 and next(iter(pers)) % 8 == 0 and all(l[2][1] - l[2][0] == l[0] and l[1][1] - l[1][0] <= l[0] for l in lay)
+        assert max(l[2][1] for l in lay) <= h + lay[0][0]   # the render target bench.py allocates (H + per_rows rows) holds every send slice
+    for bad in (None, np.zeros(135), np.full(135, np.nan), np.ones(7)):
+        assert sharding.balanced_cuts(bad, 8, 1080) == [0, 136, 272, 408, 544, 680, 816, 952, 1080]
