@@ -176,6 +176,12 @@ def run_deep(n_scenes, seed0, verbose=True, k0=0):
         scene.add_instance(model, xf.reshape(12))
         oscene.add_instance(0, xf.reshape(12))
         keep = [model]
+        if k % 7 == 3:   # the same deep model a second time, shifted by a few voxels and turned: overlapping three-level instances
+            xf2 = xf.copy()
+            xf2[:, :3] = xf[:, :3] @ np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float32)
+            xf2[:, 3] = (-(xf2[:, :3] @ np.full(3, centre, np.float32)) + rng.integers(-6, 7, 3)).astype(np.float32)
+            scene.add_instance(model, xf2.reshape(12))
+            oscene.add_instance(0, xf2.reshape(12))
         if k % 3 == 0:
             small = P.small_scene(seed=seed, n_models=1, n_instances=2, size=(40, 40, 40))
             m2 = api.Model(ctx, small.models[0][0], small.models[0][1], pal)
