@@ -5,7 +5,8 @@
             frame must equal the frame of a FRESH scene built from the instance list as it stands (the staging ring, the image
             reallocation when the scene grows, the dirty-range copy, the second stream)
   threads : several host threads, a context each, on one device at the same time
-usage: stress_host.py bands|commits|threads [n] [first_seed]"""
+  schedule: big frames under random launch shapes against the default launch
+usage: stress_host.py bands|commits|threads|schedule [n] [first_seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -194,11 +195,62 @@ def threads(n, first):
     return bad
 
 
+def schedule(n, first):
+    """The tile hand-out at scale: frames of 3 600 to 32 400 tiles under random launch shapes -- block size, workgroups per CU, reserved
+    slots, frames-in-flight share (down to a sixteenth of the slots: a hundred tiles per wave), dealt rounds, tile order on or off,
+    several frames in a row so that measured orders are in use -- must equal the default launch plane for plane, GI state included."""
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = S.sky_state()
+    bad = []
+    keys = ("DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RESERVE_BLOCKS", "DUST_HIP_STATIC_ROUNDS", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_SIDE_STREAM")
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        for k_ in keys:
+            os.environ.pop(k_, None)
+        ctx = api.Context(device=0)
+        pal = synth.make_palette(seed)
+        models = small_models(ctx, rng, pal, 3)
+        scene = api.Scene(ctx)
+        for _ in range(int(rng.integers(10, 40))):
+            scene.add_instance(models[int(rng.integers(0, 3))], rand_xf(rng).reshape(12))
+        scene.commit()
+        w, h = [(640, 360), (1280, 720), (1920, 1080)][int(rng.integers(0, 3))]
+        cam = S.camera_for(tuple(float(v) for v in rng.uniform(60, 140, 3)))
+        frames = int(rng.integers(2, 5))
+
+        def run(fif):
+            pipe = pipe_for(ctx, w, h, n0, n5)
+            if fif > 1:
+                pipe.set_frames_in_flight(fif)
+            for f in range(1, frames + 1):
+                pipe.render(scene, cam, sky, GI, frame_index=f, rand=seed + f)
+            hh, sp = pipe.read_gi()
+            return planes(pipe) + [hh, sp.view(np.uint32).copy()]
+
+        want = run(1)
+        env = {"DUST_HIP_BLOCK": str(int(rng.choice([64, 128, 256, 512]))), "DUST_HIP_BLOCKS_PER_CU": str(int(rng.choice([1, 2]))),
+               "DUST_HIP_RESERVE_BLOCKS": str(int(rng.choice([0, 32, 256]))), "DUST_HIP_STATIC_ROUNDS": str(int(rng.choice([0, 1, 2, 3])))}
+        if rng.random() < 0.3:
+            env["DUST_HIP_NO_TILE_ORDER"] = "1"
+        if rng.random() < 0.3:
+            env["DUST_HIP_NO_SIDE_STREAM"] = "1"
+        os.environ.update(env)
+        fif = int(rng.choice([1, 2, 4, 8, 16]))
+        got = run(fif)
+        for k_ in keys:
+            os.environ.pop(k_, None)
+        diff = [i for i, (a, b) in enumerate(zip(want, got)) if not np.array_equal(a, b)]
+        if diff:
+            bad.append(seed)
+            print(f"seed {seed}: {w}x{h}, {frames} frames, {env}, frames in flight {fif}: outputs {diff} differ", flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     t0 = time.time()
-    bad = {"bands": bands, "commits": commits, "threads": threads}[what](n, first)
+    bad = {"bands": bands, "commits": commits, "threads": threads, "schedule": schedule}[what](n, first)
     print(f"{what}: {n} cases, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
