@@ -605,6 +605,7 @@ DustStatus dust_vdb_tree_meta(const DustVdbTree* t, uint32_t* meta_mask, uint32_
   return DUST_OK;
 }
 uint32_t dust_vdb_lca_level(const uint32_t a[3], const uint32_t b[3], uint32_t meta_mask, uint32_t root_level) {
+  if (!a || !b) { (void)fail(DUST_ERR_INVALID_ARGUMENT, "null coordinates"); return 0xFFFFFFFFu; }
   return dust::vdb::Tree::lca_level(a, b, meta_mask, root_level);
 }
 DustStatus dust_vdb_accessor_create(const DustVdbTree* t, DustVdbAccessor** out) {
@@ -633,8 +634,12 @@ void dust_vdb_pool_free(DustVdbPool* p, uint32_t index) {
   p->pool.free(index);
 }
 size_t dust_vdb_pool_num_chunks(const DustVdbPool* p) { return p ? p->pool.num_chunks() : 0; }
-void dust_vdb_bitmask_set(uint64_t* words, size_t index, int32_t value) { dust::vdb::bit_set(words, index, value != 0); }
+void dust_vdb_bitmask_set(uint64_t* words, size_t index, int32_t value) {
+  if (!words) { (void)fail(DUST_ERR_INVALID_ARGUMENT, "null bit mask"); return; }
+  dust::vdb::bit_set(words, index, value != 0);
+}
 size_t dust_vdb_bitmask_iter_set_bits(const uint64_t* words, size_t n_words, uint32_t* out, size_t cap) {
+  if (!words && n_words) { (void)fail(DUST_ERR_INVALID_ARGUMENT, "null bit mask"); return 0; }
   size_t n = 0;
   dust::vdb::for_each_set_bit(words, n_words, [&](uint32_t i) {
     if (out && n < cap) out[n] = i;
