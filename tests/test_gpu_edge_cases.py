@@ -163,3 +163,47 @@ def test_frames_in_flight_changes_no_result():
     for bad in (0, 17):
         with pytest.raises(Exception):
             pipe.set_frames_in_flight(bad)
+
+
+def test_degenerate_cameras_and_transforms_neither_hang_nor_fault():
+    """A host bug upstream (NaN from a look-at at the pole, an uninitialised projection, a collapsed scale) must not take the device
+    down: frames from NaN / infinite / zero / enormous cameras come back at once -- nothing visible --, singular and non-finite
+    instance transforms are refused at dust_hip_scene_add_instance, and a good frame renders afterwards as before."""
+    import time
+    desc = P.small_scene(seed=2, n_models=1, n_instances=2)
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    sky, base = P.sky_state(), P.camera_for((60.0, 50.0, 70.0))
+    good = _pipe(ctx, 64, 32, gi=True)
+    good.render(scene, base, sky, GI, frame_index=1, rand=5)
+    want = _planes(good)
+
+    def cam_with(**kw):
+        c = L.Camera.from_buffer_copy(base)
+        for k, v in kw.items():
+            f = getattr(c, k)
+            if hasattr(f, "__len__"):
+                for i in range(len(f)):
+                    f[i] = v
+            else:
+                setattr(c, k, v)
+        return c
+
+    nan, inf = float("nan"), float("inf")
+    t0 = time.time()
+    for kw in (dict(position=nan), dict(position=inf), dict(position=1e30), dict(view_col0=nan), dict(view_col0=0.0, view_col1=0.0, view_col2=0.0),
+               dict(view_col2=inf), dict(tan_half_fov=0.0), dict(tan_half_fov=nan), dict(tan_half_fov=1e30), dict(near_=1e4, far_=0.1), dict(near_=-5.0)):
+        pipe = _pipe(ctx, 64, 32, gi=True)
+        for f in (1, 2):
+            pipe.render(scene, cam_with(**kw), sky, GI, frame_index=f, rand=5 + f)
+        pipe.read_plane(L.PLANE_DEPTH)
+    assert time.time() - t0 < 20.0
+    model = api.Model(ctx, desc.models[0][0], desc.models[0][1], desc.palette)
+    for mat in (np.zeros((3, 4)), np.full((3, 4), np.nan), np.array([[1, 0, 0, np.inf], [0, 1, 0, 0], [0, 0, 1, 0]]), np.ones((3, 4)), np.eye(3, 4) * 1e-30):
+        s2 = api.Scene(ctx)
+        with pytest.raises(L.DustError):
+            s2.add_instance(model, np.asarray(mat, np.float32).reshape(12))
+    again = _pipe(ctx, 64, 32, gi=True)
+    again.render(scene, base, sky, GI, frame_index=1, rand=5)
+    for x, y in zip(want, _planes(again)):
+        assert np.array_equal(x, y)
