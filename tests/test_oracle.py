@@ -202,3 +202,44 @@ def test_hierarchical_equals_brute_force_frame():
         for name in ("illuminance", "denoised", "albedo", "normal", "depth", "motion", "voxel_id"):
             assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (eye, name)
         assert np.isfinite(a.depth).sum() > 50
+
+
+@pytest.mark.parametrize("seed", [500003, 500010, 500016])
+def test_hierarchical_equals_brute_force_on_deep_trees(seed):
+    """The same on 4096^3 models (three-level hierarchy: what the DEEP kernel variants are compared with): clusters of 16-cells holding
+    1 to 40 bricks, all five passes for two frames, hash and pool included. A slice of tools/oracle_deep_sweep.py (400 scenes clean)."""
+    from dust_amd import synth
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    rng = np.random.default_rng(seed)
+    half = int(rng.integers(2, 6))
+    c0 = int(rng.integers(half, 256 - half))
+    blocks, mats, pal = P.clustered_deep_model(seed=seed, n_cells=int(rng.integers(20, 300)), cell_lo=c0 - half, cell_hi=c0 + half,
+                                               max_bricks=int(rng.choice([2, 12, 40])))
+    xf = np.eye(3, 4, dtype=np.float32)
+    xf[:, 3] = -16.0 * c0
+    oscene = O.Scene()
+    oscene.add_model(blocks, mats, pal, extent=4096)
+    oscene.add_instance(0, xf.reshape(12))
+    oscene.commit()
+    reach = 16.0 * half
+    eye = np.round(rng.uniform(-1.5 * reach, 1.5 * reach, 3) / 16.0) * 16.0 if seed % 2 == 0 else rng.uniform(-1.5 * reach, 1.5 * reach, 3)
+    if abs(eye[0]) + abs(eye[2]) < 1e-3:
+        eye[0] = 3.0
+    cam = P.camera_for(tuple(float(v) for v in eye))
+    w, h = 40, 28
+    states = []
+    for mode in (O.ORC_MODE_HIER, O.ORC_MODE_BRUTE):
+        gi = O.GI(4093, 777)
+        planes = []
+        for f in (1, 2):
+            rnd = synth.frame_rand(seed, f)
+            g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f, mode=mode)
+            planes.append((g.depth.copy(), g.voxel_id.copy(), g.illuminance.copy()))
+        states.append((planes, gi.hash().copy(), gi.pool().copy()))
+    a, b = states
+    assert np.isfinite(a[0][0][0]).mean() > 0.02
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x[0].view(np.uint32), y[0].view(np.uint32)) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+    assert np.array_equal(a[1]["fingerprint"], b[1]["fingerprint"]) and np.array_equal(a[2]["direction"], b[2]["direction"])
