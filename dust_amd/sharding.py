@@ -89,6 +89,13 @@ def assemble_bands(parts, height: int, align: int = 8):
     return torch.cat(rows, dim=0)
 
 
+def assemble_bands_from_cuts(parts, cuts):
+    """Stack gathered bands of unequal height (layout_from_cuts: every part is per_rows tall, band r fills its first cuts[r+1] - cuts[r]
+    rows) back into one frame."""
+    import torch
+    return torch.cat([p[: cuts[r + 1] - cuts[r]] for r, p in enumerate(parts)], dim=0)
+
+
 class AsyncGather:
     """Double-buffered gather of finished frames: the gather of step k overlaps the rendering of step k+1.
 

@@ -161,6 +161,30 @@ WORKER = textwrap.dedent('''
         if rank == 0:
             frame = torch.cat(bg.last(), dim=0)[:Hb].numpy().astype(np.uint16)
             assert np.array_equal(frame, full.illuminance), f"padded band gather != full frame at {Hb} rows"
+    # --- bench.py --band-cuts cost: bands of unequal height (equal measured cost), cuts agreed by broadcast from rank 0; the send
+    # slice is [r0, r0 + per_rows) of a target with H + per_rows rows, the root keeps each part's first r1 - r0 rows
+    Hc = 40
+    mine = sharding.balanced_cuts([5.0 + rank, 5.0, 1.0, 1.0, 1.0], world, Hc)   # (each rank's own map differs a little: rank 0's counts)
+    agreed = torch.tensor(mine, dtype=torch.int64)
+    dist.broadcast(agreed, src=0)
+    cuts = [int(v) for v in agreed.tolist()]
+    assert cuts == [0, 8, 40]
+    per, rows_c, send_c = sharding.layout_from_cuts(rank, cuts, Hc)
+    assert per == 32 and send_c[1] - send_c[0] == per
+    full = P.render_oracle(s, cam, sky, W, Hc, passes, noise[1], 7)
+    tgc = [torch.zeros((Hc + per, W, 4), dtype=torch.int32) for _ in range(2)]
+    cg = sharding.AsyncGather(dist, tgc[0][send_c[0]:send_c[1]], rotate=True)
+    for k in range(4):
+        cg.wait_slot(k % 2)
+        gb = P.render_oracle(s, cam, sky, W, Hc, passes, noise[1], 7, rows=rows_c)
+        tgc[k % 2][rows_c[0]:rows_c[1]] = torch.from_numpy(gb.illuminance[rows_c[0]:rows_c[1]].astype(np.int32))
+        cg.submit_view(tgc[k % 2][send_c[0]:send_c[1]])
+        root = cg.last_root()
+        cg.finish()
+        assert root == k % world
+        if rank == root:
+            frame = sharding.assemble_bands_from_cuts(cg.last(), cuts).numpy().astype(np.uint16)
+            assert np.array_equal(frame, full.illuminance), "bands of equal cost != full frame"
     if rank == 0:
         print("distributed ok")
     dist.barrier()
