@@ -130,3 +130,12 @@ def test_valid_handles_with_null_arguments_do_not_crash_either():
                  "dust_hip_scene_add_instance", "dust_hip_pipeline_configure_gi", "dust_hip_pipeline_gi_exchange", "dust_hip_tone_map",
                  "dust_hip_pipeline_set_frames_in_flight", "dust_hip_pipeline_pass_stats"):
         assert rets[name] != "0", f"{name} accepted null arguments"
+
+
+def test_integration_doc_declares_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding (the Rust extern block a maintainer would add): it names exactly the functions
+    include/dust_hip.h declares."""
+    header = set(re.findall(r"\b(dust_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "dust_hip.h")).read()))
+    doc = set(re.findall(r"pub fn (dust_[a-z0-9_]+)", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert header == set(L.SYMBOLS)
+    assert doc == header, (sorted(header - doc), sorted(doc - header))
