@@ -42,7 +42,7 @@ hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
 constexpr uint32_t kTileOrderMaxBand = 65536;  // (kernels.hip)
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s);
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, uint32_t total, uint32_t per, hipStream_t s);
 hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s);
 }  // namespace dust
 
@@ -329,6 +329,7 @@ struct Tuning {
   bool no_gather_order = false; // DUST_HIP_NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
   bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
   bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
+  bool equal_bands = false;     // DUST_HIP_EQUAL_BANDS: bands of equal tile count (round 3) instead of equal measured cost
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
   bool no_side_stream = false;  // DUST_HIP_NO_SIDE_STREAM: the surfel pass on the main stream, in place
   uint32_t side_share = 0;      // DUST_HIP_SIDE_SHARE: percent of the workgroup slots the surfel pass takes on the second stream (0: by ray counts)
@@ -348,6 +349,7 @@ struct Tuning {
     t.no_gather_order = std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;
     t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
     t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
+    t.equal_bands = std::getenv("DUST_HIP_EQUAL_BANDS") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
     t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
     t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
@@ -371,6 +373,7 @@ struct DustHipPipeline {
   // valid for the tile grid they were recorded on
   struct TileHistory {
     DeviceBuffer cost, order;
+    DeviceBuffer cuts;       // kRegions + 1 tile indices: the cost-balanced bands order[] was made for (FrameArgs::band_cuts)
     uint32_t tiles_x = 0, tiles_y = 0, capacity = 0, age = 0;
     uint32_t refresh = 8;    // launches between two measurements of a view that stands still (kOrderRefresh, doubling up to kOrderRefreshMax)
     uint64_t view = 0;       // view_key() of the launch the costs / the order were taken under
@@ -1301,7 +1304,7 @@ extern "C" DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_
 // kernels' costs drift as the hash fills: they keep being looked at).
 constexpr uint32_t kOrderRefresh = 8, kOrderRefreshMax = 64;
 static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a, hipStream_t st) {
-  a.tile_order = nullptr; a.tile_cost = nullptr;
+  a.tile_order = nullptr; a.tile_cost = nullptr; a.band_cuts = nullptr;
   if (p->tune.no_tile_order) return DUST_OK;
   DustHipPipeline::TileHistory& h = p->tile_history[kind];
   const uint32_t total = a.tiles_x * a.tiles_y;
@@ -1310,6 +1313,7 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
   if (total > h.capacity) {
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(h.cost.alloc(size_t(total) * 4)); HIP_TRY(h.order.alloc(size_t(total) * 4));
+    if (!h.cuts.p) HIP_TRY(h.cuts.alloc(size_t(dust::kRegions + 1) * 4));
     h.capacity = total; h.tiles_x = h.tiles_y = 0;
   }
   if (h.tiles_x != a.tiles_x || h.tiles_y != a.tiles_y) {  // a new grid: tiles nobody has timed count as free
@@ -1317,12 +1321,16 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     HIP_TRY(hipMemsetAsync(h.cost.p, 0, size_t(total) * 4, st));
   }
   if (h.recorded) {
-    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p), total, per_band, st));
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p),
+                                    p->tune.equal_bands ? nullptr : static_cast<uint32_t*>(h.cuts.p), total, per_band, st));
     h.recorded = false; h.ordered = true; h.age = 0;
   } else if (h.ordered) {
     ++h.age;
   }
-  if (h.ordered) a.tile_order = static_cast<const uint32_t*>(h.order.p);
+  if (h.ordered) {
+    a.tile_order = static_cast<const uint32_t*>(h.order.p);
+    if (!p->tune.equal_bands) a.band_cuts = static_cast<const uint32_t*>(h.cuts.p);
+  }
   const bool still = h.ordered && h.view == p->view_key;
   if (!still) h.refresh = kOrderRefresh;
   if (!still || h.age + 1 >= h.refresh) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
@@ -1851,8 +1859,8 @@ DustStatus dust_hip_pipeline_exposure(DustHipPipeline* p, float* avg_luminance, 
 }
 DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
                                 uint32_t out_words, uint32_t n) {
-  static const uint32_t kWords[14][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}, {2, 2}, {1, 1}};
-  if (!ctx || !in || !out || fn >= 14) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
+  static const uint32_t kWords[15][2] = {{9, 3}, {9, 3}, {9, 3}, {3, 1}, {1, 3}, {4, 1}, {1, 3}, {4, 2}, {2, 4}, {4, 1}, {3, 4}, {6, 3}, {2, 2}, {1, 1}, {1, 2}};
+  if (!ctx || !in || !out || fn >= 15) return fail(DUST_ERR_INVALID_ARGUMENT, "bad device function");
   if (in_words != kWords[fn][0] || out_words != kWords[fn][1]) return fail(DUST_ERR_INVALID_ARGUMENT, "row width does not match the function");
   if (n == 0) return DUST_OK;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1872,14 +1880,22 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
     for (uint32_t i = 0; i < n; ++i) { out[size_t(i) * 2] = k[i]; out[size_t(i) * 2 + 1] = v[i]; }
     return DUST_OK;
   }
-  if (fn == 13) {  // the cost-ordered hand-out's sorter (k_tile_order) on caller-given tile costs: rows in = cycles, rows out = tile order
-    DeviceBuffer cost, order;
+  if (fn == 13 || fn == 14) {  // the cost-ordered hand-out's sorter (k_tile_order) on caller-given tile costs: rows in = cycles, rows out = tile order
+    // fn 14: with cost-balanced bands; out rows are then {order, cut}: the kRegions + 1 cuts in the second word of the first rows (n >= 9)
+    if (fn == 14 && (out_words != 2 || n < dust::kRegions + 1)) return fail(DUST_ERR_INVALID_ARGUMENT, "fn 14 wants 2 output words and at least 9 rows");
+    DeviceBuffer cost, order, cuts;
     HIP_TRY(cost.upload(in, size_t(n) * 4, ctx->stream));
     HIP_TRY(order.alloc(size_t(n) * 4));
+    HIP_TRY(cuts.alloc(size_t(dust::kRegions + 1) * 4));
     HIP_TRY(hipMemsetAsync(order.p, 0xFF, size_t(n) * 4, ctx->stream));
-    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), n, (n + dust::kRegions - 1) / dust::kRegions, ctx->stream));
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), fn == 14 ? static_cast<uint32_t*>(cuts.p) : nullptr,
+                                    n, (n + dust::kRegions - 1) / dust::kRegions, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(copy_wait(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (fn == 13) { HIP_TRY(copy_wait(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream)); return DUST_OK; }
+    std::vector<uint32_t> o(n), c(dust::kRegions + 1);
+    HIP_TRY(copy_wait(o.data(), order.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(copy_wait(c.data(), cuts.p, c.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) { out[size_t(i) * 2] = o[i]; out[size_t(i) * 2 + 1] = i < c.size() ? c[i] : 0u; }
     return DUST_OK;
   }
   DeviceBuffer din, dout;

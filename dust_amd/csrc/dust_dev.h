@@ -175,6 +175,8 @@ struct FrameArgs {
   // of the same pass k_tile_order turns that into tile_order -- per XCD band, most expensive first --, which maps ticket ->
   // tile. Both null on the first frame of a pass (identity order) or when switched off.
   DUST_RO(uint32_t) tile_order;
+  DUST_RO(uint32_t) band_cuts;        // with tile_order: kRegions + 1 tile indices, band b = [cuts[b], cuts[b + 1]): contiguous bands of about
+                                      // EQUAL MEASURED COST instead of equal tile counts (k_tile_order). Null: tiles_per_band each
   DUST_RW(uint32_t) tile_cost;
   DUST_RW(uint32_t) work_counters;    // 8 per-band tile counters, kCounterStride apart, zero at launch
   DUST_RW(uint32_t) next_work_counters;  // the set the next launch of this pass kind uses: this launch zeroes it

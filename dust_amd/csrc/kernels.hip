@@ -37,6 +37,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // Section timers for tools/kernel_sections.py: compiled in only with -DDUST_PROFILE (a separate, never shipped
 // .so). PROF_ENTER/PROF_LEAVE add -/+ s_memtime to a per-wave LDS bucket (fire-and-forget ds_add by the first
 // active lane), so a bucket ends up holding the wave's inclusive cycles in that section.
+// -DDUST_WAVE_TIMES (never shipped; tools/wave_times.py): every wave of the fused kernel writes when it started, when the staging
+// barrier let it go and when it ran out of tiles -- on the shader clock (s_memtime) and on the constant 100 MHz wall clock
+#ifdef DUST_WAVE_TIMES
+__device__ unsigned long long g_wave_times[8192][12];
+#endif
 #ifdef DUST_PROFILE
 constexpr int kProfBuckets = 24;
 __shared__ unsigned long long g_prof[16][kProfBuckets];
@@ -1392,7 +1397,18 @@ __device__ __forceinline__ void account_tile(ArgsRef a, uint32_t next_tile) {
   }
 }
 // `ticket` = band * tiles_per_band + pos: position `pos` of the band's order
-__device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint32_t pos, Packet& p) {
+// first tile and tile count of band b: the launch's equal split, or the cost-balanced cuts that came with the order
+__device__ __forceinline__ void band_range(ArgsRef a, uint32_t b, uint32_t& lo, uint32_t& n) {
+  if (a.band_cuts) {
+    lo = a.band_cuts[b];
+    n = a.band_cuts[b + 1u] - lo;
+  } else {
+    const uint32_t total = a.tiles_x * a.tiles_y, per = a.tiles_per_band;
+    lo = b * per < total ? b * per : total;
+    n = total - lo < per ? total - lo : per;
+  }
+}
+__device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint32_t pos, uint32_t per, Packet& p) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t tile = ticket;
   if (a.tile_order) {
@@ -1401,7 +1417,6 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     // wave shares a SIMD with three others. The position in the band's order says how expensive the tile was last time:
     // the few at the front get the arbiter's priority, so the critical path runs at nearly a lone wave's speed while the
     // waves that give way have slack.
-    const uint32_t per = a.tiles_per_band;
     const uint32_t rank = pos < (per >> 5) ? 3u : (pos < (per >> 3) ? 2u : (pos < (per >> 1) ? 1u : 0u));
     const uint32_t prio = rank > a.prio_floor ? rank : a.prio_floor;
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -1418,8 +1433,6 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
   p.valid = p.px < a.width && p.py < a.row_end;
 }
 __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) {
-  const uint32_t total = a.tiles_x * a.tiles_y;
-  const uint32_t per = a.tiles_per_band;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t own = blockIdx.x & 7u;
   PROF_ENTER(P_GRAB);
@@ -1429,7 +1442,9 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     const uint32_t r = w.round;
     w.round = r + 1u;
     const uint32_t pos = r * W + ((r & 1u) ? W - 1u - i : i);
-    if (pos < per && own * per + pos < total) { packet_of_tile(a, own * per + pos, pos, p); PROF_LEAVE(P_GRAB); return true; }
+    uint32_t blo, bn;
+    band_range(a, own, blo, bn);
+    if (pos < bn) { packet_of_tile(a, blo + pos, pos, bn, p); PROF_LEAVE(P_GRAB); return true; }
     w.round = a.static_rounds;  // (a band shorter than the deal: on to the queue, which is empty for it too)
   }
   unsigned long long* q = block_queue(a);
@@ -1442,7 +1457,9 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(old >> 32));
     if (next < end) {  // (the queue holds tickets of ONE band: the high word's band)
       const uint32_t band = (own + (uint32_t)__builtin_amdgcn_readfirstlane((int)*band_try)) & 7u;
-      packet_of_tile(a, next, next - band * per, p);
+      uint32_t blo, bn;
+      band_range(a, band, blo, bn);
+      packet_of_tile(a, next, next - blo, bn, p);
       PROF_LEAVE(P_GRAB);
       return true;
     }
@@ -1458,18 +1475,18 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
         return false;
       }
       const uint32_t band = (own + bt) & 7u;
+      uint32_t blo, bn;
+      band_range(a, band, blo, bn);
       uint32_t k = 0;
       if (lane == 0) k = a.static_rounds * band_static_tickets(band) + atomicAdd((uint32_t*)&a.work_counters[band * kCounterStride], kGrabBatch);
       k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-      const uint32_t lo = band * per + k;
-      uint32_t hi = band * per + (k + kGrabBatch < per ? k + kGrabBatch : per);
-      hi = hi < total ? hi : total;
-      if (k < per && lo < hi) {
+      if (k < bn) {
+        const uint32_t lo = blo + k, hi = blo + (k + kGrabBatch < bn ? k + kGrabBatch : bn);
         if (lane == 0) {
           *band_try = bt;
           *qv = ((unsigned long long)hi << 32) | (unsigned long long)(lo + 1u);  // one 8-byte LDS store: the batch goes live
         }
-        packet_of_tile(a, lo, k, p);
+        packet_of_tile(a, lo, k, bn, p);
         PROF_LEAVE(P_GRAB);
         return true;
       }
@@ -1742,7 +1759,14 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
 template <int MODE>
 __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao(const FrameArgs) {
   ArgsRef a0 = launch_args();
+#ifdef DUST_WAVE_TIMES
+  const unsigned long long wt0 = __builtin_amdgcn_s_memtime(), ww0 = wall_clock64();
+  unsigned long long wt_tiles = 0, wt_last_tile = 0, wt_last_start = 0, wt_prev_tile = 0, wt_prev_start = 0;
+#endif
   stage_roots(a0);
+#ifdef DUST_WAVE_TIMES
+  const unsigned long long wt1 = __builtin_amdgcn_s_memtime();
+#endif
   uint32_t* cand = wave_cand_list(a0);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};
   WorkCursor wc = cursor_begin();
@@ -1750,9 +1774,25 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
   while (next_packet(a0, wc, p)) {
     float hitT;
     uint32_t npk;
+#ifdef DUST_WAVE_TIMES
+    wt_tiles += 1;
+    wt_prev_tile = wt_last_tile; wt_prev_start = wt_last_start;
+    wt_last_tile = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)p.py) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)p.px);
+    wt_last_start = wall_clock64();
+#endif
     primary_packet<MODE>(reload_args(a0), p, cand, st, false, hitT, npk);
     ao_packet<MODE>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));  // unpack(0,0,0,0) == (0,0,0)
   }
+#ifdef DUST_WAVE_TIMES
+  if ((threadIdx.x & 63u) == 0) {
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w < 8192u) {
+      g_wave_times[w][0] = wt0; g_wave_times[w][1] = wt1; g_wave_times[w][2] = __builtin_amdgcn_s_memtime();
+      g_wave_times[w][3] = ww0; g_wave_times[w][4] = wall_clock64(); g_wave_times[w][5] = wt_tiles;
+      g_wave_times[w][6] = wt_last_tile; g_wave_times[w][7] = wt_last_start; g_wave_times[w][8] = wt_prev_tile; g_wave_times[w][9] = wt_prev_start;
+    }
+  }
+#endif
   prof_end();
   flush_stats<MODE>(a0, 0, st);
   flush_stats<MODE>(a0, 1, st_sun);
@@ -2769,12 +2809,60 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
 // the band's tiles into 32 cost classes a quarter octave apart, most expensive class first. One workgroup per band, wave
 // ballots for the ranks (as radix.hip), ~5 us. The order only decides which wave traces which tile when -- never a result.
 constexpr uint32_t kTileOrderMaxBand = 65536;  // tiles per band the sorter stages in LDS (an 8K frame has 64 800)
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t total, uint32_t per) {
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t* __restrict__ cuts,
+                                                       uint32_t total, uint32_t per) {
   __shared__ uint32_t cnt[16][32];
   __shared__ uint32_t wave_part[16];
+  __shared__ unsigned long long wave_sum[16];
+  __shared__ uint32_t s_cuts[kRegions + 1];
   __shared__ uint8_t octave[kTileOrderMaxBand];  // quarter octaves of each tile's cost: the only pass over global memory
-  const uint32_t lo = blockIdx.x * per < total ? blockIdx.x * per : total, hi = lo + per < total ? lo + per : total;
-  const uint32_t n = hi - lo, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // Bands of equal COST, not of equal tile count. With equal counts the bands of a frame differ by tens of percent in work (sky
+  // above, a courtyard full of detail below): the waves of the light bands then end up stealing the heavy band's remaining tiles,
+  // which are its cheapest but still mid-sized, at a time when only small tiles should be left -- 8 % of the fused kernel's wave
+  // time idled behind them at 1080p (tools/wave_times.py). Every workgroup works the cuts out for itself (a scan over the cost
+  // map: thread t sums a contiguous run, the runs are prefix-summed through shuffles and LDS, and the thread whose run holds
+  // the k/8 point of the total walks it); a cut is a tile index in screen order, so a band is still contiguous (one XCD's L2).
+  if (cuts) {
+    const uint32_t run = (total + 1023u) / 1024u;
+    const uint32_t r0 = min(threadIdx.x * run, total), r1 = min(r0 + run, total);
+    unsigned long long mine = 0;
+    for (uint32_t i = r0; i < r1; ++i) mine += max(cost[i], 1u);  // (a tile nobody has timed yet counts as cheap)
+    unsigned long long inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const unsigned long long up = (unsigned long long)__shfl_up((long long)inc, (int)d);
+      if (lane >= d) inc += up;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = threadIdx.x == kRegions ? total : 0u;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += wave_sum[w]; all += wave_sum[w]; }
+    const unsigned long long excl = before + inc - mine;
+    for (uint32_t k = 1; k < kRegions; ++k) {
+      const unsigned long long target = all / kRegions * k;
+      if (mine != 0 && excl < target && target <= excl + mine) {
+        unsigned long long c = excl;
+        uint32_t i = r0;
+        for (; i < r1; ++i) { c += max(cost[i], 1u); if (c >= target) break; }
+        s_cuts[k] = min(i + 1u, total);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // (a band the sorter cannot stage -- frames beyond 8K with most of their cost in one corner: the equal split)
+      bool ok = true;
+      for (uint32_t k = 0; k < kRegions; ++k) ok = ok && s_cuts[k] <= s_cuts[k + 1] && s_cuts[k + 1] - s_cuts[k] <= kTileOrderMaxBand;
+      if (!ok) for (uint32_t k = 0; k <= kRegions; ++k) s_cuts[k] = min(k * per, total);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x <= kRegions) cuts[threadIdx.x] = s_cuts[threadIdx.x];
+  } else {
+    if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = min(threadIdx.x * per, total);
+    __syncthreads();
+  }
+  const uint32_t lo = s_cuts[blockIdx.x], hi = s_cuts[blockIdx.x + 1u];
+  const uint32_t n = hi - lo;
   uint32_t top = 0;
   for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
     const uint32_t c = cost[lo + i];  // (stays: a launch that measures overwrites the tiles it traces, and the map can be read back)
@@ -2838,9 +2926,10 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
   }
 }
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t total, uint32_t per, hipStream_t s) {
+// cuts: kRegions + 1 tile indices the kernel fills in (the cost-balanced bands the order is made for), or null = equal bands of `per`
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, uint32_t total, uint32_t per, hipStream_t s) {
   if (per > kTileOrderMaxBand) return hipErrorInvalidValue;  // (the caller keeps screen order for frames beyond 8K)
-  hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, total, per);
+  hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, cuts, total, per);
   return hipGetLastError();
 }
 
@@ -2964,6 +3053,11 @@ extern "C" int dust_hip_pool_stats(unsigned long long* out) {
   for (int i = 0; i < 16; ++i) out[i] = h[i];
   unsigned long long z[16] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_pool_stats), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef DUST_WAVE_TIMES
+extern "C" int dust_hip_wave_times(unsigned long long* out) {  // 8192 x 6, of the last fused launch
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dust::g_wave_times), sizeof(unsigned long long) * 8192 * 12) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef DUST_PROFILE

@@ -424,7 +424,8 @@ DustStatus dust_hip_pipeline_set_frames_in_flight(DustHipPipeline*, uint32_t n);
  *   10  CubedNormalize + normal2FaceID (normal.glsl:9-18,39-43)        d[3]                              n[3] face
  *   11  rotateVectorByNormal (normal.glsl:31-37)                       n[3] target[3]                    v[3]
  *   12  (not per row) the surfel pass's stable radix sort of the n rows by key    key value              key value
- *   13  (not per row) the cost-ordered hand-out's sorter: the n rows are tile costs in tile order, 8 bands     cycles     tile index */
+ *   13  (not per row) the cost-ordered hand-out's sorter: the n rows are tile costs in tile order, 8 bands     cycles     tile index
+ *   14  (not per row) the same with the bands cut at equal measured cost (what a frame uses), n >= 9           cycles     tile index, cut (the 9 band cuts in rows 0..8) */
 DustStatus dust_hip_device_eval(DustHipContext*, uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out,
                                 uint32_t out_words, uint32_t n);
 
