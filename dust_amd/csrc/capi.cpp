@@ -333,6 +333,8 @@ struct Tuning {
   bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
   bool no_side_stream = false;  // DUST_HIP_NO_SIDE_STREAM: the surfel pass on the main stream, in place
   uint32_t side_share = 0;      // DUST_HIP_SIDE_SHARE: percent of the workgroup slots the surfel pass takes on the second stream (0: by ray counts)
+  uint32_t static_rounds = 0xFFFFFFFFu;  // DUST_HIP_STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
+  uint32_t side_prio = 3;       // DUST_HIP_SIDE_PRIO: issue priority floor of the surfel pass on the second stream
   bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
                                 // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -342,7 +344,8 @@ struct Tuning {
   static Tuning from_environment() {
     Tuning t;
     t.debug = num("DUST_HIP_DEBUG", 0);
-    t.block = std::min(1024u, std::max(64u, num("DUST_HIP_BLOCK", 512) & ~63u));  // (<= the launch bounds of the kernels it is used with)
+    t.block = std::min(512u, std::max(128u, num("DUST_HIP_BLOCK", 512) & ~127u));  // <= the kernels' launch bounds (512); an even number of
+                                                                                    // waves keeps the LDS areas behind the per-wave lists 16-byte aligned
     t.blocks_per_cu = std::max(1u, num("DUST_HIP_BLOCKS_PER_CU", 2));
     t.reserve_blocks = num("DUST_HIP_RESERVE_BLOCKS", 0) & ~7u;  // whole rounds over the 8 XCDs
     t.no_fuse = std::getenv("DUST_HIP_NO_FUSE") != nullptr;
@@ -354,6 +357,8 @@ struct Tuning {
     t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
     t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
     t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
+    t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
+    t.side_prio = std::min(3u, num("DUST_HIP_SIDE_PRIO", 3));
     if (t.side_share) t.side_share = std::min(90u, std::max(5u, t.side_share));
     return t;
   }
@@ -1356,7 +1361,7 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
   const uint32_t block = tune.block;
     dust::FrameArgs b = a;  // 64 consecutive surfels x one ray kind per wavefront: one row of "tiles", cosine items then sun items
     // on the second stream the pass is the longer of the two sides that share the SIMDs: its waves win the issue arbitration
-    if (st != ctx->stream) b.prio_floor = std::getenv("DUST_HIP_SIDE_PRIO") ? uint32_t(std::atoi(std::getenv("DUST_HIP_SIDE_PRIO"))) : 3u;
+    if (st != ctx->stream) b.prio_floor = tune.side_prio;
     b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
     b.tiles_y = 1;
     take_counters(p, 3, b);
@@ -1464,6 +1469,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.accum_count = p->accum_count;
   const Tuning& tune = p->tune;
   a.debug = tune.debug;
+  a.static_rounds_request = tune.static_rounds;
   for (const DustHipModel* m : s->models) a.deep |= m->dev.n_levels == 3 ? 1u : 0u;
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;

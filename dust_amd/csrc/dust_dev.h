@@ -171,6 +171,7 @@ struct FrameArgs {
   uint32_t tiles_per_band;    // ceil(tiles / 8): the launch's hand-out schedule, filled in at launch (kernels.hip, with_schedule)
   uint32_t tiles_x_magic;     // floor(2^32 / tiles_x) + 1: __umulhi(tile, magic) == tile / tiles_x
   uint32_t static_rounds;     // rounds of a band's order that are dealt to its waves; the rest is grabbed
+  uint32_t static_rounds_request;  // DUST_HIP_STATIC_ROUNDS (0xFFFFFFFF: the default of with_schedule)
   // Cost-ordered work distribution: every wave records the cycles it spent on each tile (tile_cost); before the next launch
   // of the same pass k_tile_order turns that into tile_order -- per XCD band, most expensive first --, which maps ticket ->
   // tile. Both null on the first frame of a pass (identity order) or when switched off.

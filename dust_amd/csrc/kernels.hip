@@ -1380,7 +1380,10 @@ __device__ __forceinline__ WorkCursor cursor_begin() {
 // with ds_add_rtn_u64. The wave that finds it exactly empty refills it with kGrabBatch consecutive tiles -- one device-scope
 // atomic on the band's counter per batch instead of one per tile (a ~2 us round trip on which each wave used to spend 16 %
 // of its time) -- and the others retry; neighbouring tiles run at the same time on the same CU. -1.5 % to -3 % per kernel.
-constexpr uint32_t kGrabBatch = 4;
+#ifndef DUST_GRAB_BATCH
+#define DUST_GRAB_BATCH 4
+#endif
+constexpr uint32_t kGrabBatch = DUST_GRAB_BATCH;
 constexpr uint32_t kQueueDone = 0x80000000u;  // {end = 0, next >= kQueueDone}: no tiles left anywhere
 __device__ __forceinline__ unsigned long long* block_queue(ArgsRef a) {  // behind the per-wave candidate lists, zeroed by stage_roots
   return reinterpret_cast<unsigned long long*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u));
@@ -2947,7 +2950,7 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   const uint32_t waves = ((grid + kRegions - 1u) / kRegions) * (block / 64u);  // the fullest band's
   const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;
   a.static_rounds = rounds >= 1u ? 1u : 0u;  // (see next_packet: dealing more than the first round was measured and lost)
-  if (const char* e = getenv("DUST_HIP_STATIC_ROUNDS")) a.static_rounds = (uint32_t)atoi(e);
+  if (a.static_rounds_request != 0xFFFFFFFFu) a.static_rounds = a.static_rounds_request;
   return a;
 }
 // kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model)
