@@ -76,6 +76,15 @@ def parse(argv=None):
                          "tile's cycles, rank 0's map decides); rows = equal row counts")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--camera", choices=["still", "orbit"], default="still",
+                    help="orbit: the headline becomes the MOVING view (eye on a circle round the castle, the teapot of examples/castle.rs:287-291 "
+                         "swinging, set_transform + commit every frame); the default line carries it as curves.moving next to the still view")
+    ap.add_argument("--no-extra-curves", action="store_true",
+                    help="one GPU, default workload: skip curves.moving / gi_1080p / primary_ao_4k / deep (short runs after the headline's timed region)")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra curve")
+    ap.add_argument("--assets", default=None,
+                    help="directory with the reference's LFS assets (castle.vox, teapot.vox, stbn_scalar_*.png, stbn_unitvec3_cosine_*.png): a file "
+                         "whose sha256 is the oid in /root/reference/assets/* replaces its stand-in, and config.workload says so (SURVEY 8d)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline traces (0 = auto)")
     a = ap.parse_args(argv)
     a.shard = a.shard or a.gi_shard or "both"
@@ -109,6 +118,8 @@ class HipBackend:
         from dust_amd import scenes as P  # scene helpers + packaged sky; the oracle is only imported in the cpu_baseline leg
         self.torch, self.L, self.api, self.sharding, self.synth, self.P = torch, L, api, sharding, synth, P
         self.rank, self.local_rank, self.world = rank, local_rank, world
+        from dust_amd import assets as _assets
+        self.assets = _assets.Assets(None)  # main() replaces it when --assets is given
         self.device = torch.device("cuda", local_rank)
         torch.cuda.set_device(local_rank)
         # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
@@ -178,10 +189,13 @@ class HipBackend:
                        n_bricks=int(len(blocks)), deep=(blocks, mats, pal, xf))
             eye, target = (300.0, 200.0, -150.0), (0.0, 0.0, 0.0)  # inside the volume
         else:
-            data, info = synth.castle_scene(scale=args.scale)
+            data, info, real = self.assets.castle(args.scale)   # the reference's castle.vox if --assets holds it (sha256), else the stand-in
             t0 = time.time()
             desc = P.SceneDesc.from_vox(data)  # dust_vox_load: parse + tree build + flatten, models in parallel threads
             t_load = time.time() - t0
+            if info is None:
+                info = {"n_models": len(desc.models), "n_instances": len(desc.instances), "n_voxels": int(sum(len(m) for _, m in desc.models))}
+            out["real_castle"] = real
             scene = P.hip_scene(self.ctx, desc)
             s = args.scale
             eye, target = (122.0 * s, 300.61 * s, 54.45 * s), (0.0, 0.0, 0.0)  # examples/castle.rs:120-129, fov pi/4
@@ -191,7 +205,7 @@ class HipBackend:
         return out
 
     def noise(self):
-        return self.synth.stbn_scalar(), self.synth.stbn_unitvec3_cosine()
+        return self.assets.noise()   # the reference's STBN textures if --assets holds them (sha256), else the stand-ins
 
     def bind_target(self, pipe, tensor):
         pipe.bind_plane(self.L.PLANE_ILLUMINANCE, tensor.data_ptr(), tensor.numel() * 2)
@@ -402,6 +416,171 @@ def measure_curve(be, dist, args, lanes, shard):
             "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts}
 
 
+def compact(curve, gi_mode):
+    """A measured curve as the short record the default line carries under `curves` (same accounting as the headline)."""
+    acct = account(curve, gi_mode)
+    d = acct["dominant"]
+    ms = curve["ms"]
+    fused = ms[1] == 0.0
+    kernels = dict({"k_primary_ao": round(ms[0], 4)} if fused else {"k_primary": round(ms[0], 4), "k_ambient_occlusion": round(ms[1], 4)},
+                   **acct["kernels_ms_extra"])
+    return {"value": round(curve["mrays"], 2), "unit": "Mrays/s", "ms_per_step": round(curve["ms_per_step"], 4),
+            "rays_per_step": int(curve["rays_per_step"]), "settle_steps": curve["settle"], "kernels_ms": kernels,
+            "roofline": {"kernel": "k_" + d[0], "achieved": round(acct["achieved"], 3), "unit": "GB/s", "frac": round(acct["achieved"] / HBM_PEAK_GBPS, 6),
+                         "algorithmic_bytes_per_launch": int(d[1]), "kernel_ms": round(d[2], 4)}}
+
+
+def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, omega=0.25):
+    """The reference is a real-time renderer: an FPS camera and a teapot that swings (examples/castle.rs:105-130,287-291). Here the
+    eye rides a circle round the castle at `omega` rad/s (60 frames a second of scene time), the teapot follows
+    Transform::from_translation((sin t * 50, 200, 0)) -- set_transform + commit every frame, motion vectors against the previous
+    frame's transform -- and every launch re-measures its tiles. One GPU; the castle's instances plus the teapot."""
+    import math
+    import numpy as np
+    api, L, synth, P = be.api, be.L, be.synth, be.P
+    W, H = args.width, args.height
+    ctx, base = lane.ctx, lane.sc
+    tea_bytes, tea_real = be.assets.teapot()
+    tdesc = P.SceneDesc.from_vox(tea_bytes)
+    tea_model = api.Model(ctx, tdesc.models[0][0], tdesc.models[0][1], tdesc.palette)
+    scene = api.Scene(ctx)
+    for model, (_, t) in zip(base["scene"]._models, base["desc"].instances):
+        scene.add_instance(model, t)
+    home = np.asarray(tdesc.instances[0][1], np.float32).reshape(3, 4)
+
+    def tea_xf(t):
+        m = home.copy()
+        m[:, 3] += np.array([math.sin(t) * 50.0, 200.0, 0.0], np.float32)   # castle.rs:287-291
+        return m
+
+    def cols(m34):   # 3x4 row-major -> mat4 column-major (the `instances[]` entry of layout.playout:72)
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :] = m34
+        return np.ascontiguousarray(m.T).reshape(16)
+    tea = scene.add_instance(tea_model, tea_xf(0.0).reshape(12))
+    scene.commit()
+    pipe = api.StandardPipeline(ctx, W, H)
+    pipe.set_noise(5, noise5)
+    sky = be.sky_struct(base["sky"])
+    sc = args.scale
+    eye0 = (122.0 * sc, 300.61 * sc, 54.45 * sc)
+    radius, th0 = math.hypot(eye0[0], eye0[2]), math.atan2(eye0[2], eye0[0])
+    n = settle + steps
+    cams, xfs = [], []
+    for k in range(n + 1):
+        t = k / fps
+        eye = (radius * math.cos(th0 + omega * t), eye0[1], radius * math.sin(th0 + omega * t))
+        cams.append(api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), api.PinholeProjection()))
+        xfs.append(tea_xf(t))
+    prevs = [cols(xfs[max(k - 1, 0)]) for k in range(n + 1)]
+    flat = [np.ascontiguousarray(x.reshape(12)) for x in xfs]
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+
+    def frame(k, count=False):
+        scene.set_transform(tea, flat[k], prevs[k])
+        scene.commit()
+        pipe.render(scene, cams[k], sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=1 + k, rand=synth.frame_rand(1, 1 + k))
+    # untimed: the rays of exactly the frames that are timed below (they differ from frame to frame)
+    rays = 0
+    for k in range(settle, n):
+        frame(k, count=True)
+        be.sync()
+        rays += sum(pipe.pass_stats(i).rays for i in range(3))
+    pipe.clear()
+    gc.collect()
+    gc.disable()
+    for k in range(settle):
+        frame(k)
+    be.sync()
+    pipe.mark_kernel_times()
+    t0 = time.perf_counter()
+    for k in range(settle, n):
+        frame(k)
+    be.sync()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    lm, ln = pipe.kernel_times(mark=True)
+    return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "rays_per_step": int(rays / steps), "settle_steps": settle,
+            "kernels_ms": {"k_primary_ao": round(lm[0] / ln[0], 4) if ln[0] else None},
+            "camera": f"orbit: eye on a circle of radius {radius:.1f} at height {eye0[1]:.1f} round the origin, {omega} rad/s at {fps:.0f} frames/s "
+                      f"({math.degrees(omega / fps):.3f} deg per frame), looking at the origin",
+            "scene": f"the castle's {len(base['desc'].instances)} instances + teapot.vox {'(reference asset)' if tea_real else 'stand-in'} at "
+                     "(sin t * 50, 200, 0), dust_hip_scene_set_transform + dust_hip_scene_commit every frame (castle.rs:287-291)",
+            "instances": len(base["desc"].instances) + 1}
+
+
+def extra_curves(args, be, noise0, noise5, base):
+    """One GPU, default workload: short runs after the headline's timed region, so that the driver's single command also carries the
+    moving view, the GI frame, the 4K frame and the deep tree (BASELINE configs[2], [3]'s size, [4]). Each is its own pipeline and
+    timed region; none of them touches `value`. A failure is reported in its place, never raised."""
+    out = {}
+
+    def run(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        gc.enable()
+        gc.collect()
+
+    def curve(workload, W, H, sc):
+        a = argparse.Namespace(**vars(args))
+        a.workload, a.width, a.height, a.steps, a.warmup = workload, W, H, args.extra_steps, 0
+        lane = Lane()
+        lane.stream, lane.ctx, lane.sc = base.stream, base.ctx, sc
+        lane.pipe = be.api.StandardPipeline(base.ctx, W, H)
+        lane.pipe.set_noise(5, noise5)
+        gi = workload != "primary_ao"
+        if gi:
+            lane.pipe.set_noise(0, noise0)
+        lane.enter = base.enter
+        rec = compact(measure_curve(be, None, a, [lane], "bands"), gi)
+        rec["steps"], rec["frame"] = a.steps, [W, H]
+        return rec
+
+    def deep():
+        a = argparse.Namespace(**vars(args))
+        a.workload = "deep"
+        sc = be.build_scene(a)
+        rec = curve("deep", args.width, args.height, sc)
+        rec["scene"] = f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy, {sc['n_bricks']} bricks (BASELINE configs[4] on one GPU)"
+        return rec
+    run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
+    run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
+    run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))
+    run("deep", deep)
+    return out
+
+
+def account(curve, gi_mode):
+    """Algorithmic bytes per launch of every kernel of a measured curve, the dominant kernel and its achieved GB/s."""
+    st, ms = curve["st"], curve["ms"]
+    ms_primary, ms_ao, ms_fg, ms_sf = ms
+    hit_px = st[0].hits
+    miss_px = st[0].rays - st[0].hits
+    bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
+    # AO kernel: per live pixel read depth 4 + normal 4 + illuminance 8, write illuminance 8 (hit.rchit/ao.rgen)
+    bytes_ao = algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0) - (st[1].hits + st[2].hits) * 5 + hit_px * 24
+    kernels_ms_extra = {}
+    bytes_fg = bytes_sf = 0
+    if gi_mode:
+        # final gather: depth 4 + normal 4 + illuminance 8 read, 8 written, one 12-byte hash entry + 16-byte surfel per hit
+        bytes_fg = algorithmic_bytes(st[3], st[3].rays * 24 + st[3].hits * 28) - st[3].hits * 5
+        # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
+        bytes_sf = (algorithmic_bytes(st[4], 0) + algorithmic_bytes(st[5], st[5].rays * (16 + 48 + 24)) - (st[4].hits + st[5].hits) * 5)
+        kernels_ms_extra = {"k_final_gather": round(ms_fg, 4), "k_surfel_trace+apply": round(ms_sf, 4)}
+    if gi_mode and max(ms_fg, ms_sf) > ms_primary:
+        dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
+    elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
+        dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)
+    else:
+        dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
+    achieved = dominant[1] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
+    return {"bytes_primary": bytes_primary, "bytes_ao": bytes_ao, "bytes_fg": bytes_fg, "bytes_sf": bytes_sf, "dominant": dominant,
+            "achieved": achieved, "kernels_ms_extra": kernels_ms_extra}
+
+
 def run_rank(args, be, dist):
     """Everything one rank does. Rank 0 returns the JSON line's dict, the others None."""
     rank, world = be.rank, be.world
@@ -437,28 +616,11 @@ def run_rank(args, be, dist):
     if rank != 0:
         return None
 
+    acct = account(main_curve, gi_mode)
     st, ms = main_curve["st"], main_curve["ms"]
     ms_primary, ms_ao, ms_fg, ms_sf = ms
-    hit_px = st[0].hits
-    miss_px = st[0].rays - st[0].hits
-    bytes_primary = algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24)
-    # AO kernel: per live pixel read depth 4 + normal 4 + illuminance 8, write illuminance 8 (hit.rchit/ao.rgen)
-    bytes_ao = algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0) - (st[1].hits + st[2].hits) * 5 + hit_px * 24
-    kernels_ms_extra = {}
-    bytes_fg = bytes_sf = 0
-    if gi_mode:
-        # final gather: depth 4 + normal 4 + illuminance 8 read, 8 written, one 12-byte hash entry + 16-byte surfel per hit
-        bytes_fg = algorithmic_bytes(st[3], st[3].rays * 24 + st[3].hits * 28) - st[3].hits * 5
-        # surfel pass: 16-byte surfel read, 32-byte request + 16-byte replacement written, one hash entry read+write per surfel
-        bytes_sf = (algorithmic_bytes(st[4], 0) + algorithmic_bytes(st[5], st[5].rays * (16 + 48 + 24)) - (st[4].hits + st[5].hits) * 5)
-        kernels_ms_extra = {"k_final_gather": round(ms_fg, 4), "k_surfel_trace+apply": round(ms_sf, 4)}
-    if gi_mode and max(ms_fg, ms_sf) > ms_primary:
-        dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
-    elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
-        dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)
-    else:
-        dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
-    achieved = dominant[1] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
+    bytes_primary, bytes_ao, dominant, achieved, kernels_ms_extra = (acct["bytes_primary"], acct["bytes_ao"], acct["dominant"], acct["achieved"],
+                                                                     acct["kernels_ms_extra"])
     # HBM-side traffic per launch: NOT measured by this process -- rocprofv3 counter passes need their own runs
     # (tools/profile_round.sh); the committed summary of the latest one is quoted with its provenance, or nothing is
     traffic, traffic_source = None, None
@@ -496,11 +658,20 @@ def run_rank(args, be, dist):
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(args, sc, noise5, be.synth)
+    extras = {}
+    if world == 1 and args.workload == "primary_ao" and hasattr(be, "assets"):
+        if args.camera == "orbit":
+            extras["moving"] = measure_moving(be, args, lanes[0], noise5, args.steps)
+        elif not args.no_extra_curves and (W, H) == (1920, 1080) and args.scale == 1.0:
+            extras = extra_curves(args, be, noise0, noise5, lanes[0])
+        if "moving" in extras and "value" in extras["moving"]:
+            extras["moving"]["vs_still"] = round(extras["moving"]["value"] / max(main_curve["mrays"], 1e-9), 4)
 
     what = {"primary_ao": "1spp primary+shadow+AO", "gi": "1 GI frame: primary+shadow+AO+final gather+surfel",
             "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
     scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
-                  ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}"))
+                  ("castle.vox (the reference's asset, sha256 verified)" if sc.get("real_castle") else
+                   ("castle.vox stand-in (synth.castle_scene seed 0xD057)" if args.scale == 1.0 else f"castle stand-in at scale {args.scale}")))
 
     def parallelism(c):
         root_txt = "k % N for step k (rotating root)" if c["assemble"] == "rotate" and world > 1 else "0"
@@ -536,6 +707,22 @@ def run_rank(args, be, dist):
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    out["curves"].update(extras)   # moving / primary_ao_4k / gi_1080p / deep: their own timed regions AFTER the headline's, never part of `value`
+    if hasattr(be, "assets"):
+        out["config"]["assets"] = be.assets.summary()
+    if args.camera == "orbit" and "moving" in extras:   # --camera orbit: the moving view IS the line; the still view stays in curves.strong
+        mv = extras["moving"]
+        out.update(value=mv["value"], ms_per_step=mv["ms_per_step"])
+        out["config"]["workload"] += "; MOVING view: " + mv["camera"] + "; " + mv["scene"]
+        out["config"]["rays_per_step_all_gpus"] = mv["rays_per_step"]
+        out["config"]["instances"] = mv["instances"]
+        if mv["kernels_ms"]["k_primary_ao"]:
+            k_ms = mv["kernels_ms"]["k_primary_ao"]
+            out["roofline"].update(kernel_ms=k_ms, kernels_ms=mv["kernels_ms"],
+                                   note="moving view: kernel time of the moving frames; algorithmic bytes per launch are the still frame's "
+                                        "(achieved / frac are recomputed with them -- the orbit keeps the castle in view, rays per frame within a few percent)")
+            out["roofline"]["achieved"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 3)
+            out["roofline"]["frac"] = round(out["roofline"]["achieved"] / HBM_PEAK_GBPS, 6)
     return out
 
 
@@ -672,6 +859,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     be = HipBackend(rank, local_rank, world)
+    if args.assets:
+        from dust_amd import assets as _assets
+        be.assets = _assets.Assets(args.assets)
     dist = be.init_dist() if world > 1 else None
     out = run_rank(args, be, dist)
     if out is not None:
