@@ -77,8 +77,8 @@ def parse(argv=None):
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--camera", choices=["still", "orbit"], default="still",
-                    help="orbit: the headline becomes the MOVING view (eye on a circle round the castle, the teapot of examples/castle.rs:287-291 "
-                         "swinging, set_transform + commit every frame); the default line carries it as curves.moving next to the still view")
+                    help="orbit: the headline becomes the MOVING view (the eye swaying along its circle round the castle, the teapot of "
+                         "examples/castle.rs:287-291 swinging, set_transform + commit every frame); the default line carries it as curves.moving")
     ap.add_argument("--no-extra-curves", action="store_true",
                     help="one GPU, default workload: skip curves.moving / gi_1080p / primary_ao_4k / deep (short runs after the headline's timed region)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra curve")
@@ -430,11 +430,14 @@ def compact(curve, gi_mode):
                          "algorithmic_bytes_per_launch": int(d[1]), "kernel_ms": round(d[2], 4)}}
 
 
-def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, omega=0.25):
+def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.15, period=4.0):
     """The reference is a real-time renderer: an FPS camera and a teapot that swings (examples/castle.rs:105-130,287-291). Here the
-    eye rides a circle round the castle at `omega` rad/s (60 frames a second of scene time), the teapot follows
+    eye sways along the circle round the castle that the reference's start position lies on -- angle `swing` * sin(2 pi t / `period`)
+    either side of it, 60 frames a second of scene time, never at rest --, the teapot follows
     Transform::from_translation((sin t * 50, 200, 0)) -- set_transform + commit every frame, motion vectors against the previous
-    frame's transform -- and every launch re-measures its tiles. One GPU; the castle's instances plus the teapot."""
+    frame's transform. One GPU; the castle's instances plus the teapot. (A full orbit shows a different castle every second: its
+    frames cost up to 20 % more or less than the headline's view for reasons that have nothing to do with moving; the sway keeps the
+    comparison with the still view a like-for-like one, and `still_same_views` times three of its cameras standing still.)"""
     import math
     import numpy as np
     api, L, synth, P = be.api, be.L, be.synth, be.P
@@ -466,12 +469,15 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, omega=0.2
     eye0 = (122.0 * sc, 300.61 * sc, 54.45 * sc)
     radius, th0 = math.hypot(eye0[0], eye0[2]), math.atan2(eye0[2], eye0[0])
     n = settle + steps
+
+    def cam_at(th):
+        eye = (radius * math.cos(th), eye0[1], radius * math.sin(th))
+        return api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), api.PinholeProjection())
+    angle = lambda k: th0 + swing * math.sin(2.0 * math.pi * (k / fps) / period)   # noqa: E731
     cams, xfs = [], []
     for k in range(n + 1):
-        t = k / fps
-        eye = (radius * math.cos(th0 + omega * t), eye0[1], radius * math.sin(th0 + omega * t))
-        cams.append(api.make_camera(eye, api.look_at_rotation(eye, (0.0, 0.0, 0.0)), api.PinholeProjection()))
-        xfs.append(tea_xf(t))
+        cams.append(cam_at(angle(k)))
+        xfs.append(tea_xf(k / fps))
     prevs = [cols(xfs[max(k - 1, 0)]) for k in range(n + 1)]
     flat = [np.ascontiguousarray(x.reshape(12)) for x in xfs]
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
@@ -500,11 +506,26 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, omega=0.2
     dt = time.perf_counter() - t0
     gc.enable()
     lm, ln = pipe.kernel_times(mark=True)
+    # the same views standing still: three cameras of the timed stretch (first, middle, last), the teapot where it was, 40 + 40 frames each
+    still_ms = []
+    for k in (settle, settle + steps // 2, n - 1):
+        scene.set_transform(tea, flat[k], prevs[k])
+        scene.commit()
+        for j in range(80):
+            if j == 40:
+                be.sync()
+                t1 = time.perf_counter()
+            pipe.render(scene, cams[k], sky, passes, frame_index=1 + j, rand=synth.frame_rand(1, 1 + j))
+        be.sync()
+        still_ms.append((time.perf_counter() - t1) / 40 * 1e3)
+    speed = swing * 2.0 * math.pi / period
     return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "rays_per_step": int(rays / steps), "settle_steps": settle,
             "kernels_ms": {"k_primary_ao": round(lm[0] / ln[0], 4) if ln[0] else None},
-            "camera": f"orbit: eye on a circle of radius {radius:.1f} at height {eye0[1]:.1f} round the origin, {omega} rad/s at {fps:.0f} frames/s "
-                      f"({math.degrees(omega / fps):.3f} deg per frame), looking at the origin",
+            "still_same_views": {"ms_per_step": [round(v, 4) for v in still_ms], "mean_ms_per_step": round(sum(still_ms) / len(still_ms), 4),
+                                 "moving_over_still": round((dt / steps * 1e3) / (sum(still_ms) / len(still_ms)), 4)},
+            "camera": f"sway: eye on the circle of radius {radius:.1f} at height {eye0[1]:.1f} round the origin, {swing} rad either side of the reference's "
+                      f"start position with a period of {period} s at {fps:.0f} frames/s (up to {math.degrees(speed / fps):.3f} deg per frame), looking at the origin",
             "scene": f"the castle's {len(base['desc'].instances)} instances + teapot.vox {'(reference asset)' if tea_real else 'stand-in'} at "
                      "(sin t * 50, 200, 0), dust_hip_scene_set_transform + dust_hip_scene_commit every frame (castle.rs:287-291)",
             "instances": len(base["desc"].instances) + 1}

@@ -42,7 +42,9 @@ hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
 hipError_t configure_kernels(size_t max_lds);
 constexpr uint32_t kTileOrderMaxBand = 65536;  // (kernels.hip)
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, uint32_t total, uint32_t per, hipStream_t s);
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, bool reuse_cuts, uint32_t total, uint32_t per, hipStream_t s);
+hipError_t launch_cost_blend(const uint32_t* raw, uint32_t* smooth, uint32_t total, uint32_t keep_shift, hipStream_t s);
+hipError_t launch_cost_dilate(const uint32_t* in, uint32_t* out, uint32_t tiles_x, uint32_t tiles_y, hipStream_t s);
 hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words, uint32_t* out, uint32_t out_words, uint32_t n, hipStream_t s);
 }  // namespace dust
 
@@ -185,6 +187,7 @@ struct DustHipContext : RefCounted {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_side_done = nullptr;
   bool side_busy = false;
+  hipStream_t copy = nullptr;  // scene commits upload on a stream of their own (the copy engine), beside the frame in flight -- never between two frames
 };
 // wait for everything enqueued on the context's stream (and remember that we did: scene commits recycle their pinned staging
 // slots by this, without an event per commit)
@@ -217,6 +220,7 @@ static void release(DustHipContext* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   c->srgb_lut.release();
@@ -284,26 +288,37 @@ struct DustHipScene : RefCounted {
   std::vector<uint32_t> model_generation;    // their edit generations when the scene was committed
   std::vector<uint32_t> instance_slot;       // per instance: its model's slot
   bool structure_dirty = true;               // instances were added (or a model edited): slots, roots and capacity are re-derived
-  // device image + pinned staging copies of it, used in turn (a slot is rewritten only after the copy that read it has run)
-  DeviceBuffer image;
+  // The device image is a RING of kImages copies, each with a pinned host twin. A commit writes the whole image into the next
+  // slot -- on the context's copy stream, waited for by the host, so nothing is enqueued between two frames on the launch stream
+  // (one stream-ordered copy per frame used to cost a moving scene ~25 us of a 230 us frame: wait for the frame, copy, start the
+  // next) -- and frames enqueued from then on read that slot. A slot is rewritten kImages commits later: the frames that read it
+  // are done if the library has waited for the streams since they were enqueued (a frame loop does, to read its result or pace
+  // itself); otherwise the host is kImages commits ahead of the GPU and waits here (the reference's host runs <= 3 frames ahead).
+  static constexpr int kImages = 8;
+  struct Slot {
+    DeviceBuffer dev;
+    void* host = nullptr;
+    mutable uint64_t epoch = 0;  // the context's sync_epoch when a frame reading the slot was last enqueued
+  } slots[kImages];
+  int current = -1;           // the slot frames read
+  uint32_t next_slot = 0;
   SceneLayout layout;
-  size_t image_capacity = 0;  // bytes
-  static constexpr int kStaging = 4;
-  struct Staging { void* host = nullptr; uint64_t epoch = 0; } staging[kStaging];  // epoch: the context's sync_epoch when the slot's copy was enqueued
-  size_t staging_bytes = 0;
-  uint32_t staging_next = 0;
+  size_t image_capacity = 0;  // bytes per slot
   std::vector<uint8_t> master;   // host master copy of the image (dirty instances are re-derived in place)
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
   uint32_t n_lds_models = 0;
   uint64_t revision = 0;  // bumped by every commit (what the cost-ordered hand-out keys its view on)
   bool committed = false;
-  const uint8_t* dev(size_t off) const { return static_cast<const uint8_t*>(image.p) + off; }
-  void free_staging() {
-    for (Staging& st : staging) {  // (the caller has waited for the stream)
-      if (st.host) { (void)hipHostFree(st.host); st.host = nullptr; }
-      st.epoch = 0;
+  const uint8_t* dev(size_t off) const { return static_cast<const uint8_t*>(slots[current].dev.p) + off; }
+  void touch() const { slots[current].epoch = ctx->sync_epoch; }  // a frame reading the current slot is being enqueued
+  void free_images() {  // (the caller has waited for the streams)
+    for (Slot& sl : slots) {
+      if (sl.host) { (void)hipHostFree(sl.host); sl.host = nullptr; }
+      sl.dev.release();
+      sl.epoch = 0;
     }
-    staging_bytes = 0;
+    current = -1;
+    image_capacity = 0;
   }
 };
 static void release(const DustHipScene* cs) {
@@ -311,9 +326,8 @@ static void release(const DustHipScene* cs) {
   if (!s || s->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   DustHipContext* c = s->ctx;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  s->free_staging();
-  s->image.release();
+  (void)sync_stream(c);  // both streams: the surfel pass reads the scene image on the second one
+  s->free_images();
   for (HostInstance& hi : s->instances) release(hi.model);
   delete s;
   release(c);
@@ -334,6 +348,12 @@ struct Tuning {
   bool no_side_stream = false;  // DUST_HIP_NO_SIDE_STREAM: the surfel pass on the main stream, in place
   uint32_t side_share = 0;      // DUST_HIP_SIDE_SHARE: percent of the workgroup slots the surfel pass takes on the second stream (0: by ray counts)
   uint32_t static_rounds = 0xFFFFFFFFu;  // DUST_HIP_STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
+  uint32_t still_refresh_max = 64;  // DUST_HIP_STILL_REFRESH_MAX: cap of the launches between two re-measurements of a view that stands still
+  uint32_t cost_keep_shift = 1; // DUST_HIP_COST_KEEP_SHIFT k: a tile's cost estimate moves 1 / 2^k of the way to each new measurement (0: takes it as it is)
+  bool dilate = true;           // DUST_HIP_NO_DILATE: a moving view's order from the tiles' own costs only
+  bool force_moving = false;    // DUST_HIP_FORCE_MOVING: treat every view as a moving one (diagnostic)
+  uint32_t cuts_reuse = 4;      // DUST_HIP_CUTS_REUSE: re-orderings of a moving view that keep one set of band cuts
+  uint32_t moving_refresh = 4;  // DUST_HIP_MOVING_REFRESH: launches between two re-orderings of a view that moves (order_tiles)
   uint32_t side_prio = 3;       // DUST_HIP_SIDE_PRIO: issue priority floor of the surfel pass on the second stream
   bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
                                 // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
@@ -359,6 +379,12 @@ struct Tuning {
     t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
     t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
     t.side_prio = std::min(3u, num("DUST_HIP_SIDE_PRIO", 3));
+    t.moving_refresh = std::max(1u, num("DUST_HIP_MOVING_REFRESH", 4));
+    t.cost_keep_shift = std::min(4u, num("DUST_HIP_COST_KEEP_SHIFT", 1));
+    t.dilate = std::getenv("DUST_HIP_NO_DILATE") == nullptr;
+    t.force_moving = std::getenv("DUST_HIP_FORCE_MOVING") != nullptr;
+    t.cuts_reuse = std::max(1u, num("DUST_HIP_CUTS_REUSE", 4));
+    t.still_refresh_max = std::max(1u, num("DUST_HIP_STILL_REFRESH_MAX", 64));
     if (t.side_share) t.side_share = std::min(90u, std::max(5u, t.side_share));
     return t;
   }
@@ -378,6 +404,8 @@ struct DustHipPipeline {
   // valid for the tile grid they were recorded on
   struct TileHistory {
     DeviceBuffer cost, order;
+    DeviceBuffer spread;     // a moving view: each tile's estimate or its dearest neighbour's (k_cost_dilate)
+    DeviceBuffer smooth;     // running mean of the measurements of each tile: what the order is made from (k_cost_blend)
     DeviceBuffer cuts;       // kRegions + 1 tile indices: the cost-balanced bands order[] was made for (FrameArgs::band_cuts)
     uint32_t tiles_x = 0, tiles_y = 0, capacity = 0, age = 0;
     uint32_t refresh = 8;    // launches between two measurements of a view that stands still (kOrderRefresh, doubling up to kOrderRefreshMax)
@@ -385,6 +413,8 @@ struct DustHipPipeline {
     bool recorded = false;   // cost[] holds the previous launch's measurements
     bool ordered = false;    // order[] is a valid permutation of this tile grid
     bool measured = false;   // cost[] holds a launch's measurements (maybe not the last launch's)
+    bool moving = false;     // the previous launch's view differed from the one before it
+    uint32_t cuts_age = 0;   // re-orderings since cuts[] was worked out
   } tile_history[4];
   uint64_t view_key = 0;     // this frame's camera + scene revision + sun + row band
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
@@ -1167,7 +1197,6 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
   if (!s) return fail(DUST_ERR_INVALID_ARGUMENT, "null scene");
   return guarded([&]() -> DustStatus {
     HIP_TRY(hipSetDevice(s->ctx->device));
-    const hipStream_t st = s->ctx->stream;
     const size_t n = s->instances.size();
     // a model edited since the last commit changes its record (bounds, sizes, maybe addresses): everything is derived again
     for (size_t i = 0; i < s->models.size() && !s->structure_dirty; ++i)
@@ -1185,16 +1214,29 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       // roots of the first models go to LDS, as many as the budget holds
       s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
       s->layout = SceneLayout::make(n, s->models.size(), s->n_lds_models);
-      if (s->layout.total > s->image_capacity || !s->image.p) {
-        // grow (rare: instances were added). Launches that read the old image are done before it goes.
+      if (s->layout.total > s->image_capacity || s->current < 0) {
+        // grow (rare: instances were added). Launches that read the old images are done before they go; the new ones are
+        // allocated into locals first, so a failed allocation leaves the scene as it was (and the next commit tries again).
         HIP_TRY(sync_stream(s->ctx));
-        s->free_staging();
-        s->image_capacity = s->layout.total + s->layout.total / 2 + 4096;
-        HIP_TRY(s->image.alloc(s->image_capacity));
-        for (DustHipScene::Staging& sg : s->staging) {
-          HIP_TRY(hipHostMalloc(&sg.host, s->image_capacity, hipHostMallocDefault));
+        const size_t cap = s->layout.total + s->layout.total / 2 + 4096;
+        DustHipScene::Slot fresh[DustHipScene::kImages];
+        hipError_t ge = hipSuccess;
+        for (DustHipScene::Slot& sl : fresh) {
+          if (ge == hipSuccess) ge = sl.dev.alloc(cap);
+          if (ge == hipSuccess) ge = hipHostMalloc(&sl.host, cap, hipHostMallocDefault);
         }
-        s->staging_bytes = s->image_capacity;
+        if (ge != hipSuccess) {
+          for (DustHipScene::Slot& sl : fresh) { if (sl.host) (void)hipHostFree(sl.host); sl.dev.release(); }
+          return hip_fail(ge, "scene image allocation");
+        }
+        s->free_images();
+        for (int i = 0; i < DustHipScene::kImages; ++i) {
+          s->slots[i].dev.p = fresh[i].dev.p; s->slots[i].dev.bytes = fresh[i].dev.bytes;
+          fresh[i].dev.p = nullptr; fresh[i].dev.bytes = 0;  // (ownership moved: the local's destructor frees nothing)
+          s->slots[i].host = fresh[i].host; s->slots[i].epoch = 0;
+        }
+        s->image_capacity = cap;
+        s->next_slot = 0;
       }
       s->master.assign(s->layout.total, 0);
       uint8_t* img = s->master.data();
@@ -1216,16 +1258,16 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
     for (size_t i = 0; i < n; ++i)
       for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], di[i].wmin[a]); s->world_max[a] = std::max(s->world_max[a], di[i].wmax[a]); }
-    HIP_TRY(join_side(s->ctx));  // (a surfel pass still tracing the old transforms on the second stream)
-    // one asynchronous copy of the image, from the next pinned slot, behind whatever frame is in flight on the stream
-    DustHipScene::Staging& sg = s->staging[s->staging_next++ % DustHipScene::kStaging];
-    // the copy that last read this slot was enqueued four commits ago: done if anything has waited for the stream since (a frame
-    // loop does, to read its result or pace itself) -- otherwise the host is four commits ahead of the GPU, and waits here
-    if (sg.epoch == s->ctx->sync_epoch) HIP_TRY(sync_stream(s->ctx));
-    const size_t from = full ? 0 : s->layout.instances;  // transforms only: the models and roots already there stand
-    std::memcpy(static_cast<uint8_t*>(sg.host) + from, img + from, s->layout.total - from);
-    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->image.p) + from, static_cast<uint8_t*>(sg.host) + from, s->layout.total - from, hipMemcpyHostToDevice, st));
-    sg.epoch = s->ctx->sync_epoch;
+    // upload: the whole image into the next slot of the ring, on the copy stream, and wait for it here (a ~100 KB copy: ~20 us of host
+    // time, none of the launch stream's); frames in flight keep reading the slot they were enqueued with
+    if (!s->ctx->copy) HIP_TRY(hipStreamCreateWithFlags(&s->ctx->copy, hipStreamNonBlocking));
+    const int slot = int(s->next_slot++ % DustHipScene::kImages);
+    DustHipScene::Slot& sl = s->slots[slot];
+    if (sl.epoch == s->ctx->sync_epoch) HIP_TRY(sync_stream(s->ctx));  // nobody has waited since a frame last read this slot: the host is a ring ahead
+    std::memcpy(sl.host, img, s->layout.total);
+    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, s->layout.total, hipMemcpyHostToDevice, s->ctx->copy));
+    HIP_TRY(hipStreamSynchronize(s->ctx->copy));
+    s->current = slot;
     ++s->revision;
     s->structure_dirty = false;
     s->committed = true;
@@ -1237,7 +1279,7 @@ static void destroy_pipeline(DustHipPipeline* p) {
   if (!p) return;
   DustHipContext* c = p->ctx;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)sync_stream(c);  // both streams: the surfel pass writes the GI buffers on the second one
   for (auto& kind : p->ev_ring)
     for (auto& side : kind)
       for (auto& e : side) if (e) (void)hipEventDestroy(e);
@@ -1317,17 +1359,24 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
   if (per_band > dust::kTileOrderMaxBand) return DUST_OK;  // beyond 8K: screen order
   if (total > h.capacity) {
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(h.cost.alloc(size_t(total) * 4)); HIP_TRY(h.order.alloc(size_t(total) * 4));
+    HIP_TRY(h.cost.alloc(size_t(total) * 4)); HIP_TRY(h.order.alloc(size_t(total) * 4)); HIP_TRY(h.smooth.alloc(size_t(total) * 4)); HIP_TRY(h.spread.alloc(size_t(total) * 4));
     if (!h.cuts.p) HIP_TRY(h.cuts.alloc(size_t(dust::kRegions + 1) * 4));
     h.capacity = total; h.tiles_x = h.tiles_y = 0;
   }
   if (h.tiles_x != a.tiles_x || h.tiles_y != a.tiles_y) {  // a new grid: tiles nobody has timed count as free
     h.recorded = false; h.ordered = false; h.measured = false; h.tiles_x = a.tiles_x; h.tiles_y = a.tiles_y;
     HIP_TRY(hipMemsetAsync(h.cost.p, 0, size_t(total) * 4, st));
+    HIP_TRY(hipMemsetAsync(h.smooth.p, 0, size_t(total) * 4, st));
   }
   if (h.recorded) {
-    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.order.p),
-                                    p->tune.equal_bands ? nullptr : static_cast<uint32_t*>(h.cuts.p), total, per_band, st));
+    // (the cost-balanced cuts drift slowly: a view that moves keeps them for kCutsReuse re-orderings -- the scan for them is the longer half of the sorter)
+    const bool reuse = h.ordered && h.cuts_age + 1 < p->tune.cuts_reuse && h.moving;
+    HIP_TRY(dust::launch_cost_blend(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.smooth.p), total, p->tune.cost_keep_shift, st));
+    const bool spread = h.moving && p->tune.dilate && a.tiles_y > 1u;
+    if (spread) HIP_TRY(dust::launch_cost_dilate(static_cast<const uint32_t*>(h.smooth.p), static_cast<uint32_t*>(h.spread.p), a.tiles_x, a.tiles_y, st));
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(spread ? h.spread.p : h.smooth.p), static_cast<uint32_t*>(h.order.p),
+                                    p->tune.equal_bands ? nullptr : static_cast<uint32_t*>(h.cuts.p), reuse, total, per_band, st));
+    h.cuts_age = reuse ? h.cuts_age + 1 : 0;
     h.recorded = false; h.ordered = true; h.age = 0;
   } else if (h.ordered) {
     ++h.age;
@@ -1336,13 +1385,19 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     a.tile_order = static_cast<const uint32_t*>(h.order.p);
     if (!p->tune.equal_bands) a.band_cuts = static_cast<const uint32_t*>(h.cuts.p);
   }
-  const bool still = h.ordered && h.view == p->view_key;
+  const bool still = h.ordered && h.view == p->view_key && !p->tune.force_moving;
   if (!still) h.refresh = kOrderRefresh;
-  if (!still || h.age + 1 >= h.refresh) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
+  // A view that moves: tile costs shift by a fraction of a tile per frame, so the order of a few frames ago is still a good one -- it is
+  // re-measured (and the next launch re-ordered) every kMovingRefresh launches, not every launch: the sorter is a launch of its own
+  // between two frames (~10 us of a 230 us frame). The first launch after a standstill (a cut, a teleport) is measured at once.
+  const bool jumped = !still && !h.moving;
+  const uint32_t period = still ? std::min(h.refresh, p->tune.still_refresh_max) : p->tune.moving_refresh;
+  if (!h.ordered || jumped || h.age + 1 >= period) {  // measure this launch (each traced tile overwrites its cost): the next one re-orders
     a.tile_cost = static_cast<uint32_t*>(h.cost.p);
     h.recorded = true; h.measured = true;
     if (still) h.refresh = std::min(kOrderRefreshMax, h.refresh * 2u);
   }
+  h.moving = !still;
   h.view = p->view_key;
   return DUST_OK;
 }
@@ -1433,6 +1488,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   DustHipContext* ctx = p->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
   dust::FrameArgs a{};
+  s->touch();
   a.models = reinterpret_cast<const dust::DevModel*>(s->dev(s->layout.models));
   a.instances = reinterpret_cast<const dust::DevInstance*>(s->dev(s->layout.instances));
   a.n_models = uint32_t(s->models.size());
@@ -1894,7 +1950,7 @@ DustStatus dust_hip_device_eval(DustHipContext* ctx, uint32_t fn, const uint32_t
     HIP_TRY(order.alloc(size_t(n) * 4));
     HIP_TRY(cuts.alloc(size_t(dust::kRegions + 1) * 4));
     HIP_TRY(hipMemsetAsync(order.p, 0xFF, size_t(n) * 4, ctx->stream));
-    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), fn == 14 ? static_cast<uint32_t*>(cuts.p) : nullptr,
+    HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(cost.p), static_cast<uint32_t*>(order.p), fn == 14 ? static_cast<uint32_t*>(cuts.p) : nullptr, false,
                                     n, (n + dust::kRegions - 1) / dust::kRegions, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (fn == 13) { HIP_TRY(copy_wait(out, order.p, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream)); return DUST_OK; }

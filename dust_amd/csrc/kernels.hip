@@ -2812,12 +2812,13 @@ hipError_t launch_device_eval(uint32_t fn, const uint32_t* in, uint32_t in_words
 // the band's tiles into 32 cost classes a quarter octave apart, most expensive class first. One workgroup per band, wave
 // ballots for the ranks (as radix.hip), ~5 us. The order only decides which wave traces which tile when -- never a result.
 constexpr uint32_t kTileOrderMaxBand = 65536;  // tiles per band the sorter stages in LDS (an 8K frame has 64 800)
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t* __restrict__ cuts,
-                                                       uint32_t total, uint32_t per) {
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t* cuts,
+                                                       uint32_t total, uint32_t per, uint32_t reuse_cuts) {
   __shared__ uint32_t cnt[16][32];
   __shared__ uint32_t wave_part[16];
   __shared__ unsigned long long wave_sum[16];
-  __shared__ uint32_t s_cuts[kRegions + 1];
+  __shared__ uint32_t s_cuts[kRegions + 1], cut_chunk[kRegions + 1];
+  __shared__ unsigned long long cut_need[kRegions + 1];
   __shared__ uint8_t octave[kTileOrderMaxBand];  // quarter octaves of each tile's cost: the only pass over global memory
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   // Bands of equal COST, not of equal tile count. With equal counts the bands of a frame differ by tens of percent in work (sky
@@ -2826,11 +2827,33 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
   // time idled behind them at 1080p (tools/wave_times.py). Every workgroup works the cuts out for itself (a scan over the cost
   // map: thread t sums a contiguous run, the runs are prefix-summed through shuffles and LDS, and the thread whose run holds
   // the k/8 point of the total walks it); a cut is a tile index in screen order, so a band is still contiguous (one XCD's L2).
-  if (cuts) {
-    const uint32_t run = (total + 1023u) / 1024u;
-    const uint32_t r0 = min(threadIdx.x * run, total), r1 = min(r0 + run, total);
+  if (cuts && !reuse_cuts) {
+    // chunk c = tiles [64 c, 64 c + 64): its cost, summed by one wave from one coalesced load (the chunk sums live where the
+    // sorter's quarter octaves will: 8 bytes x 8192 chunks = the 64 KB of `octave`)
+    unsigned long long* chunk_sum = reinterpret_cast<unsigned long long*>(octave);
+    const uint32_t nc = (total + 63u) / 64u;   // <= 8192: total <= kRegions * kTileOrderMaxBand (the host checks `per`)
+    for (uint32_t c = wave; c < nc; c += 16u * 8u) {  // eight chunks' loads in flight at a time: this loop is all memory latency
+      uint32_t raw[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t i = (c + 16u * j) * 64u + lane;
+        raw[j] = i < total ? max(cost[i], 1u) : 0u;  // (a tile nobody has timed yet counts as cheap)
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        unsigned long long v = raw[j];
+#pragma unroll
+        for (uint32_t d = 32; d > 0; d >>= 1) v += (unsigned long long)__shfl_xor((long long)v, (int)d);
+        if (lane == 0 && c + 16u * j < nc) chunk_sum[c + 16u * j] = v;
+      }
+    }
+    if (threadIdx.x <= kRegions) { s_cuts[threadIdx.x] = threadIdx.x == kRegions ? total : 0u; cut_chunk[threadIdx.x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // thread t owns chunks [t m, t m + m): exclusive prefix over the threads' sums through shuffles and 16 wave totals
+    const uint32_t m = (nc + 1023u) / 1024u;
+    const uint32_t c0 = min(threadIdx.x * m, nc), c1 = min(c0 + m, nc);
     unsigned long long mine = 0;
-    for (uint32_t i = r0; i < r1; ++i) mine += max(cost[i], 1u);  // (a tile nobody has timed yet counts as cheap)
+    for (uint32_t c = c0; c < c1; ++c) mine += chunk_sum[c];
     unsigned long long inc = mine;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -2838,19 +2861,31 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
       if (lane >= d) inc += up;
     }
     if (lane == 63) wave_sum[wave] = inc;
-    if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = threadIdx.x == kRegions ? total : 0u;
     __syncthreads();
     unsigned long long before = 0, all = 0;
     for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += wave_sum[w]; all += wave_sum[w]; }
     const unsigned long long excl = before + inc - mine;
-    for (uint32_t k = 1; k < kRegions; ++k) {
+    for (uint32_t k = 1; k < kRegions; ++k) {  // the thread whose chunks hold the k/8 point of the total finds the chunk ...
       const unsigned long long target = all / kRegions * k;
       if (mine != 0 && excl < target && target <= excl + mine) {
-        unsigned long long c = excl;
-        uint32_t i = r0;
-        for (; i < r1; ++i) { c += max(cost[i], 1u); if (c >= target) break; }
-        s_cuts[k] = min(i + 1u, total);
+        unsigned long long acc = excl;
+        uint32_t c = c0;
+        for (; c + 1u < c1 && acc + chunk_sum[c] < target; ++c) acc += chunk_sum[c];
+        cut_chunk[k] = c; cut_need[k] = target - acc;  // (> 0, and <= the chunk's sum unless it is the thread's last chunk)
       }
+    }
+    __syncthreads();
+    if (wave >= 1u && wave < kRegions && cut_chunk[wave] != 0xFFFFFFFFu) {  // ... and wave k the tile inside it: one load, one scan, one ballot
+      const uint32_t i = cut_chunk[wave] * 64u + lane;
+      unsigned long long v = i < total ? (unsigned long long)max(cost[i], 1u) : 0ull;
+#pragma unroll
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = (unsigned long long)__shfl_up((long long)v, (int)d);
+        if (lane >= d) v += up;
+      }
+      const unsigned long long reached = __ballot(v >= cut_need[wave]);
+      const uint32_t first = reached ? (uint32_t)__builtin_ctzll(reached) : 63u;
+      if (lane == 0) s_cuts[wave] = min(cut_chunk[wave] * 64u + first + 1u, total);
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // (a band the sorter cannot stage -- frames beyond 8K with most of their cost in one corner: the equal split)
@@ -2860,6 +2895,10 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x <= kRegions) cuts[threadIdx.x] = s_cuts[threadIdx.x];
+    __syncthreads();  // (the chunk sums are dead: `octave` is the sorter's from here)
+  } else if (cuts) {  // the cuts of an earlier launch on the same grid: a view that moves keeps them for a few frames
+    if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = min(cuts[threadIdx.x], total);
+    __syncthreads();
   } else {
     if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = min(threadIdx.x * per, total);
     __syncthreads();
@@ -2929,10 +2968,42 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     }
   }
 }
+// Tile costs are noisy: the same tile of the same view, timed in two launches, differs by tens of percent (it depends on which waves
+// shared its SIMD), and the 300 most expensive tiles of one launch cost 0.76 of that in the next. The order is therefore made from
+// a running mean of the measurements -- half the new one, half what was known -- which a tile nobody has timed yet starts at once.
+__global__ void __launch_bounds__(256) k_cost_blend(const uint32_t* __restrict__ raw, uint32_t* __restrict__ smooth, uint32_t total, uint32_t keep_shift) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t r = raw[i], o = smooth[i];
+    // keep_shift k: new = old + (raw - old) / 2^k (k = 1: the mean of the two); old == 0: nothing known, take the measurement
+    smooth[i] = (o == 0u || r == 0u || keep_shift == 0u) ? (r ? r : o) : (uint32_t)((long long)o + (((long long)r - (long long)o) >> keep_shift));
+  }
+}
+// A view that moves: what made a tile expensive is, a few frames on, partly in the tile next to it. The order of such a view is made
+// from each tile's cost or its most expensive neighbour's, whichever is more (3 x 3 tiles): a tile beside an expensive one starts early too.
+__global__ void __launch_bounds__(256) k_cost_dilate(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t tiles_x, uint32_t tiles_y) {
+  const uint32_t total = tiles_x * tiles_y;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t y = i / tiles_x, x = i - y * tiles_x;
+    uint32_t m = 0;
+    for (uint32_t yy = y ? y - 1u : 0u; yy <= min(y + 1u, tiles_y - 1u); ++yy)
+      for (uint32_t xx = x ? x - 1u : 0u; xx <= min(x + 1u, tiles_x - 1u); ++xx) m = max(m, in[yy * tiles_x + xx]);
+    out[i] = m;
+  }
+}
+hipError_t launch_cost_blend(const uint32_t* raw, uint32_t* smooth, uint32_t total, uint32_t keep_shift, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost_blend, dim3((total + 255u) / 256u < 64u ? (total + 255u) / 256u : 64u), dim3(256), 0, s, raw, smooth, total, keep_shift);
+  return hipGetLastError();
+}
+hipError_t launch_cost_dilate(const uint32_t* in, uint32_t* out, uint32_t tiles_x, uint32_t tiles_y, hipStream_t s) {
+  const uint32_t total = tiles_x * tiles_y;
+  hipLaunchKernelGGL(k_cost_dilate, dim3((total + 255u) / 256u < 64u ? (total + 255u) / 256u : 64u), dim3(256), 0, s, in, out, tiles_x, tiles_y);
+  return hipGetLastError();
+}
 // cuts: kRegions + 1 tile indices the kernel fills in (the cost-balanced bands the order is made for), or null = equal bands of `per`
-hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, uint32_t total, uint32_t per, hipStream_t s) {
+// reuse_cuts: keep the cuts an earlier launch on this grid left there (the order is then made for those bands)
+hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cuts, bool reuse_cuts, uint32_t total, uint32_t per, hipStream_t s) {
   if (per > kTileOrderMaxBand) return hipErrorInvalidValue;  // (the caller keeps screen order for frames beyond 8K)
-  hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, cuts, total, per);
+  hipLaunchKernelGGL(k_tile_order, dim3(kRegions), dim3(1024), 0, s, cost, order, cuts, total, per, reuse_cuts ? 1u : 0u);
   return hipGetLastError();
 }
 
