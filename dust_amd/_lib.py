@@ -174,6 +174,16 @@ SYMBOLS = {
     "dust_hip_pipeline_set_denoiser": (C.c_int, [_P, C.POINTER(DenoiseParams)]),
     "dust_hip_pipeline_restart_denoiser": (C.c_int, [_P]),
     "dust_hip_device_eval": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),
+    # multi-GPU: RCCL communicator (or a loopback group on one device), band gather, GI exchange
+    "dust_hip_comm_unique_id": (C.c_int, [_P]),
+    "dust_hip_comm_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.POINTER(_P)]),
+    "dust_hip_comm_create_local": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    "dust_hip_comm_destroy": (None, [_P]),
+    "dust_hip_comm_info": (C.c_int, [_P, _u32p, _u32p, _u32p]),
+    "dust_hip_gather_bands": (C.c_int, [_P, _P, C.c_int, _u32p, C.c_uint32, _P, C.c_size_t]),
+    "dust_hip_comm_wait": (C.c_int, [_P]),
+    "dust_hip_comm_sync": (C.c_int, [_P]),
+    "dust_hip_gi_exchange_run": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

@@ -509,6 +509,56 @@ def _write_gi(self, hash_entries, pool):
 StandardPipeline.write_gi = _write_gi
 
 
+class Comm:
+    """One rank's end of the multi-GPU partition: an RCCL communicator on the context's device (create), or the ranks of a loopback
+    group on one device (local). Band gather and GI exchange run inside the library (comm.hip)."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._lib, self._h = ctx, ctx._lib, handle
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        L.check(L.load().dust_hip_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, ctx, rank, world, unique_id: bytes):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        L.check(ctx._lib.dust_hip_comm_create(ctx._h, rank, world, C.cast(buf, C.c_void_p), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def local(cls, ctx, world):
+        hs = (C.c_void_p * world)()
+        L.check(ctx._lib.dust_hip_comm_create_local(ctx._h, world, hs))
+        return [cls(ctx, C.c_void_p(h)) for h in hs]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.dust_hip_comm_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        r, w, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        L.check(self._lib.dust_hip_comm_info(self._h, C.byref(r), C.byref(w), C.byref(l)))
+        return r.value, w.value, bool(l.value)
+
+    def gather_bands(self, pipe, plane, cuts, root=0, dst_ptr=None, dst_bytes=0):
+        c = (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        L.check(self._lib.dust_hip_gather_bands(pipe._h, self._h, plane, c, root, C.c_void_p(dst_ptr) if dst_ptr else None, dst_bytes))
+
+    def gi_exchange(self, pipe, row_begin, row_end, band_rows, frame_index):
+        L.check(self._lib.dust_hip_gi_exchange_run(pipe._h, self._h, row_begin, row_end, band_rows, frame_index))
+
+    def wait(self):
+        L.check(self._lib.dust_hip_comm_wait(self._h))
+
+    def sync(self):
+        L.check(self._lib.dust_hip_comm_sync(self._h))
+
+
 def load_png_array(data: bytes):
     """PNG / APNG -> array (layers, height, width, channels), uint8 (big-endian uint16 for 16-bit files): the reference's
     PngLoader (rhyolite_bevy/src/loaders/png.rs:70-200). RGB comes back as RGBA with a zero fourth channel."""

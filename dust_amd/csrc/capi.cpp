@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "capi_internal.hpp"
 #include "dust_dev.h"
 #include "vdb.hpp"
 #include "png.hpp"
@@ -2012,3 +2013,14 @@ DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
 }
 
 }  // extern "C"
+
+// ---- what comm.hip needs of the handles (capi_internal.hpp)
+namespace dust_internal {
+DustStatus set_error(DustStatus status, const std::string& message) { return fail(status, message); }
+hipStream_t context_stream(DustHipContext* c) { return c->stream; }
+int context_device(DustHipContext* c) { return c->device; }
+void context_retain(DustHipContext* c) { retain(c); }
+void context_release(DustHipContext* c) { release(c); }
+DustHipContext* pipeline_context(DustHipPipeline* p) { return p->ctx; }
+void pipeline_size(DustHipPipeline* p, uint32_t* width, uint32_t* height) { *width = p->width; *height = p->height; }
+}  // namespace dust_internal

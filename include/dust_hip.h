@@ -405,6 +405,40 @@ DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
  * of one frame on 8 GPUs, four in flight: 0.045 -> 0.037 ms per band). 1 (the default): a launch may take the whole device. 1..16. */
 DustStatus dust_hip_pipeline_set_frames_in_flight(DustHipPipeline*, uint32_t n);
 
+/* ===================================================================== multi-GPU: one process per GPU, RCCL over xGMI
+ * The reference renders on one device; its plugin entry is where devices would be selected (crates/render/src/lib.rs:58-134).
+ * north_star's partition: the pixels of a frame shard across the GPUs of a node as row bands (DustHipFrameParams.row_begin /
+ * row_end; the scene is replicated), and the finished bands are gathered onto one GPU. A DustHipComm is this process's end of that:
+ * an RCCL communicator bound to a context. librccl is opened on first use -- a single-GPU host never loads it. */
+typedef struct DustHipComm DustHipComm;
+#define DUST_HIP_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 makes the id and the host carries it to the other processes (any out-of-band way: a file, a socket, MPI) */
+DustStatus dust_hip_comm_unique_id(uint8_t id[DUST_HIP_COMM_ID_BYTES]);
+/* ncclCommInitRank on the context's device. Collective: every rank of the job calls it with the same id and world. */
+DustStatus dust_hip_comm_create(DustHipContext*, uint32_t rank, uint32_t world, const uint8_t id[DUST_HIP_COMM_ID_BYTES], DustHipComm** out);
+/* A LOOPBACK group: `world` ranks on ONE context (one device, one stream), out[0..world). The same entry points take these handles;
+ * a collective is carried out -- with device copies and small reduction kernels, on the context's stream -- by the call that
+ * completes it, i.e. when the group's last rank has made it, so every rank must make a call before any rank makes the next.
+ * What a one-GPU box, the C++ host mirror and the tests drive the multi-GPU protocol with (each rank with a pipeline of its own). */
+DustStatus dust_hip_comm_create_local(DustHipContext*, uint32_t world, DustHipComm** out);
+void dust_hip_comm_destroy(DustHipComm*);
+DustStatus dust_hip_comm_info(const DustHipComm*, uint32_t* rank, uint32_t* world, uint32_t* is_local);
+/* Framebuffer gather. cuts: world + 1 row indices, 0 ... height, the same on every rank: rank r rendered rows [cuts[r], cuts[r+1]) of
+ * `plane` (into the plane's current storage: the pipeline's own, or what dust_hip_pipeline_bind_plane gave it). Those rows travel to
+ * rank `root` -- grouped ncclSend / ncclRecv, each peer over its own xGMI link -- into `dst` there (device memory of at least the
+ * plane's size; NULL = the root pipeline's own plane, whose remaining rows are then filled in). Asynchronous: ordered behind
+ * everything enqueued on the context's stream so far, carried out on the communicator's OWN stream, so that the next band frame
+ * (rendering into another bound target) overlaps the transfer. Before a source target or `dst` is used again: dust_hip_comm_wait. */
+DustStatus dust_hip_gather_bands(DustHipPipeline*, DustHipComm*, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes);
+/* the context's stream waits (on the device) for the gathers enqueued so far / the host waits for them and for the context */
+DustStatus dust_hip_comm_wait(DustHipComm*);
+DustStatus dust_hip_comm_sync(DustHipComm*);
+/* Steps 2-5 of the multi-GPU GI protocol above (dust_hip_pipeline_gi_exchange), enqueued on the context's stream: all-reduce MAX of
+ * slot_owner, all-gather of the `touched` bands (band r at row r * band_rows; every band is band_rows rows, the last may be
+ * shorter in the frame), dust_hip_gi_export(row_begin, row_end), all-reduce SUM of `merged`, dust_hip_gi_import(..., frame_index).
+ * A rank whose band lies past the end of the frame passes (height, height). */
+DustStatus dust_hip_gi_exchange_run(DustHipPipeline*, DustHipComm*, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index);
+
 /* Device function evaluation: runs ONE of the device functions the traversal / shading kernels are built from on n
  * independent inputs (host arrays in, host arrays out, synchronous). The reference has no counterpart -- its shaders are
  * only reachable through vkCmdTraceRaysKHR -- this is how vectors of (ray, brick mask) -> (t, voxel) pairs and codec

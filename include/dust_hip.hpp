@@ -346,4 +346,41 @@ class StandardPipeline {
   uint32_t width_, height_;
 };
 
+
+// One rank's end of the multi-GPU partition: an RCCL communicator on the context's device -- or, on one device, the
+// ranks of a loopback group. The reference's plugin selects ONE device (crates/render/src/lib.rs:58-134); a host that runs one
+// process per GPU makes one of these next to its RenderContext.
+class DeviceComm {
+ public:
+  static std::vector<uint8_t> unique_id() {  // on rank 0; carried to the other processes by the host
+    std::vector<uint8_t> id(DUST_HIP_COMM_ID_BYTES);
+    check(dust_hip_comm_unique_id(id.data()));
+    return id;
+  }
+  DeviceComm(RenderContext& ctx, uint32_t rank, uint32_t world, const std::vector<uint8_t>& id) { check(dust_hip_comm_create(ctx.raw(), rank, world, id.data(), &h_)); }
+  explicit DeviceComm(DustHipComm* adopted) : h_(adopted) {}
+  // `world` ranks on one device: collectives complete when the group's last rank has made the call
+  static std::vector<std::unique_ptr<DeviceComm>> loopback(RenderContext& ctx, uint32_t world) {
+    std::vector<DustHipComm*> raw(world, nullptr);
+    check(dust_hip_comm_create_local(ctx.raw(), world, raw.data()));
+    std::vector<std::unique_ptr<DeviceComm>> out;
+    for (DustHipComm* c : raw) out.emplace_back(new DeviceComm(c));
+    return out;
+  }
+  ~DeviceComm() { dust_hip_comm_destroy(h_); }
+  DeviceComm(const DeviceComm&) = delete;
+  // rows [cuts[r], cuts[r+1]) of `plane` from every rank r to `root` (its own plane when dst is null)
+  void gather_bands(StandardPipeline& p, DustHipPlane plane, const std::vector<uint32_t>& cuts, uint32_t root, void* dst = nullptr, size_t dst_bytes = 0) {
+    check(dust_hip_gather_bands(p.raw(), h_, plane, cuts.data(), root, dst, dst_bytes));
+  }
+  void gi_exchange(StandardPipeline& p, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index) {
+    check(dust_hip_gi_exchange_run(p.raw(), h_, row_begin, row_end, band_rows, frame_index));
+  }
+  void wait() { check(dust_hip_comm_wait(h_)); }
+  void sync() { check(dust_hip_comm_sync(h_)); }
+  DustHipComm* raw() const { return h_; }
+ private:
+  DustHipComm* h_ = nullptr;
+};
+
 }  // namespace dust

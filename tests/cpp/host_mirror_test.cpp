@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <algorithm>
 
 #include "dust_hip.hpp"
 
@@ -105,8 +107,31 @@ static int gpu_frame(int argc, char** argv) {
   const double eye[3] = {122.0 * 0.15, 300.61 * 0.15, 54.45 * 0.15}, target[3] = {0, 0, 0}, up[3] = {0, 1, 0};
   const float eyef[3] = {float(eye[0]), float(eye[1]), float(eye[2])};
   const DustHipCamera cam = dust::make_camera(eyef, dust::look_at_rotation(eye, target, up), dust::PinholeProjection{});
-  const bool ok = pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242);
-  EXPECT(ok);
+  if (std::string(argv[1]) == "bands") {
+    // the multi-GPU partition through the C ABI, 8 emulated ranks on this one device: every rank renders its row band into a pipeline
+    // of its own, dust_hip_gather_bands (a loopback group: device copies) assembles the planes in rank 0's pipeline -- `pipeline`
+    const uint32_t world = 8;
+    auto comms = dust::DeviceComm::loopback(ctx, world);
+    std::vector<uint32_t> cuts(world + 1);
+    const uint32_t per = ((h + world - 1) / world + 7) / 8 * 8;
+    for (uint32_t r = 0; r <= world; ++r) cuts[r] = std::min(h, r * per);
+    std::vector<std::unique_ptr<dust::StandardPipeline>> ranks;
+    for (uint32_t r = 1; r < world; ++r) {
+      ranks.emplace_back(new dust::StandardPipeline(ctx, w, h));
+      ranks.back()->set_blue_noise(5, noise5.data(), uint32_t(noise5.size() / (128 * 128 * 4)));
+    }
+    auto pipe_of = [&](uint32_t r) -> dust::StandardPipeline& { return r == 0 ? pipeline : *ranks[r - 1]; };
+    for (uint32_t r = 0; r < world; ++r)
+      if (cuts[r] < cuts[r + 1]) EXPECT(pipe_of(r).render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242, cuts[r], cuts[r + 1]));
+    for (DustHipPlane plane : {DUST_PLANE_DEPTH, DUST_PLANE_ILLUMINANCE, DUST_PLANE_VOXEL_ID}) {
+      for (uint32_t r = 0; r < world; ++r) comms[r]->gather_bands(pipe_of(r), plane, cuts, 0);
+      comms[0]->wait();
+    }
+    comms[0]->sync();
+  } else {
+    const bool ok = pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242);
+    EXPECT(ok);
+  }
   ctx.sync();
   const auto depth = pipeline.read_plane<float>(DUST_PLANE_DEPTH);
   const auto ill = pipeline.read_plane<uint16_t>(DUST_PLANE_ILLUMINANCE);
@@ -172,7 +197,7 @@ static int commit_loop(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   try {
-    if (argc >= 2 && std::string(argv[1]) == "gpu") return gpu_frame(argc, argv);
+    if (argc >= 2 && (std::string(argv[1]) == "gpu" || std::string(argv[1]) == "bands")) return gpu_frame(argc, argv);
     if (argc >= 2 && std::string(argv[1]) == "commit") return commit_loop(argc, argv);
     return cpu_tests();
   } catch (const dust::Error& e) {

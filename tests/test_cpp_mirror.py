@@ -27,7 +27,10 @@ def test_cpp_mirror_cpu(exe):
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path):
+@pytest.mark.parametrize("mode", ["gpu", "bands"])
+def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path, mode):
+    """mode "bands": the frame as 8 emulated ranks render and gather it through dust::DeviceComm (a loopback group on this device,
+    include/dust_hip.hpp) -- bit-identical to the single-device frame."""
     import parity_util as P
     from dust_amd import _lib as L, api, synth
     data, _ = synth.castle_scene(scale=0.15)
@@ -37,7 +40,7 @@ def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path):
     sky = P.sky_state()
     (tmp_path / "sky.bin").write_bytes(sky.astype(np.float32).tobytes())
     w, h = 160, 90
-    out = subprocess.run([exe, "gpu", str(tmp_path / "castle.vox"), str(w), str(h), str(tmp_path / "noise5.bin"),
+    out = subprocess.run([exe, mode, str(tmp_path / "castle.vox"), str(w), str(h), str(tmp_path / "noise5.bin"),
                           str(tmp_path / "sky.bin"), str(tmp_path / "out")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     ctx = api.Context(device=0)
