@@ -75,6 +75,10 @@ def parse(argv=None):
                     help="row bands of a non-GI workload: cost = bands of about equal measured cost (one untimed whole-frame launch records every "
                          "tile's cycles, rank 0's map decides); rows = equal row counts")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="N > 1, row bands: native = the library's own RCCL path (dust_hip_comm_create / dust_hip_gather_bands / "
+                         "dust_hip_gi_exchange_run: grouped send / receive on the communicator's stream, enqueued by the call that follows the "
+                         "band's render call); torch = the same collectives through torch.distributed (round 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--camera", choices=["still", "orbit"], default="still",
                     help="orbit: the headline becomes the MOVING view (the eye swaying along its circle round the castle, the teapot of "
@@ -204,6 +208,15 @@ class HipBackend:
                    cam=api.make_camera(eye, api.look_at_rotation(eye, target), api.PinholeProjection()))
         return out
 
+    def make_comm(self, dist, ctx):
+        """The library's RCCL communicator for one context (lane): rank 0 makes the id, torch.distributed carries it."""
+        torch = self.torch
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(self.api.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        return self.api.Comm.create(ctx, self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
+
     def noise(self):
         return self.assets.noise()   # the reference's STBN textures if --assets holds them (sha256), else the stand-ins
 
@@ -227,7 +240,37 @@ class HipBackend:
 
 class Lane:
     """a frame in flight: stream, context, scene copy and pipeline (see HipBackend.open_lane)"""
-    pass
+    comm = None
+
+
+class NativeGather:
+    """AsyncGather's interface over the library's own collectives (dust_hip_gather_bands): slot b is render target b of lane b % D;
+    the gather of step k moves every rank's rows of that target to the root's copy of it, in place, on the communicator's stream."""
+
+    def __init__(self, comms, pipes, plane, cuts, slots, rotate, world):
+        self.comms, self.pipes, self.plane, self.slots, self.rotate, self.world = comms, pipes, plane, slots, rotate, world
+        self.cuts = (ctypes.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        self.tickets = [0] * slots
+        self.root = 0
+
+    def wait_slot(self, b):
+        b %= self.slots
+        if self.tickets[b]:
+            self.comms[b % len(self.comms)].wait(self.tickets[b])   # (on the device: the lane's stream waits for the gather that last read target b)
+            self.tickets[b] = 0
+
+    def submit_slot(self, b, k):
+        self.root = k % self.world if self.rotate else 0
+        lane = b % len(self.comms)
+        self.tickets[b] = self.comms[lane].gather_bands(self.pipes[lane], self.plane, self.cuts, self.root)
+
+    def finish(self):
+        for c in self.comms:
+            c.sync()
+        self.tickets = [0] * self.slots
+
+    def last_root(self):
+        return self.root
 
 
 def measure_curve(be, dist, args, lanes, shard):
@@ -292,7 +335,24 @@ def measure_curve(be, dist, args, lanes, shard):
     if slices:
         send = (0, tgt_rows)
     # step k's exchange overlaps step k+1's rendering
-    gather = sharding.AsyncGather(dist, targets[0][send[0]:send[0] + (per_rows if bands else send[1] - send[0])], depth=S, rotate=assemble == "rotate", slices=slices)
+    native = bands and world > 1 and getattr(args, "comm", "torch") == "native" and hasattr(be, "make_comm")
+    if native:
+        try:
+            for lane in lanes:
+                if getattr(lane, "comm", None) is None:
+                    lane.comm = be.make_comm(dist, lane.ctx)
+        except Exception as e:  # noqa: BLE001 -- e.g. no librccl: the torch path still works
+            sys.stderr.write(f"bench.py: native communicator unavailable ({e}); using torch.distributed\n")
+            native = False
+        agreed = torch.tensor([1 if native else 0], dtype=torch.int64, device=be.device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)   # (every rank takes the same path)
+        native = bool(agreed.item())
+    if native:
+        row_cuts = band_cuts if band_cuts else [min(H, r * per_rows) for r in range(world)] + [H]
+        gather = NativeGather([lane.comm for lane in lanes], [lane.pipe for lane in lanes], L.PLANE_ILLUMINANCE, row_cuts, S, rotate=assemble == "rotate",
+                              world=world)
+    else:
+        gather = sharding.AsyncGather(dist, targets[0][send[0]:send[0] + (per_rows if bands else send[1] - send[0])], depth=S, rotate=assemble == "rotate", slices=slices)
     pix_stats = []
     if fixed_targets:
         for s_, lane in enumerate(lanes):
@@ -320,10 +380,13 @@ def measure_curve(be, dist, args, lanes, shard):
             if count:  # the second call restarts the counters: keep the pixel passes' now
                 be.sync()
                 pix_stats[:] = [pipe.pass_stats(i) for i in range(4)] if have_rows else []
-            sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
-                                      (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: pipe.gi_export(H, H)),  # (no rows: zeroes into the merge)
-                                      (lambda: pipe.gi_import(rows[0], rows[1], frame_index)) if have_rows else
-                                      (lambda: pipe.gi_import(H, H, frame_index)))  # empty own range: every stamp is another band's
+            if native:   # the same five steps inside the library, on the context's stream
+                lanes[0].comm.gi_exchange(pipe, rows[0] if have_rows else H, rows[1] if have_rows else H, per_rows, frame_index)
+            else:
+                sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
+                                          (lambda: pipe.gi_export(*rows)) if have_rows else (lambda: pipe.gi_export(H, H)),  # (no rows: zeroes into the merge)
+                                          (lambda: pipe.gi_import(rows[0], rows[1], frame_index)) if have_rows else
+                                          (lambda: pipe.gi_import(H, H, frame_index)))  # empty own range: every stamp is another band's
             # the replicated surfel pass must leave the SAME hash on every GPU: deterministic apply, not the racy one
             sp = L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED | cs | (L.PASS_ACCUMULATE if have_rows else 0)
             pipe.render(scene, cam, sky, sp, frame_index=frame_index, rand=rnd, rows=rows if have_rows else (0, 0))
@@ -334,7 +397,9 @@ def measure_curve(be, dist, args, lanes, shard):
         else:
             frame_index = sharding.sample_frame_index(k, rank, world)  # sample k*N + r of the spp sequence
             pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
-        if world > 1:
+        if world > 1 and native:
+            gather.submit_slot(k % S, k)   # grouped send / receive of the bands' rows, in place in the root's target, on the communicator's stream
+        elif world > 1:
             gather.submit_view(targets[k % S][send[0]:send[1]])  # asynchronous gather, straight from the target
 
     def barrier():
@@ -357,6 +422,9 @@ def measure_curve(be, dist, args, lanes, shard):
         rays_rank -= st[4].rays + st[5].rays  # the replicated surfel pass counts once
     if have_rows:
         be.check_target(pipe, targets[0], rows)
+    if native and rank == 0:   # step 0 gathered onto rank 0, in place: every band's rows arrived in its target
+        for r in range(world):
+            assert row_cuts[r] == row_cuts[r + 1] or bool((targets[0][row_cuts[r]:row_cuts[r + 1]] != 0).any()), f"band {r} did not arrive"
 
     gc.collect()
     gc.disable()  # no collector pause between two launches of the timed loop -- nor between the settle frames and the timed region
@@ -413,7 +481,8 @@ def measure_curve(be, dist, args, lanes, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts}
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts,
+            "comm": "native" if native else "torch"}
 
 
 def compact(curve, gi_mode):
@@ -723,6 +792,8 @@ def run_rank(args, be, dist):
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
                                   "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"],
+                                  **({"collectives": "libdust_hip.so's own RCCL path (dust_hip_gather_bands / dust_hip_gi_exchange_run)" if c.get("comm") == "native"
+                                      else "torch.distributed (RCCL)"} if world > 1 else {}),
                                   "settle_steps": c["settle"], **({"band_rows": c["band_cuts"]} if c.get("band_cuts") else {}),
                                   "per_rank_kernel_ms": [[round(x, 4) for x in v] for v in c["per_rank"]]} for c in curves.values()},
         "roofline": roofline,

@@ -546,14 +546,17 @@ class Comm:
         return r.value, w.value, bool(l.value)
 
     def gather_bands(self, pipe, plane, cuts, root=0, dst_ptr=None, dst_bytes=0):
-        c = (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
-        L.check(self._lib.dust_hip_gather_bands(pipe._h, self._h, plane, c, root, C.c_void_p(dst_ptr) if dst_ptr else None, dst_bytes))
+        """-> the gather's ticket (wait(ticket) before its source target or destination is used again)"""
+        c = cuts if isinstance(cuts, C.Array) else (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        t = C.c_uint64()
+        L.check(self._lib.dust_hip_gather_bands(pipe._h, self._h, plane, c, root, C.c_void_p(dst_ptr) if dst_ptr else None, dst_bytes, C.byref(t)))
+        return t.value
 
     def gi_exchange(self, pipe, row_begin, row_end, band_rows, frame_index):
         L.check(self._lib.dust_hip_gi_exchange_run(pipe._h, self._h, row_begin, row_end, band_rows, frame_index))
 
-    def wait(self):
-        L.check(self._lib.dust_hip_comm_wait(self._h))
+    def wait(self, ticket=0):
+        L.check(self._lib.dust_hip_comm_wait(self._h, ticket))
 
     def sync(self):
         L.check(self._lib.dust_hip_comm_sync(self._h))

@@ -105,8 +105,9 @@ struct DustHipComm {
   ncclComm_t nccl = nullptr;                // RCCL communicator, or
   std::shared_ptr<LocalGroup> local;        // the loopback group this rank belongs to
   hipStream_t stream = nullptr;             // the gathers' own stream (RCCL communicators only)
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-  bool in_flight = false;
+  static constexpr uint32_t kTickets = 16;
+  hipEvent_t ev_ready = nullptr, ev_done[kTickets] = {};  // ev_done[t % kTickets]: gather number t has completed
+  uint64_t next_ticket = 1;                  // tickets count the gathers of this communicator from 1
 };
 
 namespace {
@@ -246,9 +247,11 @@ DustStatus dust_hip_comm_create(DustHipContext* ctx, uint32_t rank, uint32_t wor
   NCCL_TRY(r->CommInitRank(&c->nccl, int(world), u, int(rank)));
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+  for (hipEvent_t& ev : c->ev_done)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    for (hipEvent_t ev : c->ev_done) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)r->CommDestroy(c->nccl);
     return hip_fail(e, "communicator stream");
@@ -288,7 +291,7 @@ void dust_hip_comm_destroy(DustHipComm* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) { if (Rccl* r = rccl()) (void)r->CommDestroy(c->nccl); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  for (hipEvent_t ev : c->ev_done) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   dust_internal::context_release(c->ctx);
   delete c;
@@ -302,8 +305,10 @@ DustStatus dust_hip_comm_info(const DustHipComm* c, uint32_t* rank, uint32_t* wo
   return DUST_OK;
 }
 
-DustStatus dust_hip_gather_bands(DustHipPipeline* p, DustHipComm* c, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes) {
+DustStatus dust_hip_gather_bands(DustHipPipeline* p, DustHipComm* c, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes,
+                                 uint64_t* ticket) {
   if (!p || !c || plane >= DUST_PLANE_COUNT || root >= c->world) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad gather arguments");
+  if (ticket) *ticket = 0;
   if (dust_internal::pipeline_context(p) != c->ctx) return set_error(DUST_ERR_INVALID_ARGUMENT, "pipeline and communicator belong to different contexts");
   PlaneView v;
   DUST_TRY(plane_view(p, plane, &v));
@@ -341,16 +346,20 @@ DustStatus dust_hip_gather_bands(DustHipPipeline* p, DustHipComm* c, DustHipPlan
     const size_t off = size_t(cuts[root]) * v.row_bytes, n = size_t(cuts[root + 1] - cuts[root]) * v.row_bytes;
     if (n) HIP_TRY(hipMemcpyAsync(out + off, v.ptr + off, n, hipMemcpyDeviceToDevice, c->stream));
   }
-  HIP_TRY(hipEventRecord(c->ev_done, c->stream));
-  c->in_flight = true;
+  const uint64_t t = c->next_ticket++;
+  HIP_TRY(hipEventRecord(c->ev_done[t % DustHipComm::kTickets], c->stream));
+  if (ticket) *ticket = t;
   return DUST_OK;
 }
 
-DustStatus dust_hip_comm_wait(DustHipComm* c) {
+DustStatus dust_hip_comm_wait(DustHipComm* c, uint64_t ticket) {
   if (!c) return set_error(DUST_ERR_INVALID_ARGUMENT, "null communicator");
-  if (c->local || !c->in_flight) return DUST_OK;  // (a loopback group's collectives run on the context's stream itself)
+  if (c->local || c->next_ticket == 1) return DUST_OK;  // (a loopback group's collectives run on the context's stream itself)
+  if (ticket >= c->next_ticket) return set_error(DUST_ERR_INVALID_ARGUMENT, "no such gather");
+  // gathers complete in order on the communicator's stream: a ticket whose event has been reused since is covered by the latest one
+  const uint64_t t = (ticket == 0 || ticket + DustHipComm::kTickets < c->next_ticket) ? c->next_ticket - 1 : ticket;
   HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
-  HIP_TRY(hipStreamWaitEvent(dust_internal::context_stream(c->ctx), c->ev_done, 0));
+  HIP_TRY(hipStreamWaitEvent(dust_internal::context_stream(c->ctx), c->ev_done[t % DustHipComm::kTickets], 0));
   return DUST_OK;
 }
 
@@ -358,7 +367,6 @@ DustStatus dust_hip_comm_sync(DustHipComm* c) {
   if (!c) return set_error(DUST_ERR_INVALID_ARGUMENT, "null communicator");
   HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
   if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
-  c->in_flight = false;
   return dust_hip_sync(c->ctx);
 }
 

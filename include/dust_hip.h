@@ -428,10 +428,14 @@ DustStatus dust_hip_comm_info(const DustHipComm*, uint32_t* rank, uint32_t* worl
  * rank `root` -- grouped ncclSend / ncclRecv, each peer over its own xGMI link -- into `dst` there (device memory of at least the
  * plane's size; NULL = the root pipeline's own plane, whose remaining rows are then filled in). Asynchronous: ordered behind
  * everything enqueued on the context's stream so far, carried out on the communicator's OWN stream, so that the next band frame
- * (rendering into another bound target) overlaps the transfer. Before a source target or `dst` is used again: dust_hip_comm_wait. */
-DustStatus dust_hip_gather_bands(DustHipPipeline*, DustHipComm*, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes);
-/* the context's stream waits (on the device) for the gathers enqueued so far / the host waits for them and for the context */
-DustStatus dust_hip_comm_wait(DustHipComm*);
+ * (rendering into another bound target) overlaps the transfer. *ticket (may be NULL) numbers the gather, from 1, per communicator.
+ * Before a source target or `dst` is used again: dust_hip_comm_wait with that ticket. */
+DustStatus dust_hip_gather_bands(DustHipPipeline*, DustHipComm*, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes,
+                                 uint64_t* ticket);
+/* the context's stream waits (on the device) for gather `ticket` and every earlier one (0: for all enqueued so far) -- a host that
+ * alternates two render targets waits for the gather that last read a target, not for the one still reading the other /
+ * the host waits for every gather and for the context */
+DustStatus dust_hip_comm_wait(DustHipComm*, uint64_t ticket);
 DustStatus dust_hip_comm_sync(DustHipComm*);
 /* Steps 2-5 of the multi-GPU GI protocol above (dust_hip_pipeline_gi_exchange), enqueued on the context's stream: all-reduce MAX of
  * slot_owner, all-gather of the `touched` bands (band r at row r * band_rows; every band is band_rows rows, the last may be

@@ -370,13 +370,15 @@ class DeviceComm {
   ~DeviceComm() { dust_hip_comm_destroy(h_); }
   DeviceComm(const DeviceComm&) = delete;
   // rows [cuts[r], cuts[r+1]) of `plane` from every rank r to `root` (its own plane when dst is null)
-  void gather_bands(StandardPipeline& p, DustHipPlane plane, const std::vector<uint32_t>& cuts, uint32_t root, void* dst = nullptr, size_t dst_bytes = 0) {
-    check(dust_hip_gather_bands(p.raw(), h_, plane, cuts.data(), root, dst, dst_bytes));
+  uint64_t gather_bands(StandardPipeline& p, DustHipPlane plane, const std::vector<uint32_t>& cuts, uint32_t root, void* dst = nullptr, size_t dst_bytes = 0) {
+    uint64_t ticket = 0;
+    check(dust_hip_gather_bands(p.raw(), h_, plane, cuts.data(), root, dst, dst_bytes, &ticket));
+    return ticket;
   }
   void gi_exchange(StandardPipeline& p, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index) {
     check(dust_hip_gi_exchange_run(p.raw(), h_, row_begin, row_end, band_rows, frame_index));
   }
-  void wait() { check(dust_hip_comm_wait(h_)); }
+  void wait(uint64_t ticket = 0) { check(dust_hip_comm_wait(h_, ticket)); }
   void sync() { check(dust_hip_comm_sync(h_)); }
   DustHipComm* raw() const { return h_; }
  private:

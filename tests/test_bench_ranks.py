@@ -74,7 +74,40 @@ class StubPipe:
     def gi_import(self, r0, r1, f): self.calls.append(("import", r0, r1, f))
 
 
+class StubComm:
+    """api.Comm's interface over gloo: what bench.py's native path calls, recorded; the gather really moves the rows (in place on the
+    root's target, as dust_hip_gather_bands does) so that the assembled frame can be checked"""
+    log = []
+    def __init__(self): self.n = 0
+    def gather_bands(self, pipe, plane, cuts, root=0, dst_ptr=None, dst_bytes=0):
+        cuts = [int(v) for v in cuts]
+        assert plane == L.PLANE_ILLUMINANCE and cuts[0] == 0 and cuts[-1] == H and len(cuts) == world + 1
+        if rank == root:
+            for r in range(world):
+                if r != root and cuts[r] < cuts[r + 1]:
+                    buf = torch.empty_like(pipe.target[cuts[r]:cuts[r + 1]])
+                    dist.recv(buf, src=r)
+                    pipe.target[cuts[r]:cuts[r + 1]] = buf
+            for r in range(world):   # every band of the assembled frame carries its rank and its rows
+                if cuts[r] < cuts[r + 1]:
+                    assert float(pipe.target[cuts[r], 0, 1]) == float(r) and float(pipe.target[cuts[r + 1] - 1, 0, 2]) == float(cuts[r + 1] - 1)
+        elif cuts[rank] < cuts[rank + 1]:
+            dist.send(pipe.target[cuts[rank]:cuts[rank + 1]].contiguous(), dst=root)
+        self.n += 1
+        StubComm.log.append(("gather", root, self.n))
+        return self.n
+    def wait(self, ticket=0): StubComm.log.append(("wait", ticket))
+    def sync(self): StubComm.log.append(("sync",))
+    def gi_exchange(self, pipe, r0, r1, band_rows, frame_index):
+        StubComm.log.append(("gi_exchange", r0, r1, band_rows, frame_index))
+        pipe.gi_export(r0, r1)
+        pipe.gi_import(r0, r1, frame_index)
+
+
 class StubBackend:
+    if os.environ.get("BENCH_NATIVE") == "1":
+        def make_comm(self, dist_, ctx): return StubComm()
+
     def __init__(self):
         self.torch, self.L, self.sharding, self.synth = torch, L, sharding, synth
         self.rank, self.local_rank, self.world = rank, rank, world
@@ -87,6 +120,7 @@ class StubBackend:
         lane.sc = {"scene": None, "cam": None, "sky": None, "info": {"n_models": 1, "n_instances": 1, "n_voxels": 1}, "n_bricks": 1,
                    "t_load": 0.0, "desc": None, "deep": None}
         lane.pipe = StubPipe()
+        lane.ctx = None
         lane.enter = contextlib.nullcontext
         self.pipes.append(lane.pipe)
         return lane
@@ -133,6 +167,16 @@ if rank == 0:
         assert "equal measured cost" in strong["parallelism"]
     if gi:
         assert "clear" in calls and ("export", 0, 24) in calls
+    if os.environ.get("BENCH_NATIVE") == "1":   # the library's own collectives: gathers with rotating roots, tickets waited for, the GI exchange in one call
+        assert "libdust_hip" in strong["collectives"], strong
+        kinds = [c[0] for c in StubComm.log]
+        assert kinds.count("gather") >= 3 + 7 + 1 and "wait" in kinds and "sync" in kinds, kinds
+        assert {c[1] for c in StubComm.log if c[0] == "gather"} == {0, 1}
+        assert all(c[1] > 0 for c in StubComm.log if c[0] == "wait")
+        if gi:
+            assert ("gi_exchange", 0, 24, 24, 1) in StubComm.log, StubComm.log[:8]
+    else:
+        assert "torch.distributed" in strong["collectives"], strong
     print("BENCH_RANKS_OK", json.dumps(out)[:200])
 else:
     assert out is None
@@ -143,7 +187,7 @@ dist.destroy_process_group()
 '''
 
 
-def _run(workload):
+def _run(workload, native=False):
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -151,7 +195,7 @@ def _run(workload):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
-                   BENCH_WORKLOAD=workload)
+                   BENCH_WORKLOAD=workload, BENCH_NATIVE="1" if native else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT={ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
@@ -166,6 +210,14 @@ def test_bench_rank_function_two_ranks_primary_ao():
 
 def test_bench_rank_function_two_ranks_gi():
     _run("gi")
+
+
+def test_bench_rank_function_two_ranks_native_collectives():
+    """--comm native (the default): the band gather and the GI exchange through the library's communicator -- here a gloo stand-in
+    with api.Comm's interface that really moves the rows, so the control flow (tickets, rotating roots, in-place assembly on the root,
+    one gi_exchange call per frame) has executed before an 8-GPU node runs it over RCCL"""
+    _run("primary_ao", native=True)
+    _run("gi", native=True)
 
 
 def test_bench_gpus_without_devices_says_so():
