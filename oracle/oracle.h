@@ -179,9 +179,18 @@ int orc_hash_get(OrcGI*, const int32_t pos[3], uint32_t dir, uint32_t frame_inde
 void orc_pass_final_gather(const OrcScene*, int mode, const OrcCamera*, const OrcSky*, OrcGBuffer*, const uint8_t* noise0,
                            const uint8_t* noise5, uint32_t rand, uint32_t frame_index, OrcGI*, uint32_t y0, uint32_t y1,
                            OrcRayStats* stats);
+/* the same pass on n_threads host threads, with the serial pass's result (surfel enqueues are logged per row band and applied in
+ * row-major order afterwards); for frames at the reference's size */
+void orc_pass_final_gather_mt(const OrcScene*, int mode, const OrcCamera*, const OrcSky*, OrcGBuffer*, const uint8_t* noise0,
+                              const uint8_t* noise5, uint32_t rand, uint32_t frame_index, OrcGI*, uint32_t y0, uint32_t y1,
+                              uint32_t n_threads, OrcRayStats* stats);
 /* surfel.rgen/.rchit/.rmiss + surfel/nee.rmiss */
 void orc_pass_surfel(const OrcScene*, int mode, const OrcSky*, const uint8_t* noise0, const uint8_t* noise5, uint32_t rand,
                      uint32_t frame_index, OrcGI*, OrcRayStats* stats_sun, OrcRayStats* stats_cos);
+
+/* phase 1 (trace + hash reads) on n_threads host threads, phase 2 (inserts in surfel order) as in the serial pass: same result */
+void orc_pass_surfel_mt(const OrcScene*, int mode, const OrcSky*, const uint8_t* noise0, const uint8_t* noise5, uint32_t rand,
+                        uint32_t frame_index, OrcGI*, uint32_t n_threads, OrcRayStats* stats_sun, OrcRayStats* stats_cos);
 
 /* auto exposure + tone map (auto_exposure.comp, auto_exposure_avg.comp, tone_map.comp) */
 void orc_exposure_histogram(const uint16_t* illuminance, uint32_t w, uint32_t h, float min_log, float log_range, uint32_t hist[256]);

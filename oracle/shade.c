@@ -17,6 +17,7 @@
 #include "oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -995,9 +996,14 @@ static void brick_surfel(const OrcScene* s, uint32_t inst, uint32_t block, float
 }
 
 /* final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24 */
-void orc_pass_final_gather(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky* sky, OrcGBuffer* g, const uint8_t* noise0,
-                           const uint8_t* noise5, uint32_t rnd, uint32_t frame_index, OrcGI* gi, uint32_t y0, uint32_t y1,
-                           OrcRayStats* st) {
+/* The pass over rows [y0, y1). log == NULL: surfel enqueues go straight into the pool (the serial pass, row-major: the last pixel that
+ * aliases a slot wins). log != NULL: they are appended to it instead, in pixel order -- the threaded pass applies the threads' logs
+ * one after the other, band by band, which is the same row-major order. */
+typedef struct { uint32_t slot; OrcSurfel sf; } PoolWrite;
+typedef struct { PoolWrite* w; size_t n, cap; } PoolLog;
+static void final_gather_rows(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky* sky, OrcGBuffer* g, const uint8_t* noise0,
+                              const uint8_t* noise5, uint32_t rnd, uint32_t frame_index, OrcGI* gi, uint32_t y0, uint32_t y1,
+                              OrcRayStats* st, PoolLog* log) {
   const uint32_t W = g->width, H = g->height;
   for (uint32_t py = y0; py < y1 && py < H; ++py)
     for (uint32_t px = 0; px < W; ++px) {
@@ -1030,19 +1036,72 @@ void orc_pass_final_gather(const OrcScene* s, int mode, const OrcCamera* cam, co
       hash_get(gi, key, frame_index, &rad, &count);
       float prob = 1.0f / (float)(count + 2u);
       float noise = (float)noise0[((size_t)((py + 21u + rnd) % 128u)) * 128 + ((px + 34u + rnd) % 128u)] / 255.0f;
-      if (noise > prob) gi->pool[(px + py * W) % gi->pool_size] = sf; /* final_gather.rchit:52-63 */
+      if (noise > prob) { /* final_gather.rchit:52-63 */
+        const uint32_t slot = (px + py * W) % gi->pool_size;
+        if (!log) gi->pool[slot] = sf;
+        else {
+          if (log->n == log->cap) { log->cap = log->cap ? log->cap * 2 : 4096; log->w = (PoolWrite*)realloc(log->w, log->cap * sizeof(PoolWrite)); }
+          log->w[log->n].slot = slot; log->w[log->n].sf = sf; log->n += 1;
+        }
+      }
       rad = modulate_by_avg_albedo(rad, alb);
       pack_radiance(V3(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), t, g->illuminance + pix * 4);
     }
 }
 
+void orc_pass_final_gather(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky* sky, OrcGBuffer* g, const uint8_t* noise0,
+                           const uint8_t* noise5, uint32_t rnd, uint32_t frame_index, OrcGI* gi, uint32_t y0, uint32_t y1,
+                           OrcRayStats* st) {
+  final_gather_rows(s, mode, cam, sky, g, noise0, noise5, rnd, frame_index, gi, y0, y1, st, NULL);
+}
+
+/* The same pass on n_threads host threads (row bands), with the serial pass's result: a pixel only writes its own texel; the hash is
+ * only READ, apart from last_accessed_frame stamps, which all carry this frame's index (concurrent stores of one value); the surfel
+ * enqueues -- the one order-dependent effect -- are logged per band and applied band after band. */
+typedef struct {
+  const OrcScene* s; int mode; const OrcCamera* cam; const OrcSky* sky; OrcGBuffer* g; const uint8_t *noise0, *noise5;
+  uint32_t rnd, frame_index; OrcGI* gi; uint32_t y0, y1; OrcRayStats st; PoolLog log;
+} FgJob;
+static void* fg_thread(void* p) {
+  FgJob* j = (FgJob*)p;
+  final_gather_rows(j->s, j->mode, j->cam, j->sky, j->g, j->noise0, j->noise5, j->rnd, j->frame_index, j->gi, j->y0, j->y1, &j->st, &j->log);
+  return NULL;
+}
+static void add_ray_stats(OrcRayStats* d, const OrcRayStats* a) {
+  d->rays += a->rays; d->instances_tested += a->instances_tested; d->upper_descents += a->upper_descents;
+  d->mid_descents += a->mid_descents; d->bricks_tested += a->bricks_tested; d->hits += a->hits;
+}
+void orc_pass_final_gather_mt(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky* sky, OrcGBuffer* g, const uint8_t* noise0,
+                              const uint8_t* noise5, uint32_t rnd, uint32_t frame_index, OrcGI* gi, uint32_t y0, uint32_t y1,
+                              uint32_t n_threads, OrcRayStats* st) {
+  if (y1 > g->height) y1 = g->height;
+  if (n_threads < 1) n_threads = 1;
+  if (y1 > y0 && n_threads > y1 - y0) n_threads = y1 - y0;
+  FgJob* jobs = (FgJob*)calloc(n_threads, sizeof(FgJob));
+  pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    FgJob* j = &jobs[t];
+    j->s = s; j->mode = mode; j->cam = cam; j->sky = sky; j->g = g; j->noise0 = noise0; j->noise5 = noise5; j->rnd = rnd;
+    j->frame_index = frame_index; j->gi = gi;
+    j->y0 = y0 + (uint32_t)(((uint64_t)(y1 - y0) * t) / n_threads);
+    j->y1 = y0 + (uint32_t)(((uint64_t)(y1 - y0) * (t + 1)) / n_threads);
+    pthread_create(&th[t], NULL, fg_thread, j);
+  }
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    pthread_join(th[t], NULL);
+    for (size_t k = 0; k < jobs[t].log.n; ++k) gi->pool[jobs[t].log.w[k].slot] = jobs[t].log.w[k].sf; /* bands in order = row-major order */
+    free(jobs[t].log.w);
+    if (st) add_ray_stats(st, &jobs[t].st);
+  }
+  free(th); free(jobs);
+}
+
 /* surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27 */
-void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
-                     uint32_t frame_index, OrcGI* gi, OrcRayStats* st_sun, OrcRayStats* st_cos) {
-  const uint32_t N = gi->pool_size;
-  typedef struct { int kind; HashKey key; v3 value; int replace; OrcSurfel repl; } Req;
-  Req* req = (Req*)calloc(N, sizeof(Req));
-  for (uint32_t i = 0; i < N; ++i) { /* phase 1 */
+typedef struct { int kind; HashKey key; v3 value; int replace; OrcSurfel repl; } SurfelReq;
+/* phase 1 for surfels [i0, i1): traces, READS the hash as it stands (plus frame stamps) and fills in req[i] */
+static void surfel_trace_range(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
+                               uint32_t frame_index, OrcGI* gi, SurfelReq* req, uint32_t i0, uint32_t i1, OrcRayStats* st_sun, OrcRayStats* st_cos) {
+  for (uint32_t i = i0; i < i1; ++i) { /* phase 1 */
     OrcSurfel e = gi->pool[i];
     if (e.direction >= 6u) continue;
     v3 n = faceid2normal(e.direction);
@@ -1085,11 +1144,52 @@ void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8
       if (rnd0 > prob) { req[i].replace = 1; req[i].repl = sf; }
     }
   }
+}
+static void surfel_apply(OrcGI* gi, const SurfelReq* req, uint32_t frame_index) {
+  const uint32_t N = gi->pool_size;
   for (uint32_t i = 0; i < N; ++i) { /* phase 2: in surfel order */
     if (req[i].kind == 1) hash_insert(gi, req[i].key, req[i].value, frame_index);
     if (req[i].replace) gi->pool[i % N] = req[i].repl;
   }
+}
+void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
+                     uint32_t frame_index, OrcGI* gi, OrcRayStats* st_sun, OrcRayStats* st_cos) {
+  SurfelReq* req = (SurfelReq*)calloc(gi->pool_size, sizeof(SurfelReq));
+  surfel_trace_range(s, mode, sky, noise0, noise5, rnd, frame_index, gi, req, 0, gi->pool_size, st_sun, st_cos);
+  surfel_apply(gi, req, frame_index);
   free(req);
+}
+/* phase 1 on n_threads host threads (it writes nothing but its own request and frame stamps), phase 2 as above */
+typedef struct {
+  const OrcScene* s; int mode; const OrcSky* sky; const uint8_t *noise0, *noise5; uint32_t rnd, frame_index; OrcGI* gi; SurfelReq* req;
+  uint32_t i0, i1; OrcRayStats st_sun, st_cos;
+} SfJob;
+static void* sf_thread(void* p) {
+  SfJob* j = (SfJob*)p;
+  surfel_trace_range(j->s, j->mode, j->sky, j->noise0, j->noise5, j->rnd, j->frame_index, j->gi, j->req, j->i0, j->i1, &j->st_sun, &j->st_cos);
+  return NULL;
+}
+void orc_pass_surfel_mt(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
+                        uint32_t frame_index, OrcGI* gi, uint32_t n_threads, OrcRayStats* st_sun, OrcRayStats* st_cos) {
+  const uint32_t N = gi->pool_size;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > N) n_threads = N;
+  SurfelReq* req = (SurfelReq*)calloc(N, sizeof(SurfelReq));
+  SfJob* jobs = (SfJob*)calloc(n_threads, sizeof(SfJob));
+  pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    SfJob* j = &jobs[t];
+    j->s = s; j->mode = mode; j->sky = sky; j->noise0 = noise0; j->noise5 = noise5; j->rnd = rnd; j->frame_index = frame_index; j->gi = gi; j->req = req;
+    j->i0 = (uint32_t)(((uint64_t)N * t) / n_threads); j->i1 = (uint32_t)(((uint64_t)N * (t + 1)) / n_threads);
+    pthread_create(&th[t], NULL, sf_thread, j);
+  }
+  for (uint32_t t = 0; t < n_threads; ++t) {
+    pthread_join(th[t], NULL);
+    if (st_sun) add_ray_stats(st_sun, &jobs[t].st_sun);
+    if (st_cos) add_ray_stats(st_cos, &jobs[t].st_cos);
+  }
+  surfel_apply(gi, req, frame_index);
+  free(th); free(jobs); free(req);
 }
 
 

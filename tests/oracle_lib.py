@@ -128,6 +128,11 @@ def lib():
                                             C.POINTER(OrcRayStats)]
         l.orc_pass_surfel.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcSky), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.POINTER(OrcRayStats), C.POINTER(OrcRayStats)]
+        l.orc_pass_final_gather_mt.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcCamera), C.POINTER(OrcSky), C.POINTER(OrcGBuffer),
+                                               C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.POINTER(OrcRayStats)]
+        l.orc_pass_surfel_mt.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcSky), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_uint32, C.POINTER(OrcRayStats), C.POINTER(OrcRayStats)]
         l.orc_exposure_histogram.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         l.orc_exposure_average.restype = C.c_float
         l.orc_exposure_average.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]

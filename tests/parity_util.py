@@ -99,7 +99,8 @@ def oracle_scene(desc: SceneDesc):
 
 
 def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.ORC_MODE_HIER, rows=None, stats=None,
-                  noise0=None, gi=None, frame_index=1, g=None):
+                  noise0=None, gi=None, frame_index=1, g=None, gi_threads=0):
+    """gi_threads > 0: the GI passes on that many host threads (orc_pass_final_gather_mt / orc_pass_surfel_mt: the serial passes' result)"""
     g = g or O.GBuffer(w, h)
     oc, osky = O.camera_from(cam), O.sky_from(sky)
     y0, y1 = rows if rows else (0, h)
@@ -114,10 +115,16 @@ def render_oracle(oscene, cam, sky, w, h, passes, noise5=None, rand=0, mode=O.OR
     if passes & (L.PASS_FINAL_GATHER | L.PASS_SURFEL):
         n0 = np.ascontiguousarray(noise0, np.uint8)
         n5 = np.ascontiguousarray(noise5, np.uint8)
-    if passes & L.PASS_FINAL_GATHER:
+    if passes & L.PASS_FINAL_GATHER and gi_threads:
+        l.orc_pass_final_gather_mt(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), n0.ctypes.data_as(C.c_void_p),
+                                   n5.ctypes.data_as(C.c_void_p), rand, frame_index, gi.h, y0, y1, gi_threads, C.byref(st[3]))
+    elif passes & L.PASS_FINAL_GATHER:
         l.orc_pass_final_gather(oscene.h, mode, C.byref(oc), C.byref(osky), C.byref(g.c), n0.ctypes.data_as(C.c_void_p),
                                 n5.ctypes.data_as(C.c_void_p), rand, frame_index, gi.h, y0, y1, C.byref(st[3]))
-    if passes & L.PASS_SURFEL:
+    if passes & L.PASS_SURFEL and gi_threads:
+        l.orc_pass_surfel_mt(oscene.h, mode, C.byref(osky), n0.ctypes.data_as(C.c_void_p), n5.ctypes.data_as(C.c_void_p), rand,
+                             frame_index, gi.h, gi_threads, C.byref(st[4]), C.byref(st[5]))
+    elif passes & L.PASS_SURFEL:
         l.orc_pass_surfel(oscene.h, mode, C.byref(osky), n0.ctypes.data_as(C.c_void_p), n5.ctypes.data_as(C.c_void_p), rand,
                           frame_index, gi.h, C.byref(st[4]), C.byref(st[5]))
     return g

@@ -79,3 +79,26 @@ def test_gi_frames_feed_back():
     assert filled[0] > 0 and filled[-1] >= filled[0]
     hh = gi.hash()
     assert (hh["sample_count"][hh["fingerprint"] != 0] >= 1).all()
+
+
+def test_threaded_gi_passes_equal_the_serial_ones():
+    """orc_pass_final_gather_mt / orc_pass_surfel_mt (what the full-size GPU comparison threads the oracle with) leave the G-buffer,
+    the hash and the pool exactly as the serial passes do -- small tables, so that slots alias and probes collide."""
+    desc = P.small_scene(seed=8, n_models=2, n_instances=5, size=(28, 28, 28))
+    s = P.oracle_scene(desc)
+    sky = P.sky_state()
+    cam = P.camera_for((80.0, 60.0, 90.0))
+    w, h = 72, 48
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL
+    out = []
+    for threads in (0, 5):
+        gi = O.GI(211, 97)   # (pool slots alias every 97 pixels, far inside a thread's band and across bands)
+        for f in range(1, 5):
+            g = P.render_oracle(s, cam, sky, w, h, passes, n5[f % 4], synth.frame_rand(1, f), noise0=n0[f % 4], gi=gi, frame_index=f,
+                                gi_threads=threads)
+        out.append((gi.hash().copy(), gi.pool().copy(), g.illuminance.copy()))
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    assert out[0][2].tobytes() == out[1][2].tobytes()
+    assert int((out[0][0]["fingerprint"] != 0).sum()) >= 10 and int((out[0][1]["direction"] < 6).sum()) >= 10

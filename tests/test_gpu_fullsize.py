@@ -87,3 +87,40 @@ def test_full_size_sharded_gi_equals_single_device(castle):
     h_ref = P.sharded_gi_vs_single_device(ctx, scene, P.camera_for(EYE), P.sky_state(), W, H, world=2, frames=2,
                                           n0=synth.stbn_scalar(), n5=synth.stbn_unitvec3_cosine())
     assert int((h_ref[:, 0] != 0).sum()) > 10_000
+
+
+def test_full_size_gi_matches_oracle(castle):
+    """BASELINE configs[2]'s passes at the reference's sizes -- 1920 x 1080, the 32 Mi-entry spatial hash (spatial_hash.glsl:1) and the
+    345 600-slot surfel pool (surfel.glsl:2; standard.rs:330-358) -- against the oracle, three frames with the deterministic apply:
+    every integer of the hash (fingerprints, counts, LRU stamps) and the pool bit for bit, LogLuv radiance within two quantisation
+    steps, the G-buffer as in the small-frame tests, illuminance <= 1e-3 relative L2. The oracle's pixel passes are threaded over
+    rows, its GI passes over bands / surfel ranges (orc_pass_*_mt: the serial passes' result, tests/test_gi_oracle.py)."""
+    from test_gpu_gi import compare_gi
+    ctx, desc, scene, _ = castle
+    n0, n5 = synth.stbn_scalar(), synth.stbn_unitvec3_cosine()
+    cam, sky = P.camera_for(EYE), P.sky_state()
+    pipe = api.StandardPipeline(ctx, W, H)
+    pipe.set_noise(0, n0)
+    pipe.set_noise(5, n5)
+    pipe.configure_gi(32 * 1024 * 1024, 720 * 480)
+    gi = O.GI(32 * 1024 * 1024, 720 * 480)
+    oscene = P.oracle_scene(desc)
+    g = O.GBuffer(W, H)
+    threads = max(1, min(os.cpu_count() or 1, H // 4))
+    cuts = [H * i // threads for i in range(threads + 1)]
+    pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    for f in range(1, 4):
+        rnd = synth.frame_rand(1, f)
+        pipe.render(scene, cam, sky, pix | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
+        th = [threading.Thread(target=P.render_oracle, args=(oscene, cam, sky, W, H, pix, n5[f % len(n5)], rnd),
+                               kwargs={"rows": (cuts[i], cuts[i + 1]), "g": g}) for i in range(threads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        P.render_oracle(oscene, cam, sky, W, H, L.PASS_FINAL_GATHER | L.PASS_SURFEL, n5[f % len(n5)], rnd, noise0=n0[f % len(n0)], gi=gi,
+                        frame_index=f, g=g, gi_threads=threads)
+        hip = P.read_hip_gbuffer(pipe)
+        res = P.compare_gbuffers(g, hip)
+        P.assert_parity(res)
+        assert res["illuminance_rel_l2"] <= 1e-3, (f, res)
+        used, valid = compare_gi(gi, pipe)
+    assert used > 20_000 and valid > 300_000, (used, valid)   # (three frames: the pool is nearly full, the hash holds the bricks the surfels see)
