@@ -1551,6 +1551,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // An event pair around a launch costs the stream ~6 us per record (a marker packet the next dispatch waits behind): 5 % of a
   // 0.23 ms frame. A context that only wants averages over a run of frames (bench.py) times every 4th frame's launches.
   p->timed_frame = ctx->timing && (p->frame_counter++ % ctx->timing_stride) == 0;
+  // (a frame that is not timed has no times: dust_hip_pipeline_pass_stats must not hand out an earlier frame's)
+  if (!p->timed_frame) for (bool& v : p->ev_valid) v = false;
   // while a surfel pass may be running on the second stream, the primary / AO kernels leave it its share of the slots (persistent
   // launches hold what they get: whichever came first would otherwise own the GPU until it is done)
   // The share: the pass's rays against the pixel passes' (pool x 18 surfel-ray costs to 3 rays per pixel, which puts the castle at

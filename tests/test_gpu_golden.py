@@ -110,3 +110,36 @@ def test_tile_order_is_a_stable_sort_by_cost_class(ctx):
             digit = np.where(qb == 0, 31, np.minimum(top - qb, 31))
             expect[lo:hi] = lo + np.argsort(digit, kind="stable")
         assert np.array_equal(out, expect), n
+
+
+def test_tile_order_with_cost_balanced_bands(ctx):
+    """device function 14 = k_tile_order as a frame uses it: the tile list is cut into 8 contiguous bands of about equal COST (not equal
+    count), and inside each band the stable class sort of test_tile_order_is_a_stable_sort_by_cost_class. Against numpy: the cuts
+    are where the running cost passes k/8 of the total, every band holds exactly its own tiles, and its order is that sort."""
+    rng = np.random.default_rng(14)
+    for n in (9, 100, 32400, 129_600):
+        k = rng.integers(40, 121, n)
+        cost = np.floor(np.exp2((k + 0.5) / 4.0)).astype(np.uint32)
+        cost[n // 3: n // 2] = np.floor(np.exp2((rng.integers(40, 60, n // 2 - n // 3) + 0.5) / 4.0)).astype(np.uint32)   # a cheap stretch (sky)
+        if n > 100:
+            cost[rng.random(n) < 0.05] = 0
+        out = ctx.device_eval(14, np.ascontiguousarray(cost.reshape(-1, 1)), 2)
+        order, cuts = out[:, 0], [int(v) for v in out[:9, 1]]
+        assert cuts[0] == 0 and cuts[8] == n and all(a <= b for a, b in zip(cuts, cuts[1:])), cuts
+        eff = np.maximum(cost, 1).astype(np.int64)   # (a tile nobody has timed counts as cheap)
+        run = np.concatenate([[0], np.cumsum(eff)])
+        for b in range(1, 8):   # cut b = one past the first tile at which the running cost reaches b/8 of the total
+            target = run[-1] // 8 * b
+            want = int(np.searchsorted(run[1:], target, side="left")) + 1 if target > 0 else 0
+            assert cuts[b] == min(want, n), (n, b, cuts[b], want)
+        if n >= 32400:
+            sums = np.array([run[cuts[b + 1]] - run[cuts[b]] for b in range(8)], np.float64)
+            assert sums.max() / sums.mean() < 1.01, sums
+        q = np.where(cost == 0, 0, 1 + np.floor(4.0 * np.log2(np.maximum(cost, 1).astype(np.float64))).astype(np.int64))
+        for b in range(8):
+            lo, hi = cuts[b], cuts[b + 1]
+            if lo == hi:
+                continue
+            qb = q[lo:hi]
+            digit = np.where(qb == 0, 31, np.minimum(qb.max() - qb, 31))
+            assert np.array_equal(order[lo:hi], lo + np.argsort(digit, kind="stable")), (n, b)

@@ -338,3 +338,47 @@ def test_bound_plane_equals_own_storage():
     pipe = api.StandardPipeline(ctx, W, H)
     with pytest.raises(L.DustError):
         pipe.bind_plane(L.PLANE_ILLUMINANCE, torch.zeros(16, device="cuda").data_ptr(), 64)   # too small
+
+
+def test_moving_view_hand_out_never_changes_a_result():
+    """A view that moves: the cost-balanced bands, the order re-made every fourth launch from running-mean costs spread over 3 x 3 tiles,
+    set_transform + commit into the ring of scene images every frame -- all of it decides which wave traces which tile when, never a
+    texel: every frame of a moving sequence equals the same frame rendered by a pipeline and a scene that have no history."""
+    W, H = 264, 152
+    ctx = api.Context(device=0)
+    desc = P.small_scene(seed=21, n_models=3, n_instances=7)
+    scene = P.hip_scene(ctx, desc)
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    pipe = api.StandardPipeline(ctx, W, H)
+    pipe.set_noise(5, n5)
+    moved = 3
+    base = np.asarray(desc.instances[moved][1], np.float32).reshape(3, 4)
+    for f in range(1, 22):
+        eye = (90.0 * np.cos(0.05 * f), 60.0 + f, -80.0 * np.sin(0.05 * f) - 40.0)
+        cam = P.camera_for(eye)
+        xf = base.copy()
+        xf[:, 3] += np.array([2.0 * f, 0.0, -1.5 * f], np.float32)
+        scene.set_transform(moved, xf.reshape(12))
+        scene.commit()
+        pipe.render(scene, cam, sky, passes, f, synth.frame_rand(3, f))
+        if f % 4 == 1 or f > 17:
+            got = P.read_hip_gbuffer(pipe)
+            d2 = P.SceneDesc(desc.models, desc.palette, [(m, (xf.reshape(12) if i == moved else t)) for i, (m, t) in enumerate(desc.instances)])
+            fresh_scene = P.hip_scene(ctx, d2)
+            fresh = api.StandardPipeline(ctx, W, H)
+            fresh.set_noise(5, n5)
+            fresh.render(fresh_scene, cam, sky, passes, f, synth.frame_rand(3, f))
+            want = P.read_hip_gbuffer(fresh)
+            hit = np.isfinite(want["depth"])
+            assert hit.any() and not hit.all()
+            for k in want:
+                if k == "motion":
+                    continue   # (the moved instance's motion vectors are measured against its previous transform, which the fresh scene does not have)
+                a, b = want[k], got[k]
+                if k in ("illuminance", "normal", "voxel_id"):   # planes only hit pixels write (hit.rchit:57-94): a pixel that misses keeps what an earlier frame left
+                    a, b = a[hit], b[hit]
+                elif k == "denoised":                             # ... and this one only the pixels that miss (miss.rmiss:13)
+                    a, b = a[~hit], b[~hit]
+                assert a.tobytes() == b.tobytes(), (f, k)
