@@ -351,6 +351,8 @@ struct Tuning {
   uint32_t static_rounds = 0xFFFFFFFFu;  // DUST_HIP_STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
   uint32_t still_refresh_max = 64;  // DUST_HIP_STILL_REFRESH_MAX: cap of the launches between two re-measurements of a view that stands still
   uint32_t cost_keep_shift = 1; // DUST_HIP_COST_KEEP_SHIFT k: a tile's cost estimate moves 1 / 2^k of the way to each new measurement (0: takes it as it is)
+  bool wide_fused = true;       // DUST_HIP_NO_WIDE_FUSED: the fused kernel always as two 512-thread workgroups per CU
+  bool dilate_still = false;    // DUST_HIP_DILATE_STILL: ... of a still view as well (experiment)
   bool dilate = true;           // DUST_HIP_NO_DILATE: a moving view's order from the tiles' own costs only
   bool force_moving = false;    // DUST_HIP_FORCE_MOVING: treat every view as a moving one (diagnostic)
   uint32_t cuts_reuse = 4;      // DUST_HIP_CUTS_REUSE: re-orderings of a moving view that keep one set of band cuts
@@ -365,7 +367,10 @@ struct Tuning {
   static Tuning from_environment() {
     Tuning t;
     t.debug = num("DUST_HIP_DEBUG", 0);
-    t.block = std::min(512u, std::max(128u, num("DUST_HIP_BLOCK", 512) & ~127u));  // <= the kernels' launch bounds (512); an even number of
+#ifndef DUST_MAX_BLOCK
+#define DUST_MAX_BLOCK 512u   // the kernels' launch bounds (an experiment build may raise both)
+#endif
+    t.block = std::min(DUST_MAX_BLOCK, std::max(128u, num("DUST_HIP_BLOCK", 512) & ~127u));  // <= the kernels' launch bounds (512); an even number of
                                                                                     // waves keeps the LDS areas behind the per-wave lists 16-byte aligned
     t.blocks_per_cu = std::max(1u, num("DUST_HIP_BLOCKS_PER_CU", 2));
     t.reserve_blocks = num("DUST_HIP_RESERVE_BLOCKS", 0) & ~7u;  // whole rounds over the 8 XCDs
@@ -383,6 +388,8 @@ struct Tuning {
     t.moving_refresh = std::max(1u, num("DUST_HIP_MOVING_REFRESH", 4));
     t.cost_keep_shift = std::min(4u, num("DUST_HIP_COST_KEEP_SHIFT", 1));
     t.dilate = std::getenv("DUST_HIP_NO_DILATE") == nullptr;
+    t.wide_fused = std::getenv("DUST_HIP_NO_WIDE_FUSED") == nullptr && std::getenv("DUST_HIP_BLOCK") == nullptr;
+    t.dilate_still = std::getenv("DUST_HIP_DILATE_STILL") != nullptr;
     t.force_moving = std::getenv("DUST_HIP_FORCE_MOVING") != nullptr;
     t.cuts_reuse = std::max(1u, num("DUST_HIP_CUTS_REUSE", 4));
     t.still_refresh_max = std::max(1u, num("DUST_HIP_STILL_REFRESH_MAX", 64));
@@ -1373,7 +1380,7 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     // (the cost-balanced cuts drift slowly: a view that moves keeps them for kCutsReuse re-orderings -- the scan for them is the longer half of the sorter)
     const bool reuse = h.ordered && h.cuts_age + 1 < p->tune.cuts_reuse && h.moving;
     HIP_TRY(dust::launch_cost_blend(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.smooth.p), total, p->tune.cost_keep_shift, st));
-    const bool spread = h.moving && p->tune.dilate && a.tiles_y > 1u;
+    const bool spread = (h.moving || p->tune.dilate_still) && p->tune.dilate && a.tiles_y > 1u;
     if (spread) HIP_TRY(dust::launch_cost_dilate(static_cast<const uint32_t*>(h.smooth.p), static_cast<uint32_t*>(h.spread.p), a.tiles_x, a.tiles_y, st));
     HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(spread ? h.spread.p : h.smooth.p), static_cast<uint32_t*>(h.order.p),
                                     p->tune.equal_bands ? nullptr : static_cast<uint32_t*>(h.cuts.p), reuse, total, per_band, st));
@@ -1610,7 +1617,16 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
-    HIP_TRY(dust::launch_primary_ao(a, grid, block, count, st));
+    // One 1024-thread workgroup per CU when the kernel has the device to itself (no surfel pass beside it, one frame in flight,
+    // no slots reserved, the default block size): the roots are staged once per CU and sixteen waves share a tile queue
+    uint32_t fblock = block, fgrid = grid;
+    const size_t lds_wide = size_t(a.n_lds_models) * dust::kN16LdsBytes + 16u * (dust::kMaxCand * 8 + 8) + 16 + size_t(a.n_lds_boxes) * 32;
+    if (tune.wide_fused && block == 512 && bpc == 2 && !ctx->side_busy && p->frames_in_flight <= 1 && !tune.reserve_blocks && lds_wide <= ctx->max_lds &&
+        grid == resident) {
+      fblock = 1024;
+      fgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus), (total_tiles + 7) / 8));
+    }
+    HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {

@@ -1530,7 +1530,16 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   // scene's packed root table
   const uint32_t n16 = a.n_lds_models * (kN16LdsBytes / 16u);
   DUST_RO(u32x4) src = (DUST_RO(u32x4))a.root_table;
-  for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<u32x4*>(g_lds)[i] = src[i];
+  {  // four 16-byte loads in flight per lane before the first is stored (this loop is the launch's first ~3 us: nothing but latency)
+    u32x4* dst = reinterpret_cast<u32x4*>(g_lds);
+    const uint32_t step = blockDim.x;
+    uint32_t i = threadIdx.x;
+    for (; i + 3u * step < n16; i += 4u * step) {
+      const u32x4 v0 = src[i], v1 = src[i + step], v2 = src[i + 2u * step], v3 = src[i + 3u * step];
+      dst[i] = v0; dst[i + step] = v1; dst[i + 2u * step] = v2; dst[i + 3u * step] = v3;
+    }
+    for (; i < n16; i += step) dst[i] = src[i];
+  }
   {  // the instance boxes the packet cull streams through, when they fit as well
     DUST_RO(u32x4) bsrc = (DUST_RO(u32x4))a.boxes;
     u32x4* bdst = lds_boxes(a);
@@ -1755,8 +1764,10 @@ __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
 #ifndef DUST_POOL_GROUP
 #define DUST_POOL_GROUP 256  // entries per work item of the ray-lane kernels (k_final_gather_pool, k_surfel_trace_pool)
 #endif
+// The fused kernel may be launched as ONE 1024-thread workgroup per CU instead of two of 512 (capi.cpp, render_frame): the same
+// 4 waves per SIMD, but the roots are staged once per CU instead of twice and sixteen waves share a tile queue (-1 %).
 #ifndef DUST_PAO_THREADS
-#define DUST_PAO_THREADS 512
+#define DUST_PAO_THREADS 1024
 #define DUST_PAO_WAVES 4
 #endif
 template <int MODE>

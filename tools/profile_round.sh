@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ keeps for a round:
-#   python tools/kernel_sections.py --build && gpurun --timeout 2400 -- "HEAD_STAMP=$(git rev-parse --short HEAD) bash tools/profile_round.sh r03"
+#   python tools/kernel_sections.py --build && make -s -C dust_amd/csrc VARIANT=wt EXTRA=-DDUST_WAVE_TIMES && gpurun --timeout 2400 -- "HEAD_STAMP=$(git rev-parse --short HEAD) bash tools/profile_round.sh r03"
 # writes gpurun_out/<tag>_{gpu_tests.log,bench*.log,kernel_stats*.{txt,json},pmc*.txt,sections*.txt,tile_costs.txt,denoise_kernels.txt}.
 # Counter passes run separately from the kernel-trace/stats pass (one counter group per run).
 tag=${1:-r01}
@@ -13,29 +13,30 @@ cd "$R" || exit 1
 { echo "# HEAD ${HEAD_STAMP:-unknown}"; python -m pytest tests -m gpu -x -q -p no:cacheprovider; } > "$out/${tag}_gpu_tests.log" 2>&1
 tail -2 "$out/${tag}_gpu_tests.log"
 
-python bench.py > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"
+python bench.py --no-extra-curves > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench.log" | cut -c1-600
 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_gi.log" | cut -c1-600
 python bench.py --workload deep --steps 30 > "$out/${tag}_bench_deep.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_deep.log" | cut -c1-600
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/${tag}_bench_driver_style.log" 2>> "$out/${tag}_bench.err"   # the driver's command line
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/${tag}_bench_driver_style.log" 2>> "$out/${tag}_bench.err"   # the driver's command line: the headline + curves.moving / primary_ao_4k / gi_1080p / deep
+python bench.py --camera orbit --steps 240 --no-cpu-baseline > "$out/${tag}_bench_moving.log" 2>> "$out/${tag}_bench.err"   # the moving view as the headline
 python bench.py --workload teapot_cpu > "$out/${tag}_bench_teapot_cpu.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_RAY_LANES=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ray_lanes.log" 2>> "$out/${tag}_bench.err"
-python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
+python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 # what ONE rank of an N-GPU row-band run does between collectives (four frames in flight, launches on a quarter of the slots each): every band of N = 2, 4, 8
 : > "$out/${tag}_bench_bands_emulated.log"
 for n in 2 4 8; do for r in $(seq 0 $((n - 1))); do
-  DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
+  DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
     python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/$n', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight'], 'rays_per_step': j['config']['rays_per_step_all_gpus']}))" >> "$out/${tag}_bench_bands_emulated.log"
 done; done
 
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench -- \
-    python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_prof.log" 2>&1
+    python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi -- \
     python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_deep -- \
@@ -56,7 +57,7 @@ for wl in primary_ao gi deep; do
     n=$(echo $c | cut -d' ' -f1)
     if [ $wl = deep ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ]; then continue; fi
     rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$tag" -o ${wl}_$n -- \
-        python "$R/bench.py" --workload $wl --steps 4 --warmup 2 --no-cpu-baseline > "$out/pmc_${wl}_$n.log" 2>&1
+        python "$R/bench.py" --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${wl}_$n.log" 2>&1
   done
 done
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'primary_ao_*_results.db' | sort) > "$out/${tag}_pmc.txt" 2>&1
@@ -68,5 +69,7 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o denoise -- \
 python "$R/tools/kernel_sections.py" > "$out/${tag}_sections.txt" 2>&1
 python "$R/tools/kernel_sections.py" --deep > "$out/${tag}_sections_deep.txt" 2>&1
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
+DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times.txt" 2>&1
+DUST_HIP_EQUAL_BANDS=1 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times_equal_bands.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
