@@ -33,6 +33,13 @@ for n in 2 4 8; do for r in $(seq 0 $((n - 1))); do
     python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/$n', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight'], 'rays_per_step': j['config']['rays_per_step_all_gpus']}))" >> "$out/${tag}_bench_bands_emulated.log"
 done; done
 
+# a 1/8 band launched ALONE, one frame in flight: what single-frame strong scaling on 8 GPUs would get from the kernel
+: > "$out/${tag}_bench_band_alone.log"
+for r in 0 1 2 3 4 5 6 7; do
+  DUST_BENCH_EMULATE_BAND=$r/8 python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 1 2>> "$out/${tag}_bench.err" |
+    python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/8', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight']}))" >> "$out/${tag}_bench_band_alone.log"
+done
+
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench -- \
