@@ -2839,32 +2839,47 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
   // map: thread t sums a contiguous run, the runs are prefix-summed through shuffles and LDS, and the thread whose run holds
   // the k/8 point of the total walks it); a cut is a tile index in screen order, so a band is still contiguous (one XCD's L2).
   if (cuts && !reuse_cuts) {
-    // chunk c = tiles [64 c, 64 c + 64): its cost, summed by one wave from one coalesced load (the chunk sums live where the
-    // sorter's quarter octaves will: 8 bytes x 8192 chunks = the 64 KB of `octave`)
-    unsigned long long* chunk_sum = reinterpret_cast<unsigned long long*>(octave);
-    const uint32_t nc = (total + 63u) / 64u;   // <= 8192: total <= kRegions * kTileOrderMaxBand (the host checks `per`)
-    for (uint32_t c = wave; c < nc; c += 16u * 8u) {  // eight chunks' loads in flight at a time: this loop is all memory latency
-      uint32_t raw[8];
+    // chunk c = tiles [512 c, 512 c + 512) as eight rows of 64: load j of a wave is row j, one coalesced 256-byte access (a lane reading
+    // eight CONSECUTIVE tiles made every load touch 64 different sectors: 13 us of address processing per workgroup). A lane adds up its
+    // column, a wave the 64 columns (values are capped at 2^22 cycles, so a chunk fits 32 bits; the chunk sums live where the sorter's
+    // quarter octaves will)
+    uint32_t* chunk_sum = reinterpret_cast<uint32_t*>(octave);
+    constexpr uint32_t kChunk = 512u, kCap = 1u << 22;
+    const uint32_t nc = (total + kChunk - 1u) / kChunk;   // <= 1024: total <= kRegions * kTileOrderMaxBand (the host checks `per`)
+    for (uint32_t c = wave; c < nc; c += 64u) {  // four chunks' 32 loads in flight before the first reduction: this loop is memory latency and nothing else
+      uint32_t v[4], raw[4][8];
 #pragma unroll
-      for (uint32_t j = 0; j < 8; ++j) {
-        const uint32_t i = (c + 16u * j) * 64u + lane;
-        raw[j] = i < total ? max(cost[i], 1u) : 0u;  // (a tile nobody has timed yet counts as cheap)
+      for (uint32_t q = 0; q < 4; ++q) {  // clamped indices, so that no load needs a guard ...
+        const uint32_t i0 = (c + 16u * q) * kChunk + lane;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) raw[q][j] = cost[min(i0 + 64u * j, total - 1u)];
       }
 #pragma unroll
-      for (uint32_t j = 0; j < 8; ++j) {
-        unsigned long long v = raw[j];
+      for (uint32_t q = 0; q < 4; ++q)  // ... and the values pinned here, so that the compiler does not sink each load behind its use again (a wait per load: 13 us)
+        asm volatile("" ::"v"(raw[q][0]), "v"(raw[q][1]), "v"(raw[q][2]), "v"(raw[q][3]), "v"(raw[q][4]), "v"(raw[q][5]), "v"(raw[q][6]), "v"(raw[q][7]));
 #pragma unroll
-        for (uint32_t d = 32; d > 0; d >>= 1) v += (unsigned long long)__shfl_xor((long long)v, (int)d);
-        if (lane == 0 && c + 16u * j < nc) chunk_sum[c + 16u * j] = v;
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t i0 = (c + 16u * q) * kChunk + lane;
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) t += i0 + 64u * j < total ? min(max(raw[q][j], 1u), kCap) : 0u;  // (a tile nobody has timed yet counts as cheap)
+        v[q] = t;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) {
+        uint32_t t = v[q];
+#pragma unroll
+        for (uint32_t d = 32; d > 0; d >>= 1) t += (uint32_t)__shfl_xor((int)t, (int)d);
+        if (lane == 0 && c + 16u * q < nc) chunk_sum[c + 16u * q] = t;
       }
     }
     if (threadIdx.x <= kRegions) { s_cuts[threadIdx.x] = threadIdx.x == kRegions ? total : 0u; cut_chunk[threadIdx.x] = 0xFFFFFFFFu; }
     __syncthreads();
-    // thread t owns chunks [t m, t m + m): exclusive prefix over the threads' sums through shuffles and 16 wave totals
-    const uint32_t m = (nc + 1023u) / 1024u;
-    const uint32_t c0 = min(threadIdx.x * m, nc), c1 = min(c0 + m, nc);
-    unsigned long long mine = 0;
-    for (uint32_t c = c0; c < c1; ++c) mine += chunk_sum[c];
+#if defined(DUST_SORTER_STOP) && DUST_SORTER_STOP == 1
+    if (cuts) return;
+#endif
+    // thread t owns chunk t: exclusive prefix over the chunk sums through shuffles and 16 wave totals
+    const unsigned long long mine = threadIdx.x < nc ? chunk_sum[threadIdx.x] : 0u;
     unsigned long long inc = mine;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -2876,27 +2891,35 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     unsigned long long before = 0, all = 0;
     for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += wave_sum[w]; all += wave_sum[w]; }
     const unsigned long long excl = before + inc - mine;
-    for (uint32_t k = 1; k < kRegions; ++k) {  // the thread whose chunks hold the k/8 point of the total finds the chunk ...
+    for (uint32_t k = 1; k < kRegions; ++k) {  // the thread whose chunk holds the k/8 point of the total says so ...
       const unsigned long long target = all / kRegions * k;
-      if (mine != 0 && excl < target && target <= excl + mine) {
-        unsigned long long acc = excl;
-        uint32_t c = c0;
-        for (; c + 1u < c1 && acc + chunk_sum[c] < target; ++c) acc += chunk_sum[c];
-        cut_chunk[k] = c; cut_need[k] = target - acc;  // (> 0, and <= the chunk's sum unless it is the thread's last chunk)
-      }
+      if (mine != 0 && excl < target && target <= excl + mine) { cut_chunk[k] = threadIdx.x; cut_need[k] = target - excl; }
     }
     __syncthreads();
-    if (wave >= 1u && wave < kRegions && cut_chunk[wave] != 0xFFFFFFFFu) {  // ... and wave k the tile inside it: one load, one scan, one ballot
-      const uint32_t i = cut_chunk[wave] * 64u + lane;
-      unsigned long long v = i < total ? (unsigned long long)max(cost[i], 1u) : 0ull;
+    if (wave >= 1u && wave < kRegions && cut_chunk[wave] != 0xFFFFFFFFu) {  // ... and wave k finds the tile inside it: the row of 64, then the lane
+      const uint32_t i0 = cut_chunk[wave] * kChunk + lane;
+      uint32_t t8[8];
 #pragma unroll
-      for (uint32_t d = 1; d < 64; d <<= 1) {
-        const unsigned long long up = (unsigned long long)__shfl_up((long long)v, (int)d);
-        if (lane >= d) v += up;
+      for (uint32_t j = 0; j < 8; ++j) t8[j] = cost[min(i0 + 64u * j, total - 1u)];
+      asm volatile("" ::"v"(t8[0]), "v"(t8[1]), "v"(t8[2]), "v"(t8[3]), "v"(t8[4]), "v"(t8[5]), "v"(t8[6]), "v"(t8[7]));
+      unsigned long long need = cut_need[wave];
+      uint32_t cut = min(cut_chunk[wave] * kChunk + kChunk, total);  // (the chunk's last tile, should rounding leave the point behind it)
+      bool found = false;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t mine_j = i0 + 64u * j < total ? min(max(t8[j], 1u), kCap) : 0u;
+        uint32_t incl = mine_j;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, (int)d);
+          if (lane >= d) incl += up;
+        }
+        const uint32_t row = (uint32_t)__shfl((int)incl, 63);
+        const unsigned long long reached = __ballot((unsigned long long)incl >= need);
+        if (!found && reached) { cut = min(cut_chunk[wave] * kChunk + 64u * j + (uint32_t)__builtin_ctzll(reached) + 1u, total); found = true; }
+        if (!found) need -= row;
       }
-      const unsigned long long reached = __ballot(v >= cut_need[wave]);
-      const uint32_t first = reached ? (uint32_t)__builtin_ctzll(reached) : 63u;
-      if (lane == 0) s_cuts[wave] = min(cut_chunk[wave] * 64u + first + 1u, total);
+      if (lane == 0) s_cuts[wave] = cut;
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // (a band the sorter cannot stage -- frames beyond 8K with most of their cost in one corner: the equal split)
@@ -2914,6 +2937,9 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict_
     if (threadIdx.x <= kRegions) s_cuts[threadIdx.x] = min(threadIdx.x * per, total);
     __syncthreads();
   }
+#if defined(DUST_SORTER_STOP) && DUST_SORTER_STOP == 2
+  if (cuts) return;
+#endif
   const uint32_t lo = s_cuts[blockIdx.x], hi = s_cuts[blockIdx.x + 1u];
   const uint32_t n = hi - lo;
   uint32_t top = 0;
