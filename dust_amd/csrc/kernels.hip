@@ -41,6 +41,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // barrier let it go and when it ran out of tiles -- on the shader clock (s_memtime) and on the constant 100 MHz wall clock
 #ifdef DUST_WAVE_TIMES
 __device__ unsigned long long g_wave_times[8192][12];
+__device__ unsigned long long g_launch_clock[256][3];  // per launch (frame_index & 255): wave 0's shader ticks, wall ticks (10 ns), frame index
 #endif
 #ifdef DUST_PROFILE
 constexpr int kProfBuckets = 24;
@@ -1804,6 +1805,10 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
       g_wave_times[w][0] = wt0; g_wave_times[w][1] = wt1; g_wave_times[w][2] = __builtin_amdgcn_s_memtime();
       g_wave_times[w][3] = ww0; g_wave_times[w][4] = wall_clock64(); g_wave_times[w][5] = wt_tiles;
       g_wave_times[w][6] = wt_last_tile; g_wave_times[w][7] = wt_last_start; g_wave_times[w][8] = wt_prev_tile; g_wave_times[w][9] = wt_prev_start;
+      if (w == 0u) {
+        const uint32_t slot = a0.frame_index & 255u;
+        g_launch_clock[slot][0] = g_wave_times[w][2] - wt0; g_launch_clock[slot][1] = g_wave_times[w][4] - ww0; g_launch_clock[slot][2] = a0.frame_index;
+      }
     }
   }
 #endif
@@ -3167,6 +3172,9 @@ extern "C" int dust_hip_pool_stats(unsigned long long* out) {
 }
 #endif
 #ifdef DUST_WAVE_TIMES
+extern "C" int dust_hip_launch_clocks(unsigned long long* out) {  // 256 x 3
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dust::g_launch_clock), sizeof(unsigned long long) * 256 * 3) == hipSuccess ? 0 : -1;
+}
 extern "C" int dust_hip_wave_times(unsigned long long* out) {  // 8192 x 6, of the last fused launch
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dust::g_wave_times), sizeof(unsigned long long) * 8192 * 12) == hipSuccess ? 0 : -1;
 }

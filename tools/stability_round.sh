@@ -1,0 +1,27 @@
+#!/bin/bash
+# One GPU-box pass of the randomised sweeps on the round's final kernels -> gpurun_out/<tag>_stability.log (copied to profiles/).
+#   gpurun --timeout 2400 -- "HEAD_STAMP=$(git rev-parse --short HEAD) bash tools/stability_round.sh r04"
+tag=${1:-r04}
+cd "$(dirname "$0")/.." || exit 1
+out=gpurun_out/${tag}_stability.log
+mkdir -p gpurun_out
+{
+  echo "# HEAD ${HEAD_STAMP:-unknown}: randomised GPU-vs-oracle sweeps (tools/stress_*.py), native backtrace preload"
+  export LD_PRELOAD=$PWD/tools/diag/libsegv_bt.so
+  run() { local t0=$SECONDS; "$@" > gpurun_out/_stab.tmp 2>&1; local rc=$?; echo "rc $rc ${SECONDS}s+$((SECONDS - t0)): $* :: $(tail -1 gpurun_out/_stab.tmp | cut -c1-160)"; }
+  run timeout 900 python3 tools/stress_parity.py 4000 41000
+  STRESS_SWITCHES=1 run timeout 900 python3 tools/stress_parity.py 4000 45000
+  STRESS_BIG=1 run timeout 900 python3 tools/stress_parity.py 600 49000
+  STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 150 49600
+  STRESS_FULL=1 run timeout 900 python3 tools/stress_parity.py 200 49800
+  STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 1500 50000
+  run timeout 900 python3 tools/stress_sharded.py 300 51500
+  run timeout 900 python3 tools/stress_host.py bands 300 52000
+  run timeout 900 python3 tools/stress_host.py commits 300 52300
+  run timeout 900 python3 tools/stress_host.py threads 20 52600
+  run timeout 900 python3 tools/stress_host.py schedule 40 52700
+  run timeout 600 python3 tools/stress_edits.py
+  run timeout 600 python3 tools/stress_denoise.py
+  run timeout 600 python3 tools/stress_tonemap.py
+} > "$out" 2>&1
+cat "$out"

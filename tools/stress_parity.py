@@ -20,11 +20,16 @@ from dust_amd import _lib as L, api, synth  # noqa: E402
 def random_switches(rng):
     """a random combination of the library's diagnostic switches (read when a pipeline is created) and a context of its own with a
     random LDS budget for staged roots"""
-    for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES"):
+    for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES",
+                 "EQUAL_BANDS", "NO_DILATE", "NO_WIDE_FUSED", "FORCE_MOVING", "DILATE_STILL"):   # (round 4: the hand-out's new knobs)
         os.environ.pop("DUST_HIP_" + name, None)
         if rng.random() < 0.3:
             os.environ["DUST_HIP_" + name] = "1"
-    os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([64, 128, 256, 512])))
+    os.environ.pop("DUST_HIP_BLOCK", None)
+    if rng.random() < 0.6:   # (unset: the fused kernel may take the 1024-thread shape)
+        os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([128, 256, 512])))
+    os.environ["DUST_HIP_COST_KEEP_SHIFT"] = str(int(rng.choice([0, 1, 3])))
+    os.environ["DUST_HIP_MOVING_REFRESH"] = str(int(rng.choice([1, 2, 4])))
     os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
     return api.Context(device=0, lds_root_bytes=int(rng.choice([0, 640, 1280, 64 * 1024])))
 
