@@ -86,6 +86,7 @@ def parse(argv=None):
     ap.add_argument("--no-extra-curves", action="store_true",
                     help="one GPU, default workload: skip curves.moving / gi_1080p / primary_ao_4k / deep (short runs after the headline's timed region)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra curve")
+    ap.add_argument("--extra-timeout", type=float, default=150.0, help="seconds the extra curves may take before the line is printed without them")
     ap.add_argument("--assets", default=None,
                     help="directory with the reference's LFS assets (castle.vox, teapot.vox, stbn_scalar_*.png, stbn_unitvec3_cosine_*.png): a file "
                          "whose sha256 is the oid in /root/reference/assets/* replaces its stand-in, and config.workload says so (SURVEY 8d)")
@@ -748,15 +749,6 @@ def run_rank(args, be, dist):
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(args, sc, noise5, be.synth)
-    extras = {}
-    if world == 1 and args.workload == "primary_ao" and hasattr(be, "assets"):
-        if args.camera == "orbit":
-            extras["moving"] = measure_moving(be, args, lanes[0], noise5, args.steps)
-        elif not args.no_extra_curves and (W, H) == (1920, 1080) and args.scale == 1.0:
-            extras = extra_curves(args, be, noise0, noise5, lanes[0])
-        if "moving" in extras and "value" in extras["moving"]:
-            extras["moving"]["vs_still"] = round(extras["moving"]["value"] / max(main_curve["mrays"], 1e-9), 4)
-
     what = {"primary_ao": "1spp primary+shadow+AO", "gi": "1 GI frame: primary+shadow+AO+final gather+surfel",
             "deep": "1 GI frame: primary+shadow+AO+final gather+surfel"}[args.workload]
     scene_name = (f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy (synth.procedural_deep_blocks seed 0xC5)" if deep else
@@ -799,7 +791,28 @@ def run_rank(args, be, dist):
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
-    out["curves"].update(extras)   # moving / primary_ao_4k / gi_1080p / deep: their own timed regions AFTER the headline's, never part of `value`
+    # The extra curves: their own timed regions AFTER the headline's, never part of `value`. The headline line is complete at this
+    # point; should an extra curve hang, a watchdog prints it as it stands and ends the process (a line without the extras beats no line).
+    extras = {}
+    if world == 1 and args.workload == "primary_ao" and hasattr(be, "assets"):
+        finished, said = threading.Event(), threading.Lock()
+
+        def watchdog():
+            if not finished.wait(args.extra_timeout) and said.acquire(blocking=False):
+                out["curves"]["extra_curves_error"] = f"not finished after {args.extra_timeout:.0f} s: line printed without them"
+                print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        if args.camera == "orbit":
+            extras["moving"] = measure_moving(be, args, lanes[0], noise5, args.steps)
+        elif not args.no_extra_curves and (W, H) == (1920, 1080) and args.scale == 1.0:
+            extras = extra_curves(args, be, noise0, noise5, lanes[0])
+        finished.set()
+        if not said.acquire(blocking=False):   # the watchdog is printing: let it
+            time.sleep(3600)
+        if "moving" in extras and "value" in extras["moving"]:
+            extras["moving"]["vs_still"] = round(extras["moving"]["value"] / max(main_curve["mrays"], 1e-9), 4)
+    out["curves"].update(extras)   # moving / primary_ao_4k / gi_1080p / deep
     if hasattr(be, "assets"):
         out["config"]["assets"] = be.assets.summary()
     if args.camera == "orbit" and "moving" in extras:   # --camera orbit: the moving view IS the line; the still view stays in curves.strong
