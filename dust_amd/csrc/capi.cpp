@@ -28,6 +28,7 @@ hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, boo
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t);
+hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t);
 uint32_t final_gather_pool_group();
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
@@ -351,6 +352,8 @@ struct Tuning {
   uint32_t static_rounds = 0xFFFFFFFFu;  // DUST_HIP_STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
   uint32_t still_refresh_max = 64;  // DUST_HIP_STILL_REFRESH_MAX: cap of the launches between two re-measurements of a view that stands still
   uint32_t cost_keep_shift = 1; // DUST_HIP_COST_KEEP_SHIFT k: a tile's cost estimate moves 1 / 2^k of the way to each new measurement (0: takes it as it is)
+  bool gather_join_first = false;  // DUST_HIP_GATHER_JOIN_FIRST: split gather, but the trace too waits for the surfel pass (experiment)
+  bool gather_split = false;    // DUST_HIP_GATHER_SPLIT: the final gather as a trace kernel + a shading pass over hit records (measured slower, see render_frame)
   bool wide_fused = true;       // DUST_HIP_NO_WIDE_FUSED: the fused kernel always as two 512-thread workgroups per CU
   bool dilate_still = false;    // DUST_HIP_DILATE_STILL: ... of a still view as well (experiment)
   bool dilate = true;           // DUST_HIP_NO_DILATE: a moving view's order from the tiles' own costs only
@@ -388,6 +391,8 @@ struct Tuning {
     t.moving_refresh = std::max(1u, num("DUST_HIP_MOVING_REFRESH", 4));
     t.cost_keep_shift = std::min(4u, num("DUST_HIP_COST_KEEP_SHIFT", 1));
     t.dilate = std::getenv("DUST_HIP_NO_DILATE") == nullptr;
+    t.gather_join_first = std::getenv("DUST_HIP_GATHER_JOIN_FIRST") != nullptr;
+    t.gather_split = std::getenv("DUST_HIP_GATHER_SPLIT") != nullptr;
     t.wide_fused = std::getenv("DUST_HIP_NO_WIDE_FUSED") == nullptr && std::getenv("DUST_HIP_BLOCK") == nullptr;
     t.dilate_still = std::getenv("DUST_HIP_DILATE_STILL") != nullptr;
     t.force_moving = std::getenv("DUST_HIP_FORCE_MOVING") != nullptr;
@@ -429,6 +434,7 @@ struct DustHipPipeline {
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
   DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
+  DeviceBuffer gi_fg_hits;  // per pixel: the hit record of its gather ray (k_final_gather -> k_final_gather_shade)
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 64x64 tile grouped by ray direction bin
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
@@ -1668,12 +1674,34 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
-    HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
+    // DUST_HIP_GATHER_SPLIT (opt-in, round 4): trace, then shade. The gather RAYS touch no GI state: traced by a kernel of their own
+    // (hit records in gi_fg_hits) they can run beside the previous frame's surfel pass like the primary / AO kernel before them, on the
+    // same share of the slots; only the shading -- hash lookups and stamps, surfel enqueues, the radiance texels -- waits for that pass
+    // (join_side), as a full-occupancy pass over the records in pixel order. Built as the round-3 review proposed, and measured: the
+    // trace-only kernel is 0.190 ms against 0.233 fused, but the shading pass exposes the hash's random HBM traffic that the fused
+    // kernel hides under tracing (GI frame 0.747 ms with the join first, 0.84 beside the surfel pass at its usual share, 0.719 with the
+    // share cut to 22 %, against 0.730 fused): not the default.
+    const bool split = !pool && tune.gather_split;
+    if (split) {
+      const size_t need = size_t(p->width) * p->height * sizeof(dust::DevGatherHit);
+      if (p->gi_fg_hits.bytes < need) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(p->gi_fg_hits.alloc(need)); }
+      g.gi.fg_hits = static_cast<dust::DevGatherHit*>(p->gi_fg_hits.p);
+      if (tune.gather_join_first) HIP_TRY(join_side(ctx));
+      if (ctx->side_busy) ggrid = std::max(8u, std::min<uint32_t>(frame_slots, ggrid));  // (the pass beside it keeps its share)
+    } else {
+      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
+    }
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
-    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the join and the regrouping pre-pass: the gather kernel + commit)
-    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, pool, st));
+    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the regrouping pre-pass: the gather kernel)
+    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded && !split, pool, st));
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
+    if (split) {
+      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool the shading reads
+      dust::FrameArgs sh = a;   // (pixel order over the band: no regrouping, no work counters)
+      sh.gi.fg_hits = g.gi.fg_hits;
+      HIP_TRY(dust::launch_final_gather_shade(sh, !sharded, st));
+    }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
     // On the context's second stream, behind this frame's final gather (see DustHipContext::side): the pass is a handful of

@@ -126,6 +126,7 @@ struct DevHashRequest {  // one SpatialHashInsert call recorded by the surfel pa
   float vx, vy, vz;
   uint32_t pad;
 };
+struct DevGatherHit { float t; uint32_t inst, block, found; };  // what a gather ray found: the hit record the shading kernel takes up
 struct DevGI {
   uint32_t* hash;           // (capacity + 2) x 3 words
   uint32_t hash_capacity;
@@ -146,6 +147,8 @@ struct DevGI {
   uint32_t order_tiles_x;   // 32x32 tiles per row
   uint32_t* touched;        // multi-GPU: per pixel, 1 + index of the hash entry its final gather stamped (null otherwise)
   DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
+  DevGatherHit* fg_hits;    // per pixel: k_final_gather only TRACES and leaves its hits here, k_final_gather_shade does the hash lookups and
+                            // stores afterwards (null: the gather kernel shades its own rays)
 };
 
 struct FrameArgs {

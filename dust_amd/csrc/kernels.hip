@@ -2153,7 +2153,16 @@ __device__ __forceinline__ void gather_packet(ArgsRef a0, uint32_t px, uint32_t 
   const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
   trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
-  if (live) gather_shade(reload_args(a0), px, py, inval, loc, ad, h);
+  ArgsRef b = reload_args(a0);
+  if (b.gi.fg_hits) {  // tracing only: the ray touches no GI state, so this kernel may run while the previous frame's surfel pass still writes it
+    if (live) {
+      u32x4 rec;
+      rec.x = __float_as_uint(h.t); rec.y = h.inst; rec.z = h.block; rec.w = h.found ? 1u : 0u;
+      *reinterpret_cast<u32x4*>(&b.gi.fg_hits[(size_t)py * b.width + px]) = rec;
+    }
+  } else if (live) {
+    gather_shade(b, px, py, inval, loc, ad, h);
+  }
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24, a packet at a time
@@ -2180,6 +2189,27 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
   }
   prof_end();
   flush_stats<MODE>(a0, 0, st);
+}
+
+// final_gather.rchit:35-91 / final_gather.rmiss:12-24 as a pass of its own over the hit records k_final_gather left (DevGI::fg_hits): a
+// pixel per thread in pixel order -- the radiance texels and the per-pixel surfels go out as whole lines instead of 8- and 16-byte pieces
+// scattered by the regrouping --, at full occupancy (the hash probe is a dependent chain instance -> block -> 36 random bytes of a 384 MB
+// table: latency that many resident waves hide and four persistent ones per SIMD did not). It is also what lets the TRACE run beside the
+// previous frame's surfel pass: only this kernel reads and stamps the hash. A pixel is live exactly when the trace found it live
+// (gather_ray reads the same G-buffer texels: nothing has written them in between).
+__global__ void __launch_bounds__(256) k_final_gather_shade(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t rows = a.row_end - a.row_begin;
+  const size_t n = (size_t)rows * a.width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t py = a.row_begin + (uint32_t)(i / a.width), px = (uint32_t)(i % a.width);
+    V3 inval, loc, ad;
+    if (!gather_ray(a, px, py, true, inval, loc, ad)) continue;
+    const u32x4 rec = *reinterpret_cast<const u32x4*>(&a.gi.fg_hits[(size_t)py * a.width + px]);
+    Hit h;
+    h.t = __uint_as_float(rec.x); h.inst = rec.y; h.block = rec.z; h.voxel = 0; h.found = rec.w != 0u;
+    gather_shade(a, px, py, inval, loc, ad, h);
+  }
 }
 
 // The same pass over ray lanes (trace_pool): a work item is kPoolGroup consecutive entries of a tile's direction-ordered list --
@@ -3114,6 +3144,11 @@ hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t bl
   if (pool) DUST_LAUNCH_MODE(k_final_gather_pool, count, a_in);
   else DUST_LAUNCH_MODE(k_final_gather, count, a_in);
   if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a_in);
+  return hipGetLastError();
+}
+hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_gather_shade, dim3(4096), dim3(256), 0, s, a);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {

@@ -324,3 +324,34 @@ def test_clustered_apply_equals_serial_apply(monkeypatch):
         assert (states[0][0][:, 0] != 0).sum() > 100
         for x, y in zip(*states):
             assert np.array_equal(x, y), capacity
+
+
+def test_split_gather_equals_the_fused_one(monkeypatch):
+    """DUST_HIP_GATHER_SPLIT: the final gather as a trace-only kernel (hit records) + a shading pass in pixel order -- what the gather
+    rays find and what the shading does with it are the same operations, so every plane, the hash and the pool are bit-identical."""
+    desc = P.small_scene(seed=12, n_models=3, n_instances=6, size=(28, 28, 28))
+    sky, cam = P.sky_state(), P.camera_for((80.0, 60.0, 90.0))
+    w, h = 136, 72
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    outs = []
+    for env in (None, "DUST_HIP_GATHER_SPLIT", "DUST_HIP_GATHER_JOIN_FIRST"):
+        if env:
+            monkeypatch.setenv("DUST_HIP_GATHER_SPLIT", "1")
+            monkeypatch.setenv(env, "1")
+        ctx = api.Context(device=0)
+        scene = P.hip_scene(ctx, desc)
+        pipe = api.StandardPipeline(ctx, w, h)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(4099, 512)
+        for f in range(1, 6):
+            pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(2, f))
+        outs.append((P.read_hip_gbuffer(pipe), pipe.read_gi()))
+        monkeypatch.delenv("DUST_HIP_GATHER_SPLIT", raising=False)
+        monkeypatch.delenv("DUST_HIP_GATHER_JOIN_FIRST", raising=False)
+    for g, (hh, sp) in outs[1:]:
+        for k in outs[0][0]:
+            assert outs[0][0][k].tobytes() == g[k].tobytes(), k
+        assert np.array_equal(outs[0][1][0], hh) and outs[0][1][1].tobytes() == sp.tobytes()
+    assert int((outs[0][1][0][:, 0] != 0).sum()) > 20

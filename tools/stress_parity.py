@@ -21,7 +21,7 @@ def random_switches(rng):
     """a random combination of the library's diagnostic switches (read when a pipeline is created) and a context of its own with a
     random LDS budget for staged roots"""
     for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES",
-                 "EQUAL_BANDS", "NO_DILATE", "NO_WIDE_FUSED", "FORCE_MOVING", "DILATE_STILL"):   # (round 4: the hand-out's new knobs)
+                 "EQUAL_BANDS", "NO_DILATE", "NO_WIDE_FUSED", "FORCE_MOVING", "DILATE_STILL", "GATHER_SPLIT", "GATHER_JOIN_FIRST"):   # (round 4: the hand-out's new knobs)
         os.environ.pop("DUST_HIP_" + name, None)
         if rng.random() < 0.3:
             os.environ["DUST_HIP_" + name] = "1"
