@@ -85,6 +85,14 @@ enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
 enum { P_L_TRIPS = 16, P_L_BRICK, P_L_EMPTY4, P_L_EMPTY16, P_SETUP = 20, P_PRIMARY_SHADE = 21, P_AO_SETUP = 22, P_CAND = 23 };  // lane-level trip outcomes  // the P_N_* buckets count events, not cycles
 
+#ifdef DUST_DYNAMIC_PRIO
+#ifndef DUST_DYN_T1
+#define DUST_DYN_T1 100000u
+#define DUST_DYN_T2 180000u
+#define DUST_DYN_T3 280000u
+#endif
+__shared__ uint32_t g_tile_start[16], g_tile_prio[16];  // per wave: when its tile began (shader clock), the priority its position in the order gave it
+#endif
 namespace {
 
 // launch descriptor, models and instances live in the constant address space (see dust_dev.h)
@@ -702,6 +710,20 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
     PROF_COUNT(P_N_STEPS, 1);
+#ifdef DUST_DYNAMIC_PRIO
+    // A tile that turns out to be a long one earns its priority as it goes (a moving view's order is a few frames old, and the
+    // priorities it hands out with it): every 16th trip of a visit the wave looks at how long its tile has been running.
+    if ((guard & 15) == 15) {
+      const uint32_t w = threadIdx.x >> 6;
+      const uint32_t el = (uint32_t)__builtin_amdgcn_s_memtime() - g_tile_start[w];
+      const uint32_t earned = el > DUST_DYN_T3 ? 3u : (el > DUST_DYN_T2 ? 2u : (el > DUST_DYN_T1 ? 1u : 0u));
+      const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_tile_prio[w]);
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)earned) > have) {
+        if (earned == 3u) __builtin_amdgcn_s_setprio(3); else if (earned == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) g_tile_prio[w] = earned;
+      }
+    }
+#endif
     {
       const float limit = best.found ? best.t : tmax;
       if (t * (1.0f - 2e-6f) > limit) return;
@@ -1428,8 +1450,15 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
+#ifdef DUST_DYNAMIC_PRIO
+    if (lane == 0) g_tile_prio[threadIdx.x >> 6] = prio;
+#endif
     tile = a.tile_order[ticket];  // ticket -> tile, most expensive tiles of the band first
   }
+#ifdef DUST_DYNAMIC_PRIO
+  else { __builtin_amdgcn_s_setprio(0); if (lane == 0) g_tile_prio[threadIdx.x >> 6] = a.prio_floor; }
+  if (lane == 0) g_tile_start[threadIdx.x >> 6] = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
   account_tile(a, tile);
   // tile / tiles_x: through the multiplier where that is exact (with_schedule); a one-row list of work items has quotient 0
   const uint32_t ty = a.tiles_x_magic ? __umulhi(tile, a.tiles_x_magic) : (a.tiles_y > 1u ? tile / a.tiles_x : 0u), tx = tile - ty * a.tiles_x;
