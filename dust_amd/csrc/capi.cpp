@@ -825,7 +825,7 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024;
+  c->max_lds = (prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024) - 256;  // dynamic LDS a launch may ask for: the kernels hold 128 bytes of static LDS (earned priorities)
   if (const char* env = std::getenv("DUST_HIP_LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));
   // what a 512-thread workgroup needs besides the staged roots: 8 candidate lists, the tile queue, and the static
   // buckets of the profiling / debug builds (kernels.hip lds_bytes(), configure_kernels())

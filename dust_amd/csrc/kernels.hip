@@ -85,14 +85,17 @@ enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
 enum { P_L_TRIPS = 16, P_L_BRICK, P_L_EMPTY4, P_L_EMPTY16, P_SETUP = 20, P_PRIMARY_SHADE = 21, P_AO_SETUP = 22, P_CAND = 23 };  // lane-level trip outcomes  // the P_N_* buckets count events, not cycles
 
-#ifdef DUST_DYNAMIC_PRIO
+// Earned priorities (round 4): per wave, when its tile began (shader clock) and the issue priority it runs at. A tile's position in the
+// cost order gives it a priority to start with (packet_of_tile); a tile that turns out longer than that promised -- a view that moves
+// hands out a few frames old order, a first frame has none -- earns the priority as it goes: the walk looks at the clock every 16th
+// trip of a visit. 60 k / 120 k / 200 k cycles (the median tile is 49 k, the heaviest 467 k): -0.8 % on the still castle, -2 % on the
+// moving one, -2 % on the deep tree; 100/180/280 k, 40/80/140 k and 30/60/100 k measured the same.
 #ifndef DUST_DYN_T1
-#define DUST_DYN_T1 100000u
-#define DUST_DYN_T2 180000u
-#define DUST_DYN_T3 280000u
+#define DUST_DYN_T1 60000u
+#define DUST_DYN_T2 120000u
+#define DUST_DYN_T3 200000u
 #endif
-__shared__ uint32_t g_tile_start[16], g_tile_prio[16];  // per wave: when its tile began (shader clock), the priority its position in the order gave it
-#endif
+__shared__ uint32_t g_tile_start[16], g_tile_prio[16];
 namespace {
 
 // launch descriptor, models and instances live in the constant address space (see dust_dev.h)
@@ -710,10 +713,9 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   PROF_LEAVE(P_CAND);
   for (int guard = 0; guard < 200000; ++guard) {
     PROF_COUNT(P_N_STEPS, 1);
-#ifdef DUST_DYNAMIC_PRIO
-    // A tile that turns out to be a long one earns its priority as it goes (a moving view's order is a few frames old, and the
-    // priorities it hands out with it): every 16th trip of a visit the wave looks at how long its tile has been running.
-    if ((guard & 15) == 15) {
+    // a tile that turns out to be a long one earns its priority as it goes (g_tile_start above); the camera, sun and AO rays only:
+    // the GI kernels measured no gain
+    if (RT <= 1 && (guard & 15) == 15) {
       const uint32_t w = threadIdx.x >> 6;
       const uint32_t el = (uint32_t)__builtin_amdgcn_s_memtime() - g_tile_start[w];
       const uint32_t earned = el > DUST_DYN_T3 ? 3u : (el > DUST_DYN_T2 ? 2u : (el > DUST_DYN_T1 ? 1u : 0u));
@@ -723,7 +725,6 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
         if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) g_tile_prio[w] = earned;
       }
     }
-#endif
     {
       const float limit = best.found ? best.t : tmax;
       if (t * (1.0f - 2e-6f) > limit) return;
@@ -1450,15 +1451,11 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
-#ifdef DUST_DYNAMIC_PRIO
     if (lane == 0) g_tile_prio[threadIdx.x >> 6] = prio;
-#endif
     tile = a.tile_order[ticket];  // ticket -> tile, most expensive tiles of the band first
   }
-#ifdef DUST_DYNAMIC_PRIO
-  else { __builtin_amdgcn_s_setprio(0); if (lane == 0) g_tile_prio[threadIdx.x >> 6] = a.prio_floor; }
+  else if (lane == 0) g_tile_prio[threadIdx.x >> 6] = 0u;  // (no order yet: every tile starts at 0 and earns what it needs)
   if (lane == 0) g_tile_start[threadIdx.x >> 6] = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
   account_tile(a, tile);
   // tile / tiles_x: through the multiplier where that is exact (with_schedule); a one-row list of work items has quotient 0
   const uint32_t ty = a.tiles_x_magic ? __umulhi(tile, a.tiles_x_magic) : (a.tiles_y > 1u ? tile / a.tiles_x : 0u), tx = tile - ty * a.tiles_x;
