@@ -15,6 +15,7 @@ mkdir -p gpurun_out
   STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 150 49600
   STRESS_FULL=1 run timeout 900 python3 tools/stress_parity.py 200 49800
   STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 1500 50000
+  STRESS_FULLGI=1 run timeout 1200 python3 tools/stress_parity.py 12 53000
   run timeout 900 python3 tools/stress_sharded.py 300 51500
   run timeout 900 python3 tools/stress_host.py bands 300 52000
   run timeout 900 python3 tools/stress_host.py commits 300 52300

@@ -4,7 +4,8 @@ Many small random scenes -- overlapping instances on aligned and half-voxel-shif
 cameras inside and outside, axis-parallel views -- through all five passes for a few frames each; integer planes, hit
 distances and GI state must match the oracle bit for bit, radiance within 1e-3.
 usage: stress_parity.py [n_scenes] [first_seed] [position of first_seed in the sweep to reproduce]      STRESS_BIG=1: larger scenes; STRESS_FULL=1: one 256^3 model filled to its faces; STRESS_MANY=1: 90-160 models, 150-900 instances; STRESS_SWITCHES=1: a random combination of the
-library's diagnostic switches per scene; STRESS_DEEP=1: 4096^3 models (run_deep)"""
+library's diagnostic switches per scene; STRESS_DEEP=1: 4096^3 models (run_deep); STRESS_FULLGI=1: the castle stand-in with GI at the reference's
+sizes (run_fullgi: seconds per scene)"""
 import os
 import sys
 import time
@@ -232,11 +233,71 @@ def run_deep(n_scenes, seed0, verbose=True, k0=0):
     return failed
 
 
+def run_fullgi(n_scenes, seed0, verbose=True):
+    """STRESS_FULLGI=1: GI at (nearly) the reference's sizes -- the castle stand-in at a random scale and camera, frames of up to 1920 x 1080,
+    the 32 Mi-entry hash or a smaller prime-sized one, the 345 600-slot pool or a smaller one, two or three frames, the oracle's pixel
+    passes threaded over rows and its GI passes over bands / surfel ranges (orc_pass_*_mt). Seconds per scene."""
+    import threading
+    ctx = api.Context(device=0)
+    sky = P.sky_state()
+    n0, n5 = synth.stbn_scalar(layers=8), synth.stbn_unitvec3_cosine(layers=8)
+    failed = []
+    for k in range(n_scenes):
+        seed = seed0 + k
+        rng = np.random.default_rng(seed)
+        scale = float(rng.choice([0.25, 0.5, 1.0]))
+        data, _ = synth.castle_scene(seed=0xD057 + (seed % 3), scale=scale)
+        desc = P.SceneDesc.from_vox(data)
+        scene, oscene = P.hip_scene(ctx, desc), P.oracle_scene(desc)
+        w, h = [(1920, 1080), (1280, 720), (960, 536), (1000, 600)][int(rng.integers(0, 4))]
+        cap = int(rng.choice([32 * 1024 * 1024, 4194301, 262139]))
+        pool = int(rng.choice([720 * 480, 86400, 20011]))
+        th = float(rng.uniform(0, 2 * np.pi))
+        eye = (133.6 * scale * np.cos(th), float(rng.uniform(120, 320)) * scale, 133.6 * scale * np.sin(th))
+        cam = P.camera_for(eye)
+        pipe = api.StandardPipeline(ctx, w, h)
+        pipe.set_noise(0, n0)
+        pipe.set_noise(5, n5)
+        pipe.configure_gi(cap, pool)
+        gi, g = O.GI(cap, pool), O.GBuffer(w, h)
+        threads = max(1, min(os.cpu_count() or 1, h // 4))
+        cuts = [h * i // threads for i in range(threads + 1)]
+        pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+        f = 0
+        try:
+            for f in range(1, int(rng.integers(3, 5))):
+                rnd = synth.frame_rand(seed, f)
+                pipe.render(scene, cam, sky, pix | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED, frame_index=f, rand=rnd)
+                ts = [threading.Thread(target=P.render_oracle, args=(oscene, cam, sky, w, h, pix, n5[f % 8], rnd),
+                                       kwargs={"rows": (cuts[i], cuts[i + 1]), "g": g}) for i in range(threads)]
+                [t.start() for t in ts]
+                [t.join() for t in ts]
+                P.render_oracle(oscene, cam, sky, w, h, L.PASS_FINAL_GATHER | L.PASS_SURFEL, n5[f % 8], rnd, noise0=n0[f % 8], gi=gi, frame_index=f,
+                                g=g, gi_threads=threads)
+                res = P.compare_gbuffers(g, P.read_hip_gbuffer(pipe))
+                P.assert_parity(res)
+                assert res.get("illuminance_rel_l2", 0.0) <= 1e-3, res
+                oh, op = gi.hash(), gi.pool()
+                hh, hp = pipe.read_gi()
+                assert np.array_equal(oh["fingerprint"], hh[:, 0]), "hash fingerprints"
+                assert np.array_equal(oh["sample_count"], hh[:, 2] >> 16) and np.array_equal(oh["last_accessed_frame"], hh[:, 2] & 0xFFFF), "hash counts / stamps"
+                assert np.array_equal(op["direction"], hp["direction"]), "surfel pool"
+        except AssertionError as e:
+            failed.append(seed)
+            if verbose:
+                print(f"full-GI seed {seed}: MISMATCH frame {f} ({w}x{h}, scale {scale}, hash {cap}, pool {pool}): {str(e)[:300]}", flush=True)
+        del pipe, gi, g
+    return failed
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0 = time.time()
     k0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    bad = run_deep(n, first, k0=k0) if os.environ.get("STRESS_DEEP") == "1" else run(n, first, big=os.environ.get("STRESS_BIG") == "1", k0=k0)
+    if os.environ.get("STRESS_FULLGI") == "1":
+        bad = run_fullgi(n, first)
+    else:
+        bad = run_deep(n, first, k0=k0) if os.environ.get("STRESS_DEEP") == "1" else run(n, first, big=os.environ.get("STRESS_BIG") == "1", k0=k0)
     print(f"{n} scenes, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
