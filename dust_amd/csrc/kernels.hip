@@ -1724,6 +1724,12 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   Hit h;
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
+#ifdef DUST_SKIP_SUN   // (never shipped: timing builds that leave a ray kind out -- make VARIANT=nosun EXTRA=-DDUST_SKIP_SUN, tools/diag/kinds.py)
+    if (k == 0) continue;
+#endif
+#ifdef DUST_SKIP_AO
+    if (k == 1) { h.found = false; h.t = 0.0f; continue; }
+#endif
     ArgsRef b = reload_args(a);
     const bool act = k == 0 ? sun_live : live;
     const V3 dir = k == 0 ? sd : ad;
