@@ -173,8 +173,7 @@ DustStatus run_local_gi(LocalGroup& g, hipStream_t st) {
     DUST_TRY(dust_hip_pipeline_gi_exchange(g.calls[r].pipe, W * c0.band_rows, &ex[r]));
     if (ex[r].pool_size != ex[0].pool_size || ex[r].width != ex[0].width) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' GI buffers differ in size");
   }
-  // the pointer tables the reduction kernels read: a small pinned staging buffer would do; hipMemcpyAsync from pageable memory
-  // copies through the runtime's own staging before it returns, so a stack array is safe here
+  // the pointer tables the reduction kernels read (uploaded from `host`, which the wait below keeps alive until the copy is done)
   void** table = nullptr;
   HIP_TRY(hipMalloc(&table, sizeof(void*) * W * 2));
   std::vector<void*> host(W * 2);
