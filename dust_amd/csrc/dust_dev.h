@@ -92,10 +92,27 @@ struct DevVisit {  // what a ray needs to test and enter an instance, in one rec
   DevModel m;
 };
 
-struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, pad, hi.xyz, pad}
-  float lo[3], pad0;
-  float hi[3], pad1;
+struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, cells_lo, hi.xyz, cells_hi}
+  float lo[3], pad0;   // pad0 / pad1 (as bit patterns): the block of top-level grid cells the box is listed in, low and high corner,
+  float hi[3], pad1;   // x | y << 8 | z << 16 (DevGrid); the packet cull ignores them
 };
+
+// The top-level structure over the instances (what the reference hands to the driver as a TLAS, accel_struct/tlas.rs:37-117):
+// a uniform grid over the union of the instances' world boxes; a cell lists the instances whose (slightly grown) box overlaps it.
+// Built on the host by dust_hip_scene_commit, part of the scene image. The per-ray walks of the incoherent passes (gi.hip,
+// k_ray_stream) step through it front to back; up to 256 cells per axis.
+struct DevGrid {
+  DUST_RO(uint32_t) cells;   // dim[0] * dim[1] * dim[2] + 1 offsets into `items`; cell (x, y, z) is entry (z * dim[1] + y) * dim[0] + x
+  DUST_RO(uint16_t) items;   // instance ids, cell after cell, ascending inside a cell
+  float lo[3], hi[3];        // the grid's world box (hi = lo + dim * cell)
+  float cell[3], inv_cell[3];
+  uint32_t dim[3];
+  uint32_t pad;
+};
+
+// One ray of a ray stream (gi.hip): 32 bytes, written by a ray-making kernel, traced by k_ray_stream, whose hit record goes to
+// ray_hits[id]. flags bit 0: any-hit (terminate on first hit: the surfel pass's sun rays)
+struct DevRay { float ox, oy, oz; uint32_t id; float dx, dy, dz; uint32_t flags; };
 
 struct DevCamera {
   float col0[3], col1[3], col2[3], pos[3];
@@ -149,6 +166,12 @@ struct DevGI {
   DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
   DevGatherHit* fg_hits;    // per pixel: k_final_gather only TRACES and leaves its hits here, k_final_gather_shade does the hash lookups and
                             // stores afterwards (null: the gather kernel shades its own rays)
+  // ray streams (k_gather_rays / k_surfel_rays -> k_ray_stream -> k_final_gather_shade / k_surfel_shade)
+  DevRay* rays;             // the pass's rays, compacted (live rays only), neighbours in the frame / the pool next to each other
+  uint32_t* ray_count;      // how many: counted by the ray-making kernel, read by k_ray_stream
+  uint32_t* next_ray_count; // the counter the NEXT launch of this pass kind uses: the ray-making kernel zeroes it
+  DevGatherHit* ray_hits;   // [ray id]: pixel index for gather rays (== fg_hits), 2 * surfel + kind for surfel rays
+  float ray_tmin, ray_tmax; // gl_RayTminEXT / gl_RayTmaxEXT of the pass (final_gather.rgen:47, surfel.rgen:33-62)
 };
 
 struct FrameArgs {
@@ -191,6 +214,7 @@ struct FrameArgs {
   uint32_t accum_count;       // frames already in `accum`
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
+  DevGrid grid;               // top-level structure over the instances (per-ray walks of the GI passes)
   uint32_t deep;              // the scene holds a 4096^3 model with its per-cell table: launch the DEEP kernel variants
   uint32_t prio_floor;        // lowest issue priority this launch's waves run at (the surfel pass on the second stream, beside the next frame's kernels: 3)
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in

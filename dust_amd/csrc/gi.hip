@@ -1,0 +1,725 @@
+// gi.hip -- CDNA4 (gfx950) kernels of the hash-fed global illumination passes: final gather (final_gather.rgen/.rchit/.rmiss,
+// rough.rint) and surfel pass (surfel/*.rgen/.rchit/.rmiss, spatial_hash.glsl). Traversal and hash code: traverse.hpp.
+#include "traverse.hpp"
+
+namespace dust {
+
+// ==================================================================== final gather
+// final_gather.rgen:14-44: is this pixel's gather ray live, and where does it start and point?
+__device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, bool valid, V3& inval, V3& loc, V3& ad) {
+  const size_t pix = valid ? (size_t)py * a.width + px : 0;
+  const float hitT = valid ? a.g.depth[pix] : INFINITY;
+  bool live = valid && !(hitT == INFINITY);
+  inval = mk(0, 0, 0); loc = mk(0, 0, 0); ad = mk(0, 0, 1);
+  if (live) {
+    float w;
+    inval = load_radiance(a.g.illuminance, pix, w);
+    if (w > 0.0f) live = false;  // resolved by the ambient occlusion pass
+  }
+  if (live) {
+    const V3 n = nrd_unpack_normal(a.g.normal[pix]);
+    const V3 d = camera_ray_dir(a, px, py);
+    loc = mk((hitT * d.x + a.cam.pos[0]) + n.x * 0.01f, (hitT * d.y + a.cam.pos[1]) + n.y * 0.01f,
+             (hitT * d.z + a.cam.pos[2]) + n.z * 0.01f);
+    const uint32_t nx = (px + 7u + a.rand) % 128u, ny = (py + 183u + a.rand) % 128u;
+    const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[ny * 128u + nx];
+    const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                     div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
+    ad = normalize3(rotate_by_normal(n, ns));
+  }
+  return live;
+}
+
+// Regrouping pre-pass. Gather rays leave neighbouring pixels in unrelated directions, so an 8x8 pixel packet bounds
+// nothing by direction and most of its lanes idle through every instance visit. One workgroup per 64x64 pixel tile (four
+// pixels per thread) orders the tile's LIVE pixels by direction bin -- the octant their ray points into times the order of
+// its components' magnitudes, 48 bins -- with a stable counting sort on ballots (deterministic); k_final_gather then takes
+// 64 consecutive entries as a packet: same neighbourhood, similar directions, no dead lanes. Measured on the castle, final
+// gather kernel: 32x32 tiles and 8 octants (round 1) 0.304 ms, 24 bins 0.281, 48 bins 0.276, 96 bins 0.273 (but the frame no
+// faster); 48 bins on 64x32 tiles 0.267, 64x64 0.256 (96 bins there: 0.250, frame 0.3 % faster), 128x64 0.255 (frame no faster): more rays per tile make a packet's 64
+// entries fall into fewer bins, until the spread of their origins costs as much.
+// Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
+constexpr uint32_t kOrderTile = 32, kOrderTileW = 64, kOrderTileH = 64, kOrderThreads = kOrderTile * kOrderTile, kOrderSlots = kOrderTileW * kOrderTileH;
+__global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs) {
+  ArgsRef a = launch_args();
+  constexpr uint32_t kWaves = kOrderSlots / 64;   // "virtual" waves: the tile's 32x32 quarter h is waves 16 h .. 16 h + 15 of the order
+  constexpr uint32_t kBins = 48;
+  constexpr uint32_t kCounters = kBins * kWaves;
+  __shared__ uint32_t cnt[kCounters];
+  __shared__ uint32_t bin_base[kBins];
+  __shared__ uint32_t grand_total;
+  const uint32_t tile = blockIdx.x, tx = tile % a.gi.order_tiles_x, ty = tile / a.gi.order_tiles_x;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < kCounters; i += kOrderThreads) cnt[i] = 0u;
+  if (threadIdx.x == 0) grand_total = 0u;
+  __syncthreads();
+  constexpr uint32_t kSub = kOrderSlots / kOrderThreads;
+  uint32_t keys[kSub], below[kSub], pix[kSub];
+  bool lives[kSub];
+#pragma unroll
+  for (uint32_t h = 0; h < kSub; ++h) {
+    constexpr uint32_t kSubX = kOrderTileW / kOrderTile;
+    const uint32_t px = tx * kOrderTileW + (h % kSubX) * 32u + (threadIdx.x % kOrderTile), py = a.row_begin + ty * kOrderTileH + (h / kSubX) * 32u + (threadIdx.x / kOrderTile);
+    V3 inval, loc, ad;
+    const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
+    const float ax = fabsf(ad.x), ay = fabsf(ad.y), az = fabsf(ad.z);
+    const uint32_t dom = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+    const uint32_t sec = dom == 0u ? (ay >= az ? 0u : 1u) : (dom == 1u ? (ax >= az ? 0u : 1u) : (ax >= ay ? 0u : 1u));
+    const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec : kBins;
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 6; ++bit) {
+      const bool one = (key >> bit) & 1u;
+      const uint64_t m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    keys[h] = key; lives[h] = live; pix[h] = py * a.width + px;
+    below[h] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    if (key < kBins && below[h] == 0) cnt[key * kWaves + h * 16u + wave] = (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  // a bin's counters are one per lane of a wavefront (64 virtual waves): each wave scans whole bins with shuffles, then the first
+  // wave scans the bins' totals -- two barriers, whatever the number of bins
+  static_assert(kWaves == 64, "one counter per lane");
+  for (uint32_t b = wave; b < kBins; b += kOrderThreads / 64u) {
+    const uint32_t v = cnt[b * kWaves + lane];
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d);
+      if (lane >= d) inc += up;
+    }
+    cnt[b * kWaves + lane] = inc - v;
+    if (lane == 63) bin_base[b] = inc;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < kBins; base += 64u) {
+      const uint32_t v = base + lane < kBins ? bin_base[base + lane] : 0u;
+      uint32_t inc = v;
+#pragma unroll
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+      }
+      if (base + lane < kBins) bin_base[base + lane] = carry + inc - v;
+      carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) grand_total = carry;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t h = 0; h < kSub; ++h)
+    if (lives[h]) a.gi.order[(size_t)tile * kOrderSlots + bin_base[keys[h]] + cnt[keys[h] * kWaves + h * 16u + wave] + below[h]] = pix[h];
+  if (threadIdx.x == 0) a.gi.order_count[tile] = grand_total;
+}
+
+// final_gather.rchit:35-91 / final_gather.rmiss:12-24 for one finished gather ray of pixel (px, py)
+__device__ __forceinline__ void gather_shade(ArgsRef ar, uint32_t px, uint32_t py, V3 inval, V3 loc, V3 ad, const Hit& h) {
+  const size_t pix = (size_t)py * ar.width + px;
+  if (!h.found) {
+    const V3 sk = sky_radiance(ar.sky, normalize3(ad));
+    store_radiance_scattered(ar.g.illuminance, pix, mk(inval.x + sk.x, inval.y + sk.y, inval.z + sk.z), 0.0f);
+    return;
+  }
+  HashKey key;
+  DevSurfel sf;
+  uint32_t alb;
+  brick_surfel(ar, h, loc, ad, key, sf, alb);
+  V3 rad;
+  uint32_t count;
+  uint32_t entry;
+  hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+  if (ar.gi.touched) ar.gi.touched[px + py * ar.width] = entry;  // multi-GPU: the other ranks repeat this stamp
+  const float prob = 1.0f / (float)(count + 2u);
+  const float noise = div_const((float)ar.noise0[((py + 21u + ar.rand) % 128u) * 128u + ((px + 34u + ar.rand) % 128u)], 255.0f);
+  if (noise > prob) {  // final_gather.rchit:52-63; the highest pixel index wins the slot (k_surfel_commit)
+    const uint32_t index = px + py * ar.width;
+    ar.gi.pixel_surfel[index] = sf;
+    atomicMax(&ar.gi.slot_owner[index % ar.gi.pool_size], index + 1u);
+  }
+  rad = modulate_by_avg_albedo(rad, alb);
+  store_radiance_scattered(ar.g.illuminance, pix, mk(inval.x + rad.x, inval.y + rad.y, inval.z + rad.z), h.t);
+}
+// one packet of gather rays, start to finish, with a cull of its own (final_gather.rgen:14-52 + rough.rint)
+template <int MODE>
+__device__ __forceinline__ void gather_packet(ArgsRef a0, uint32_t px, uint32_t py, bool valid, uint32_t* cand, LaneStats& st) {
+  ArgsRef a = reload_args(a0);
+  V3 inval, loc, ad;
+  const bool live = gather_ray(a, px, py, valid, inval, loc, ad);
+#ifdef DUST_TRACE_DEBUG
+  {
+    const size_t pix = valid ? (size_t)py * a.width + px : 0;
+    const unsigned long long m = __ballot(valid && (uint32_t)pix + 1u == (a.debug >> 12));
+    if ((threadIdx.x & 63u) == 0) g_dbg_mask[threadIdx.x >> 6] = m;
+    __builtin_amdgcn_wave_barrier();
+    DBG_PRINT("FG pixel %u,%u live=%d o=%.9g,%.9g,%.9g d=%.9g,%.9g,%.9g\n", px, py, (int)live, loc.x, loc.y, loc.z, ad.x, ad.y, ad.z);
+  }
+#endif
+  Hit h;
+  const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
+  trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
+  __builtin_amdgcn_wave_barrier();
+  ArgsRef b = reload_args(a0);
+  if (b.gi.fg_hits) {  // tracing only: the ray touches no GI state, so this kernel may run while the previous frame's surfel pass still writes it
+    if (live) {
+      u32x4 rec;
+      rec.x = __float_as_uint(h.t); rec.y = h.inst; rec.z = h.block; rec.w = h.found ? 1u : 0u;
+      *reinterpret_cast<u32x4*>(&b.gi.fg_hits[(size_t)py * b.width + px]) = rec;
+    }
+  } else if (live) {
+    gather_shade(b, px, py, inval, loc, ad, h);
+  }
+}
+
+// final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24, a packet at a time
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = cursor_begin();
+  Packet p;
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
+    if (a.gi.order) {  // regrouped: packet id -> 64 entries of one tile's octant-ordered pixel list
+      const uint32_t id = p.px / kTileW, tile = id / (kOrderSlots / 64u), idx = (id % (kOrderSlots / 64u)) * 64u + (threadIdx.x & 63u);
+      const uint32_t n = a.gi.order_count[tile];
+      if ((idx & ~63u) >= n) continue;  // this tile has fewer live pixels
+      p.valid = idx < n;
+      const uint32_t pixel = p.valid ? a.gi.order[(size_t)tile * kOrderSlots + idx] : 0u;
+      p.px = pixel % a.width;
+      p.py = pixel / a.width;
+    }
+    gather_packet<MODE>(a0, p.px, p.py, p.valid, cand, st);
+  }
+  prof_end();
+  flush_stats<MODE>(a0, 0, st);
+}
+
+// final_gather.rchit:35-91 / final_gather.rmiss:12-24 as a pass of its own over the hit records k_final_gather left (DevGI::fg_hits): a
+// pixel per thread in pixel order -- the radiance texels and the per-pixel surfels go out as whole lines instead of 8- and 16-byte pieces
+// scattered by the regrouping --, at full occupancy (the hash probe is a dependent chain instance -> block -> 36 random bytes of a 384 MB
+// table: latency that many resident waves hide and four persistent ones per SIMD did not). It is also what lets the TRACE run beside the
+// previous frame's surfel pass: only this kernel reads and stamps the hash. A pixel is live exactly when the trace found it live
+// (gather_ray reads the same G-buffer texels: nothing has written them in between).
+__global__ void __launch_bounds__(256) k_final_gather_shade(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t rows = a.row_end - a.row_begin;
+  const size_t n = (size_t)rows * a.width;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t py = a.row_begin + (uint32_t)(i / a.width), px = (uint32_t)(i % a.width);
+    V3 inval, loc, ad;
+    if (!gather_ray(a, px, py, true, inval, loc, ad)) continue;
+    const u32x4 rec = *reinterpret_cast<const u32x4*>(&a.gi.fg_hits[(size_t)py * a.width + px]);
+    Hit h;
+    h.t = __uint_as_float(rec.x); h.inst = rec.y; h.block = rec.z; h.voxel = 0; h.found = rec.w != 0u;
+    gather_shade(a, px, py, inval, loc, ad, h);
+  }
+}
+
+// The same pass over ray lanes (trace_pool): a work item is kPoolGroup consecutive entries of a tile's direction-ordered list --
+// several packets' worth of rays that share one cull and are streamed through the wave's 64 lanes.
+#ifndef DUST_POOL_GROUP
+#define DUST_POOL_GROUP 256  // entries per work item of the ray-lane kernels (k_final_gather_pool, k_surfel_trace_pool)
+#endif
+constexpr uint32_t kPoolGroup = DUST_POOL_GROUP;
+struct GatherSource {
+  uint32_t tile;
+  __device__ __forceinline__ void pixel_of(ArgsRef a, uint32_t idx, uint32_t& px, uint32_t& py) const {
+    const uint32_t pixel = a.gi.order[(size_t)tile * kOrderSlots + idx];
+    py = pixel / a.width;
+    px = pixel - py * a.width;
+  }
+  __device__ __forceinline__ bool fetch(ArgsRef a, uint32_t idx, V3& o, V3& d) const {
+    uint32_t px, py;
+    pixel_of(a, idx, px, py);
+    V3 inval;
+    return gather_ray(a, px, py, true, inval, o, d);
+  }
+  __device__ __forceinline__ void skip(ArgsRef, uint32_t) const {}
+  __device__ __forceinline__ void shade(ArgsRef a, uint32_t idx, V3 o, V3 d, const Hit& h) const {
+    uint32_t px, py;
+    pixel_of(a, idx, px, py);
+    float w;
+    const V3 inval = load_radiance(a.g.illuminance, (size_t)py * a.width + px, w);  // (what gather_ray read when the ray was made)
+    gather_shade(a, px, py, inval, o, d, h);
+  }
+};
+__device__ __forceinline__ void merge_range(Range3& r, const Range3& q) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(r.lo[k], q.lo[k]); r.hi[k] = fmaxf(r.hi[k], q.hi[k]); }
+}
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_final_gather_pool(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = cursor_begin();
+  Packet p;
+  const uint32_t lane = threadIdx.x & 63u;
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);
+    constexpr uint32_t kGroups = kOrderSlots / kPoolGroup;
+    const uint32_t id = p.px / kTileW, tile = id / kGroups, begin = (id % kGroups) * kPoolGroup;
+    const uint32_t n = a.gi.order_count[tile];
+    if (begin >= n) continue;  // this tile has fewer live pixels
+    const uint32_t end = n < begin + kPoolGroup ? n : begin + kPoolGroup;
+    GatherSource src;
+    src.tile = tile;
+    // the item's ray bundle: one pass over its entries, a packet at a time (the rays themselves are made again when a lane
+    // takes them: six floats apiece are cheaper to recompute than to park)
+    Range3 org, dir;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { org.lo[k] = dir.lo[k] = INFINITY; org.hi[k] = dir.hi[k] = -INFINITY; }
+    bool any = false;
+    for (uint32_t j = begin; j < end; j += 64u) {
+      V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+      const bool live = j + lane < end && src.fetch(a, j + lane, o, d);
+      merge_range(org, wave_range(live, o));
+      merge_range(dir, wave_range(live, d));
+      any = any | (__any(live) != 0);
+    }
+    const uint32_t ncand = cull_instances(a, any, org, dir, a.cam.far_, cand);
+    if (ncand > kMaxCand || (a.debug & 12u)) {  // the list overflowed (or a debug order was asked for): packets, each with its own cull
+      for (uint32_t j = begin; j < end; j += 64u) {
+        uint32_t px = 0, py = 0;
+        const bool valid = j + lane < end;
+        if (valid) src.pixel_of(a, j + lane, px, py);
+        gather_packet<MODE>(a0, px, py, valid, cand, st);
+      }
+      continue;
+    }
+    trace_pool<2, MODE>(a, src, begin, end, cand, ncand, 8.0f, a.cam.far_, false, st);
+  }
+  prof_end();
+  flush_stats<MODE>(a0, 0, st);
+}
+
+// the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
+__global__ void k_surfel_commit(const FrameArgs) {
+  ArgsRef a = launch_args();
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    const uint32_t o = a.gi.slot_owner[s];
+    if (o != 0u) {
+      a.gi.pool[s] = a.gi.pixel_surfel[o - 1u];
+      a.gi.slot_owner[s] = 0u;
+    }
+  }
+}
+
+// ==================================================================== multi-GPU exchange of the final gather's side effects
+// (dust_hip.h, dust_hip_pipeline_gi_exchange). slot_owner holds the all-reduced (MAX) owners when these run.
+// export: this rank's share of the winning surfels -- the slots whose winning pixel lies in rows [row_begin, row_end)
+__global__ void k_gi_export(const FrameArgs) {
+  ArgsRef a = launch_args();
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    const uint32_t o = a.gi.slot_owner[s];
+    DevSurfel v;
+    v.x = v.y = v.z = 0.0f; v.direction = 0u;
+    if (o != 0u) {
+      const uint32_t row = (o - 1u) / a.width;
+      if (row >= a.row_begin && row < a.row_end) v = a.gi.pixel_surfel[o - 1u];
+    }
+    a.gi.merged[s] = v;
+  }
+}
+// import: repeat the last_accessed_frame stamps of the other bands' final gather, commit the merged winners
+__global__ void k_gi_import(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t n_px = a.width * a.height;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += gridDim.x * blockDim.x) {
+    const uint32_t row = i / a.width;
+    if (row >= a.row_begin && row < a.row_end) continue;  // this rank's own final gather already stamped those
+    const uint32_t e = a.gi.touched[i];
+    if (e != 0u) reinterpret_cast<uint16_t*>(a.gi.hash + (size_t)(e - 1u) * 3)[4] = (uint16_t)a.frame_index;
+  }
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.gi.pool_size; s += gridDim.x * blockDim.x) {
+    if (a.gi.slot_owner[s] != 0u) {
+      a.gi.pool[s] = a.gi.merged[s];
+      a.gi.slot_owner[s] = 0u;
+    }
+  }
+}
+
+// ==================================================================== surfel pass, phase 0: order the pool by position
+// Consecutive pool slots hold the hit points of unrelated final-gather rays, scattered over the whole scene: a packet of
+// 64 of them bounds nothing and walks a dozen instances per ray. Sorting the slots by a 16-bit Morton key of their
+// position (32 x 32 x 64 cells over the scene's bounds; dead slots last) makes a packet's origins neighbours, so the packet culling works again.
+// Only the grouping into packets changes: every surfel still computes and writes exactly what it did, at its own slot.
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 1023u;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void k_surfel_keys(const FrameArgs) {
+  ArgsRef a = launch_args();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.gi.pool_size; i += gridDim.x * blockDim.x) {
+    const DevSurfel e = a.gi.pool[i];
+    uint32_t key = 0xFFFFu;  // dead slots sort last
+    if (e.direction < 6u) {
+      const float q[3] = {e.x, e.y, e.z};
+      uint32_t c[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float span = fmaxf(a.world_max[k] - a.world_min[k], 1.0f);
+        const float f = fminf(fmaxf((q[k] - a.world_min[k]) * (1024.0f / span), 0.0f), 1023.0f);  // NaN -> 0
+        c[k] = (uint32_t)f;
+      }
+      // the top 16 bits of the 30-bit Morton code: five full levels of the octree over the scene's bounds and one more
+      // split (16 bits: two 8-bit digit passes of radix.hip; a finer order costs more in the sort than it saves in the trace)
+      key = (spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2)) >> 14;
+      key = key < 0xFFFEu ? key : 0xFFFEu;
+    }
+    a.gi.sort_keys[i] = key;
+    a.gi.sort_vals[i] = i;
+  }
+}
+
+// ==================================================================== surfel pass, phase 1: trace + read the hash
+// surfel.rgen:12-67 + rough.rint + surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
+  LaneStats st_sun = {0, 0, 0, 0, 0, 0}, st_cos = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = cursor_begin();
+  Packet p;
+  const V3 sun = mk(a0.sky[48], a0.sky[49], a0.sky[50]);
+  // Work items: 64 consecutive surfels x one ray kind. The closest-hit cosine rays of every group come first (the long
+  // items), then the any-hit sun rays: with both rays of a group in one item the pool is only 1.3 items per resident wave and
+  // the kernel lasts as long as the waves that drew two. What a lit surfel receives from the sun goes through its own array
+  // and is added when the request is applied (surfel.rmiss:14-26 / surfel.rchit:35-102 add it to the same value there).
+  while (next_packet(a0, wc, p)) {  // tiles_x = 2 * ceil(pool_size / 64), tiles_y = 1
+    ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
+    const uint32_t groups = (a.gi.pool_size + 63u) / 64u;
+    const uint32_t item = p.px / kTileW;
+    const bool sun_item = item >= groups;
+    const uint32_t slot = (sun_item ? item - groups : item) * 64u + (threadIdx.x & 63u);
+    const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
+    const bool in_range = i < a.gi.pool_size;
+    DevSurfel e;
+    e.x = e.y = e.z = 0.0f; e.direction = 0xFFFFFFFFu;
+    if (in_range) e = a.gi.pool[i];
+    const bool live = in_range && e.direction < 6u;
+    const V3 n = faceid2normal(live ? e.direction : 0u);
+    const V3 org = mk(e.x + 2.01f * n.x, e.y + 2.01f * n.y, e.z + 2.01f * n.z);
+    const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+    const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
+    V3 dir = sd;
+    bool act = live && dot3(sun, n) > 0.0f;
+    if (!sun_item) {
+      act = live;
+      dir = mk(0, 0, 1);
+      if (live) {
+        const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
+        const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                         div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
+        dir = normalize3(rotate_by_normal(n, ns));
+      }
+    }
+    Hit h;
+    {
+      const Range3 orgs = wave_range(live, org);
+      const uint32_t ncand = cull_instances(a, __any(act), orgs, sun_item ? point_range(sd) : wave_range(live, dir), 10000.0f, cand);
+      LaneStats cur = {0, 0, 0, 0, 0, 0};
+      trace_ray<3, MODE>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
+      if (COUNT) add_stats(sun_item ? st_sun : st_cos, cur);
+      __builtin_amdgcn_wave_barrier();
+#ifdef DUST_SURFEL_DEBUG  // (never shipped) every surfel ray with its result, for tools/diag/deep_mismatch.py to hand to the oracle one by one
+      if (act) printf("SF %u %d %.9g %.9g %.9g %.9g %.9g %.9g %d %.9g %u %u\n", i, (int)sun_item, org.x, org.y, org.z, dir.x, dir.y, dir.z, (int)h.found, h.t, h.inst, h.block);
+#endif
+    }
+    ArgsRef ar = reload_args(a0);
+    if (sun_item) {  // surfel/nee.rmiss:15-27
+      f32x4 pay = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (act && !h.found) {
+        const float dn = dot3(n, sd);
+        pay.x = ar.sun_term[0] * dn; pay.y = ar.sun_term[1] * dn; pay.z = ar.sun_term[2] * dn;
+      }
+      if (in_range) reinterpret_cast<f32x4*>(ar.gi.sun_payload)[i] = pay;
+      continue;
+    }
+    const V3 cd = dir;
+    DevHashRequest rq;
+    rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
+    DevSurfel repl;
+    repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
+    if (live) {
+      rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
+      rq.dir_flags = e.direction & 0xFFu;
+      if (!h.found) {  // surfel.rmiss:14-26
+        const V3 sk = sky_radiance(ar.sky, normalize3(cd));
+        rq.vx = sk.x; rq.vy = sk.y; rq.vz = sk.z;
+        rq.dir_flags |= 0x100u;
+      } else {         // surfel.rchit:35-102
+        HashKey key;
+        DevSurfel sf;
+        uint32_t alb;
+        brick_surfel(ar, h, org, cd, key, sf, alb);
+        V3 rad;
+        uint32_t count = 0;
+        uint32_t entry;
+        const bool found = hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+        const float rnd0 = div_const((float)ar.noise0[((ny0 + 40u + ar.rand) % 128u) * 128u + ((nx0 + 114u + ar.rand) % 128u)], 255.0f);
+        if (found) {
+          rad = modulate_by_avg_albedo(rad, alb);
+          rq.vx = rad.x; rq.vy = rad.y; rq.vz = rad.z;
+          rq.dir_flags |= 0x100u;
+        } else if (rnd0 > 1.0f / (float)(count + 2u)) {
+          repl = sf;
+        }
+      }
+    }
+    if (in_range) {
+      ar.gi.requests[i] = rq;
+      ar.gi.replacement[i] = repl;
+    }
+  }
+  prof_end();
+  flush_stats<MODE>(a0, 0, st_sun);
+  flush_stats<MODE>(a0, 1, st_cos);
+}
+
+// ==================================================================== surfel pass, phase 2: apply in surfel order
+// Deterministic mode: one wavefront scans the requests 64 at a time and lane 0 applies them in index order.
+__global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t base = 0; base < a.gi.pool_size; base += 64u) {
+    const uint32_t i = base + lane;
+    bool work = false;
+    if (i < a.gi.pool_size) work = (a.gi.requests[i].dir_flags & 0x100u) || a.gi.replacement[i].direction != 0xFFFFFFFFu;
+    uint64_t mask = __ballot(work);
+    if (lane == 0) {
+      while (mask) {
+        const uint32_t j = base + (uint32_t)__ffsll((long long)mask) - 1u;
+        mask &= mask - 1ull;
+        const DevHashRequest rq = a.gi.requests[j];
+        if (rq.dir_flags & 0x100u) {
+          HashKey k;
+          k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+          const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
+          hash_insert(a.gi, k, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
+        }
+        const DevSurfel r = a.gi.replacement[j];
+        if (r.direction != 0xFFFFFFFFu) a.gi.pool[j % a.gi.pool_size] = r;
+      }
+    }
+  }
+}
+// Deterministic mode at full width. A SpatialHashInsert touches the three entries of its probe window and nothing else, so
+// two requests only interact when their windows overlap -- hash locations at most 2 apart. Requests sorted by location
+// (radix.hip; stable, so equal locations stay in surfel order) therefore fall into CLUSTERS, maximal runs whose consecutive
+// locations differ by <= 2; different clusters touch disjoint entries and commute. One thread per cluster applies its
+// requests in surfel-index order: the hash ends up exactly as the serial loop above leaves it, at the speed of the racy kernel.
+__global__ void k_surfel_apply_keys(const FrameArgs) {  // hash location of every insert request -> sort keys
+  ArgsRef a = launch_args();
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
+    const DevHashRequest rq = a.gi.requests[j];
+    uint32_t loc = a.gi.hash_capacity;  // "no insert": sorts behind every real location
+    if (rq.dir_flags & 0x100u) {
+      HashKey k;
+      k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+      loc = key_location(k, a.gi.hash_capacity);
+    }
+    a.gi.sort_keys[j] = loc;
+    a.gi.sort_vals[j] = j;
+    const DevSurfel r = a.gi.replacement[j];  // slot replacements are independent of each other and of the hash
+    if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
+  }
+}
+__shared__ uint32_t g_apply_slab[256][25];  // k_surfel_apply_clusters: a thread's staged probe windows (8 entries, padded to 25 words)
+__global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t n = a.gi.pool_size, none = a.gi.hash_capacity;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t loc = a.gi.apply_keys[i];
+    if (loc == none) continue;
+    if (i > 0 && loc - a.gi.apply_keys[i - 1] <= 2u) continue;  // not the first request of its cluster
+    uint32_t end = i + 1;
+    for (uint32_t prev = loc; end < n; ++end) {
+      const uint32_t next = a.gi.apply_keys[end];
+      if (next == none || next - prev > 2u) break;
+      prev = next;
+    }
+    auto request = [&](uint32_t j, uint32_t& fp, V3& value) {
+      const DevHashRequest rq = a.gi.requests[j];
+      HashKey key;
+      key.x = rq.kx; key.y = rq.ky; key.z = rq.kz; key.dir = rq.dir_flags & 0xFFu;
+      const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
+      fp = key_fingerprint(key);
+      value = mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z);
+    };
+    if (a.gi.apply_keys[end - 1] == loc) {
+      // Every request of the cluster probes the same window (all but a handful of clusters: surfels of one brick face
+      // share a key). The sort is stable, so they already stand in surfel order: load the window once, run them on the
+      // register copy, store it once -- a chain of ALU work instead of several dependent memory round trips per request.
+      HashWindow win;
+      uint32_t* base = a.gi.hash + (size_t)loc * 3;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) win.w[k] = base[k];
+      // eight requests at a time: their (independent) loads are in flight together, then the eight inserts run as one chain
+      // of arithmetic on the register window
+      constexpr uint32_t kBatch = 8;
+      for (uint32_t k0 = i; k0 < end; k0 += kBatch) {
+        uint32_t fp[kBatch];
+        V3 value[kBatch];
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; ++b) {
+          const uint32_t k = k0 + b < end ? k0 + b : end - 1u;
+          request(a.gi.apply_vals[k], fp[b], value[b]);
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; ++b)
+          if (k0 + b < end) hash_insert_window(win, fp[b], value[b], a.frame_index);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) base[k] = win.w[k];
+      continue;
+    }
+    // Windows at different offsets (a few dozen clusters per pass, but some are long: two popular brick faces whose
+    // locations happen to lie within two entries of each other). Up to kRuns locations spanning up to kSpan entries: the union
+    // of the windows is staged in this thread's LDS slab, the runs (each already in surfel order) are merged by surfel index.
+    constexpr uint32_t kRuns = 4, kSpan = 8;
+    uint32_t run_at[kRuns], run_end[kRuns], run_loc[kRuns], n_runs = 0;
+    bool fits = true;
+    for (uint32_t k = i; k < end;) {
+      const uint32_t l = a.gi.apply_keys[k];
+      uint32_t e2 = k + 1;
+      while (e2 < end && a.gi.apply_keys[e2] == l) ++e2;
+      if (n_runs < kRuns) { run_at[n_runs] = k; run_end[n_runs] = e2; run_loc[n_runs] = l; }
+      else fits = false;
+      ++n_runs;
+      k = e2;
+    }
+    const uint32_t last_loc = a.gi.apply_keys[end - 1];
+    fits = fits && last_loc - loc + 3u <= kSpan;
+    if (fits) {
+      uint32_t* slab = &g_apply_slab[threadIdx.x][0];
+      const uint32_t words = (last_loc - loc + 3u) * 3u;
+      uint32_t* base = a.gi.hash + (size_t)loc * 3;
+      for (uint32_t k = 0; k < words; ++k) slab[k] = base[k];
+      uint32_t head[kRuns];
+#pragma unroll
+      for (uint32_t r = 0; r < kRuns; ++r) head[r] = r < n_runs ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
+      for (uint32_t done = 0; done < end - i; ++done) {
+        uint32_t best = 0;
+#pragma unroll
+        for (uint32_t r = 1; r < kRuns; ++r) best = head[r] < head[best] ? r : best;
+        uint32_t j = 0, l = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < kRuns; ++r)
+          if (r == best) {
+            j = head[r]; l = run_loc[r];
+            run_at[r] += 1;
+            head[r] = run_at[r] < run_end[r] ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
+          }
+        uint32_t fp;
+        V3 value;
+        request(j, fp, value);
+        HashMemory m;  // the same accessor: "memory" is the slab
+        m.base = slab + (l - loc) * 3u;
+        hash_insert_window(m, fp, value, a.frame_index);
+      }
+      for (uint32_t k = 0; k < words; ++k) base[k] = slab[k];
+      continue;
+    }
+    // anything wider: through memory, in ascending surfel index found by repeated minimum
+    uint32_t last = 0;
+    for (uint32_t done = 0; done < end - i; ++done) {
+      uint32_t j = 0xFFFFFFFFu, at = i;
+      for (uint32_t k = i; k < end; ++k) {
+        const uint32_t v = a.gi.apply_vals[k];
+        if ((done == 0 || v > last) && v < j) { j = v; at = k; }
+      }
+      last = j;
+      uint32_t fp;
+      V3 value;
+      request(j, fp, value);
+      HashMemory m;
+      m.base = a.gi.hash + (size_t)a.gi.apply_keys[at] * 3;
+      hash_insert_window(m, fp, value, a.frame_index);
+    }
+  }
+}
+// Throughput mode: every surfel applies its own insert concurrently, as the reference's shaders do (racy by design,
+// spatial_hash.glsl:147-195 only claims the fingerprint atomically); results are statistically, not bitwise, repeatable.
+__global__ void k_surfel_apply_racy(const FrameArgs) {
+  ArgsRef a = launch_args();
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.gi.pool_size; j += gridDim.x * blockDim.x) {
+    const DevHashRequest rq = a.gi.requests[j];
+    if (rq.dir_flags & 0x100u) {
+      HashKey k;
+      k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
+      const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];
+      hash_insert(a.gi, k, mk(rq.vx + sp.x, rq.vy + sp.y, rq.vz + sp.z), a.frame_index);
+    }
+    const DevSurfel r = a.gi.replacement[j];
+    if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
+  }
+}
+
+hipError_t launch_gi_export(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_export, dim3(512), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_gi_import(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gi_import, dim3(1024), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderThreads), 0, s, a);
+  return hipGetLastError();
+}
+uint32_t final_gather_pool_group() { return kPoolGroup; }
+hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  if (pool) DUST_LAUNCH_MODE(k_final_gather_pool, count, a_in);
+  else DUST_LAUNCH_MODE(k_final_gather, count, a_in);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a_in);
+  return hipGetLastError();
+}
+hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_gather_shade, dim3(4096), dim3(256), 0, s, a);
+  if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(512), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_keys(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_keys, dim3(512), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_trace(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = lds_bytes(a_in, block);
+  DUST_LAUNCH_MODE(k_surfel_trace, count, a_in);
+  return hipGetLastError();
+}
+// mode 0: concurrent (racy, as the reference); 1: serial in surfel order (one wavefront); 2: keys for the clustered apply;
+// 3: the clustered apply itself (after the sort)
+hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL(k_surfel_apply_racy, dim3(1024), dim3(256), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL(k_surfel_apply_keys, dim3(512), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_surfel_apply_clusters, dim3(1024), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_kernels left after the build's static LDS)
+  const void* fns[] = {
+      (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
+      (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>,
+      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>};
+  for (const void* f : fns) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace dust
