@@ -39,6 +39,10 @@ hipError_t radix_sort_pairs(void* scratch, uint32_t* keys_a, uint32_t* vals_a, u
                             uint32_t key_bits, bool* in_b, hipStream_t s);
 hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t);
+hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t);
+hipError_t launch_surfel_rays(const FrameArgs& a, hipStream_t);
+hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t);
+hipError_t launch_ray_stream(const FrameArgs& a, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
@@ -269,8 +273,9 @@ struct HostInstance {
 // stream (tlas.rs:37-65 rebuilds the TLAS inside the frame's command stream the same way): no allocation, no wait, and the
 // kernels' pointers stay what they were until instances are added.
 struct SceneLayout {
-  size_t models = 0, root_table = 0, instances = 0, boxes = 0, visits = 0, total = 0;
-  static SceneLayout make(size_t n_inst, size_t n_models, size_t n_roots) {
+  size_t models = 0, root_table = 0, instances = 0, boxes = 0, visits = 0, enters = 0, grid_cells = 0, grid_items = 0, total = 0;
+  size_t cap_cells = 0, cap_items = 0;  // entries the two grid sections hold (a commit that needs more lays the image out again)
+  static SceneLayout make(size_t n_inst, size_t n_models, size_t n_roots, size_t n_cells, size_t n_items) {
     SceneLayout l;
     auto place = [&l](size_t bytes) { const size_t at = l.total; l.total = (l.total + bytes + 255) & ~size_t(255); return at; };
     l.models = place(n_models * sizeof(dust::DevModel));
@@ -278,6 +283,12 @@ struct SceneLayout {
     l.instances = place(n_inst * sizeof(dust::DevInstance));
     l.boxes = place((n_inst + 1) * sizeof(dust::DevBox));
     l.visits = place((n_inst + 1) * sizeof(dust::DevVisit));
+    l.enters = place((n_inst + 1) * sizeof(dust::DevEnter));
+    // the top-level grid last, with room to spare: its size follows the instances' positions, not only their number
+    l.cap_cells = n_cells + n_cells / 2 + 64;
+    l.cap_items = n_items + n_items / 2 + 256;
+    l.grid_cells = place((l.cap_cells + 4) * sizeof(uint32_t));
+    l.grid_items = place((l.cap_items + 8) * sizeof(uint16_t));
     return l;
   }
 };
@@ -308,6 +319,12 @@ struct DustHipScene : RefCounted {
   size_t image_capacity = 0;  // bytes per slot
   std::vector<uint8_t> master;   // host master copy of the image (dirty instances are re-derived in place)
   float world_min[3] = {0, 0, 0}, world_max[3] = {0, 0, 0};  // union of the instances' world boxes
+  // the top-level grid over the instance boxes (dust_dev.h DevGrid; rebuilt by every commit): its header, and the two arrays
+  // that are copied into the image
+  dust::DevGrid grid{};
+  std::vector<uint32_t> grid_cells;
+  std::vector<uint16_t> grid_items;
+  std::vector<float> world_boxes;  // per instance {lo[3], hi[3]}: what derive_instance writes into the image, kept for the grid
   uint32_t n_lds_models = 0;
   uint64_t revision = 0;  // bumped by every commit (what the cost-ordered hand-out keys its view on)
   bool committed = false;
@@ -361,6 +378,10 @@ struct Tuning {
   uint32_t cuts_reuse = 4;      // DUST_HIP_CUTS_REUSE: re-orderings of a moving view that keep one set of band cuts
   uint32_t moving_refresh = 4;  // DUST_HIP_MOVING_REFRESH: launches between two re-orderings of a view that moves (order_tiles)
   uint32_t side_prio = 3;       // DUST_HIP_SIDE_PRIO: issue priority floor of the surfel pass on the second stream
+  uint32_t stream_refill = 16;  // DUST_HIP_STREAM_REFILL, DUST_HIP_STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
+  uint32_t stream_top_iters = 8;
+  bool no_stream_lds = false;   // DUST_HIP_NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
+  bool packet_gi = false;       // DUST_HIP_PACKET_GI: the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace: rounds 1-4) instead of as ray streams
   bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
                                 // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -384,6 +405,11 @@ struct Tuning {
     t.equal_bands = std::getenv("DUST_HIP_EQUAL_BANDS") != nullptr;
     t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
     t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
+    t.no_stream_lds = std::getenv("DUST_HIP_NO_STREAM_LDS") != nullptr;
+    t.stream_refill = std::min(64u, std::max(1u, num("DUST_HIP_STREAM_REFILL", 16)));
+    t.stream_top_iters = std::max(1u, num("DUST_HIP_STREAM_TOP_ITERS", 8));
+    t.packet_gi = std::getenv("DUST_HIP_PACKET_GI") != nullptr || t.ray_lanes || std::getenv("DUST_HIP_GATHER_SPLIT") != nullptr || (t.debug & 12u) != 0 ||
+                  std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;  // (switches of the packet kernels select them)
     t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
     t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
     t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
@@ -434,7 +460,9 @@ struct DustHipPipeline {
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
   DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
-  DeviceBuffer gi_fg_hits;  // per pixel: the hit record of its gather ray (k_final_gather -> k_final_gather_shade)
+  DeviceBuffer gi_fg_hits;  // per pixel: the hit record of its gather ray (k_ray_stream / k_final_gather -> k_final_gather_shade)
+  // ray streams (gi.hip): the compacted rays of the two GI passes, the surfel rays' hit records, and per pass two ray counters used in turn
+  DeviceBuffer gi_rays_fg, gi_rays_sf, gi_hits_sf, gi_groups_fg, gi_groups_sf;
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 64x64 tile grouped by ray direction bin
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
@@ -1174,6 +1202,21 @@ DustStatus dust_hip_scene_set_transform(DustHipScene* s, uint32_t id, const floa
 }
 
 namespace {
+// conservative world box of instance i: the eight corners of its model's tight bounds, each padded by 1e-4 of its size
+void world_box(const HostInstance& hi, float wmin[3], float wmax[3]) {
+  const dust::DevModel& m = hi.model->dev;
+  for (int a = 0; a < 3; ++a) { wmin[a] = 1e30f; wmax[a] = -1e30f; }
+  for (int c = 0; c < 8; ++c) {
+    const double p[3] = {(c & 1) ? m.bmax[0] : m.bmin[0], (c & 2) ? m.bmax[1] : m.bmin[1], (c & 4) ? m.bmax[2] : m.bmin[2]};
+    for (int a = 0; a < 3; ++a) {
+      const float* r = hi.o2w + a * 4;
+      const double w = double(r[0]) * p[0] + double(r[1]) * p[1] + double(r[2]) * p[2] + double(r[3]);
+      const double pad = 1e-4 * (std::fabs(w) + 1.0);
+      wmin[a] = std::min(wmin[a], float(w - pad));
+      wmax[a] = std::max(wmax[a], float(w + pad));
+    }
+  }
+}
 // the device records of instance i, re-derived in the host master image (instance, box, visit)
 void derive_instance(DustHipScene* s, size_t i) {
   const HostInstance& hi = s->instances[i];
@@ -1184,18 +1227,7 @@ void derive_instance(DustHipScene* s, size_t i) {
   invert_affine(hi.o2w, d.w2o);
   d.model = s->instance_slot[i];
   d.pad = 0;
-  const dust::DevModel& m = hi.model->dev;
-  for (int a = 0; a < 3; ++a) { d.wmin[a] = 1e30f; d.wmax[a] = -1e30f; }
-  for (int c = 0; c < 8; ++c) {
-    const double p[3] = {(c & 1) ? m.bmax[0] : m.bmin[0], (c & 2) ? m.bmax[1] : m.bmin[1], (c & 4) ? m.bmax[2] : m.bmin[2]};
-    for (int a = 0; a < 3; ++a) {
-      const float* r = hi.o2w + a * 4;
-      const double w = double(r[0]) * p[0] + double(r[1]) * p[1] + double(r[2]) * p[2] + double(r[3]);
-      const double pad = 1e-4 * (std::fabs(w) + 1.0);
-      d.wmin[a] = std::min(d.wmin[a], float(w - pad));
-      d.wmax[a] = std::max(d.wmax[a], float(w + pad));
-    }
-  }
+  world_box(hi, d.wmin, d.wmax);
   // the world box again, packed 32 bytes apiece: what the packet culling streams through (coalesced) and the candidate
   // loop reads with one scalar load; and the flattened visit record (box, world -> object, model)
   dust::DevBox& bx = reinterpret_cast<dust::DevBox*>(img + s->layout.boxes)[i];
@@ -1204,6 +1236,82 @@ void derive_instance(DustHipScene* s, size_t i) {
   bx.pad0 = bx.pad1 = v.pad0 = v.pad1 = 0.0f;
   std::memcpy(v.w2o, d.w2o, sizeof(v.w2o));
   v.m = reinterpret_cast<const dust::DevModel*>(img + s->layout.models)[d.model];
+  // and what the ray streams' instance set-up reads, in 80 bytes (the model's bounds are multiples of 4 up to 4096: exact in 16 bits)
+  dust::DevEnter& e = reinterpret_cast<dust::DevEnter*>(img + s->layout.enters)[i];
+  std::memcpy(e.w2o, d.w2o, sizeof(e.w2o));
+  for (int a = 0; a < 3; ++a) { e.bmin[a] = uint16_t(v.m.bmin[a]); e.bmax[a] = uint16_t(v.m.bmax[a]); }
+  e.model = uint16_t(d.model);
+  e.lds_slot = v.m.lds_slot >= 0 && v.m.lds_slot < 255 ? uint8_t(v.m.lds_slot) : uint8_t(255);
+  e.extent_log2 = v.m.extent > 256u ? 12 : 8;
+  e.root = v.m.root;
+  e.dense_mask = v.m.dense_mask;
+}
+
+// The top-level grid over the instances' world boxes (DevGrid; tlas.rs:37-65 rebuilds the TLAS every frame the same way).
+// About `density` cells per instance (DUST_HIP_GRID_DENSITY, default 12; at most 256 per axis, 2^18 in all), cubes as nearly
+// as the scene's proportions allow. An instance is listed in every cell its box, grown by kGridMargin of the scene's size,
+// overlaps: the margin is what lets the per-ray walk (gi.hip, top_next) trust its single-precision cell steps.
+// boxes: n x {lo[3], hi[3]}. ranges: per instance the block of cells it is listed in, {lo, hi} as x | y << 9 | z << 18.
+constexpr double kGridMargin = 2e-5;
+void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<uint32_t>& ranges) {
+  const size_t n = boxes.size() / 6;
+  dust::DevGrid& g = s->grid;
+  double ext[3], big = 0.0;
+  for (int a = 0; a < 3; ++a) big = std::max(big, double(s->world_max[a]) - double(s->world_min[a]));
+  const double margin = kGridMargin * big + 0.01;
+  for (int a = 0; a < 3; ++a) {
+    g.lo[a] = float(double(s->world_min[a]) - 2.0 * margin);
+    ext[a] = std::max(double(s->world_max[a]) + 2.0 * margin - double(g.lo[a]), 1e-3 * big + 1.0);
+  }
+  static const double density0 = [] { const char* e = std::getenv("DUST_HIP_GRID_DENSITY"); return e ? std::max(0.01, std::atof(e)) : 12.0; }();
+  ranges.resize(n * 2);
+  std::vector<uint32_t> count;
+  for (double density = density0;; density *= 0.5) {  // (coarser until a cell's list and the item array fit the packed cell word: never, for scenes of any sane shape)
+    const double target = std::min(262144.0, std::max(1.0, density * double(std::max<size_t>(n, 1))));
+    const double edge = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+    for (int a = 0; a < 3; ++a) {
+      g.dim[a] = uint32_t(std::min(256.0, std::max(1.0, std::floor(ext[a] / edge + 0.5))));
+      g.cell[a] = float(ext[a] / double(g.dim[a]));
+      g.inv_cell[a] = float(double(g.dim[a]) / ext[a]);
+      g.hi[a] = float(double(g.lo[a]) + ext[a]);
+    }
+    const size_t n_cells = size_t(g.dim[0]) * g.dim[1] * g.dim[2];
+    count.assign(n_cells, 0u);
+    auto cell_of = [&](double w, int a) {
+      const double c = std::floor((w - double(g.lo[a])) / ext[a] * double(g.dim[a]));
+      return uint32_t(std::min(double(g.dim[a] - 1), std::max(0.0, c)));
+    };
+    size_t total = 0;
+    uint32_t most = 0;
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t lo[3], hi[3];
+      for (int a = 0; a < 3; ++a) { lo[a] = cell_of(double(boxes[i * 6 + a]) - margin, a); hi[a] = cell_of(double(boxes[i * 6 + 3 + a]) + margin, a); }
+      ranges[i * 2] = lo[0] | (lo[1] << 9) | (lo[2] << 18);
+      ranges[i * 2 + 1] = hi[0] | (hi[1] << 9) | (hi[2] << 18);
+      for (uint32_t z = lo[2]; z <= hi[2]; ++z)
+        for (uint32_t y = lo[1]; y <= hi[1]; ++y)
+          for (uint32_t x = lo[0]; x <= hi[0]; ++x) most = std::max(most, ++count[(size_t(z) * g.dim[1] + y) * g.dim[0] + x]);
+      total += size_t(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+    }
+    if ((total < (size_t(1) << dust::kGridItemBits) && most <= dust::kGridMaxCellItems) || n_cells == 1) break;
+  }
+  const size_t n_cells = count.size();
+  s->grid_cells.assign(n_cells, 0u);
+  std::vector<uint32_t> at(n_cells);
+  uint32_t run = 0;
+  for (size_t c = 0; c < n_cells; ++c) {
+    at[c] = run;
+    s->grid_cells[c] = run | (std::min(count[c], dust::kGridMaxCellItems) << dust::kGridItemBits);
+    run += count[c];
+  }
+  g.n_items = run;
+  s->grid_items.assign(run, 0);
+  for (size_t i = 0; i < n; ++i) {  // ascending instance order inside every cell
+    const uint32_t rl = ranges[i * 2], rh = ranges[i * 2 + 1];
+    for (uint32_t z = rl >> 18; z <= (rh >> 18); ++z)
+      for (uint32_t y = (rl >> 9) & 255u; y <= ((rh >> 9) & 255u); ++y)
+        for (uint32_t x = rl & 255u; x <= (rh & 255u); ++x) s->grid_items[at[(size_t(z) * g.dim[1] + y) * g.dim[0] + x]++] = uint16_t(i);
+  }
 }
 }  // namespace
 
@@ -1215,8 +1323,9 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     // a model edited since the last commit changes its record (bounds, sizes, maybe addresses): everything is derived again
     for (size_t i = 0; i < s->models.size() && !s->structure_dirty; ++i)
       if (s->models[i]->generation != s->model_generation[i]) s->structure_dirty = true;
-    const bool full = s->structure_dirty;
+    bool full = s->structure_dirty;
     if (full) {
+      s->committed = false;  // (until the new image is up: what follows replaces the layout the current one was made with)
       s->models.clear();
       s->instance_slot.resize(n);
       for (size_t i = 0; i < n; ++i) {
@@ -1227,7 +1336,24 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       }
       // roots of the first models go to LDS, as many as the budget holds
       s->n_lds_models = std::min<uint32_t>(uint32_t(s->models.size()), s->ctx->lds_root_bytes / dust::kN16LdsBytes);
-      s->layout = SceneLayout::make(n, s->models.size(), s->n_lds_models);
+    }
+    // the instances' world boxes (those that moved, or all), the scene's bounds, and the top-level grid over them: the grid's
+    // size decides the image's layout
+    s->world_boxes.resize(n * 6);
+    for (size_t i = 0; i < n; ++i)
+      if (full || s->dirty[i]) world_box(s->instances[i], &s->world_boxes[i * 6], &s->world_boxes[i * 6 + 3]);
+    for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
+    for (size_t i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], s->world_boxes[i * 6 + a]); s->world_max[a] = std::max(s->world_max[a], s->world_boxes[i * 6 + 3 + a]); }
+    if (n == 0) for (int a = 0; a < 3; ++a) s->world_min[a] = s->world_max[a] = 0.0f;
+    std::vector<uint32_t> ranges;
+    build_grid(s, s->world_boxes, ranges);
+    const size_t n_cells = s->grid_cells.size(), n_items = s->grid_items.size();
+    if (!full && (n_cells > s->layout.cap_cells || n_items > s->layout.cap_items)) full = true;  // the grid outgrew its sections
+    if (full) {
+      s->committed = false;
+      s->structure_dirty = true;
+      s->layout = SceneLayout::make(n, s->models.size(), s->n_lds_models, n_cells, n_items);
       if (s->layout.total > s->image_capacity || s->current < 0) {
         // grow (rare: instances were added). Launches that read the old images are done before they go; the new ones are
         // allocated into locals first, so a failed allocation leaves the scene as it was (and the next commit tries again).
@@ -1241,8 +1367,12 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
         }
         if (ge != hipSuccess) {
           for (DustHipScene::Slot& sl : fresh) { if (sl.host) (void)hipHostFree(sl.host); sl.dev.release(); }
+          s->structure_dirty = true;  // (the layout above is not the images': the next commit starts over)
+          s->committed = false;
           return hip_fail(ge, "scene image allocation");
         }
+        s->committed = false;  // no current image until the upload below has succeeded (a frame must not index slot -1)
+        s->structure_dirty = true;
         s->free_images();
         for (int i = 0; i < DustHipScene::kImages; ++i) {
           s->slots[i].dev.p = fresh[i].dev.p; s->slots[i].dev.bytes = fresh[i].dev.bytes;
@@ -1268,18 +1398,26 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     for (size_t i = 0; i < n; ++i)
       if (full || s->dirty[i]) { derive_instance(s, i); s->dirty[i] = 0; }
     // (the record behind the last instance stays zero: the cull reads boxes 64 at a time)
-    const dust::DevInstance* di = reinterpret_cast<const dust::DevInstance*>(img + s->layout.instances);
-    for (int a = 0; a < 3; ++a) { s->world_min[a] = 1e30f; s->world_max[a] = -1e30f; }
-    for (size_t i = 0; i < n; ++i)
-      for (int a = 0; a < 3; ++a) { s->world_min[a] = std::min(s->world_min[a], di[i].wmin[a]); s->world_max[a] = std::max(s->world_max[a], di[i].wmax[a]); }
+    // every instance's block of grid cells into the spare words of its box record (the grid is new: so are the blocks), the grid behind the records
+    {
+      dust::DevBox* bx = reinterpret_cast<dust::DevBox*>(img + s->layout.boxes);
+      dust::DevVisit* vs = reinterpret_cast<dust::DevVisit*>(img + s->layout.visits);
+      for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&bx[i].pad0, &ranges[i * 2], 4); std::memcpy(&bx[i].pad1, &ranges[i * 2 + 1], 4);
+        vs[i].pad0 = bx[i].pad0; vs[i].pad1 = bx[i].pad1;
+      }
+      std::memcpy(img + s->layout.grid_cells, s->grid_cells.data(), s->grid_cells.size() * sizeof(uint32_t));
+      if (n_items) std::memcpy(img + s->layout.grid_items, s->grid_items.data(), n_items * sizeof(uint16_t));
+    }
     // upload: the whole image into the next slot of the ring, on the copy stream, and wait for it here (a ~100 KB copy: ~20 us of host
     // time, none of the launch stream's); frames in flight keep reading the slot they were enqueued with
     if (!s->ctx->copy) HIP_TRY(hipStreamCreateWithFlags(&s->ctx->copy, hipStreamNonBlocking));
     const int slot = int(s->next_slot++ % DustHipScene::kImages);
     DustHipScene::Slot& sl = s->slots[slot];
     if (sl.epoch == s->ctx->sync_epoch) HIP_TRY(sync_stream(s->ctx));  // nobody has waited since a frame last read this slot: the host is a ring ahead
-    std::memcpy(sl.host, img, s->layout.total);
-    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, s->layout.total, hipMemcpyHostToDevice, s->ctx->copy));
+    const size_t used = s->layout.grid_items + n_items * sizeof(uint16_t);  // (the sections' spare room is not sent)
+    std::memcpy(sl.host, img, used);
+    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, used, hipMemcpyHostToDevice, s->ctx->copy));
     HIP_TRY(hipStreamSynchronize(s->ctx->copy));
     s->current = slot;
     ++s->revision;
@@ -1423,6 +1561,23 @@ static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a)
   p->counter_parity[kind] = par ^ 1u;
 }
 
+// The ray stream of pass kind `kind` (0: final gather, 1: surfel pass) for the launch about to be made: its buffers, this launch's
+// ray counter (zero: the previous launch of the kind zeroed it) and the one the next launch will use.
+static void stream_args(DustHipPipeline* p, int kind, dust::FrameArgs& a, float tmin, float tmax) {
+  a.gi.rays = static_cast<dust::DevRay*>(kind == 0 ? p->gi_rays_fg.p : p->gi_rays_sf.p);
+  a.gi.group_count = static_cast<uint32_t*>(kind == 0 ? p->gi_groups_fg.p : p->gi_groups_sf.p);
+  if (kind == 0) {  // a group = a 16 x 16 pixel tile of the band (k_gather_rays)
+    a.gi.n_groups = ((p->width + 15u) / 16u) * ((a.row_end - a.row_begin + 15u) / 16u);
+    a.gi.group_rays = 256;
+  } else {          // a group = 256 consecutive surfels of the (ordered) pool, two rays each (k_surfel_rays)
+    a.gi.n_groups = (p->gi_pool_size + 255u) / 256u;
+    a.gi.group_rays = 512;
+  }
+  a.gi.ray_hits = static_cast<dust::DevGatherHit*>(kind == 0 ? p->gi_fg_hits.p : p->gi_hits_sf.p);
+  a.gi.ray_tmin = tmin; a.gi.ray_tmax = tmax;
+  a.tile_order = nullptr; a.tile_cost = nullptr; a.band_cuts = nullptr;  // (the stream hands out rays, not tiles)
+  a.tiles_x = a.tiles_y = 1;
+}
 // The surfel pass of one frame (surfel.rgen + the spatial hash update) on stream `st`, on at most `resident` workgroup slots.
 static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, uint32_t passes, bool count, hipStream_t st, uint32_t resident) {
   DustHipContext* ctx = p->ctx;
@@ -1433,8 +1588,6 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     if (st != ctx->stream) b.prio_floor = tune.side_prio;
     b.tiles_x = 2 * ((p->gi_pool_size + 63) / 64);
     b.tiles_y = 1;
-    take_counters(p, 3, b);
-    { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
     b.stats = static_cast<dust::DevStats*>(p->stats.p) + 4;
     uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
     uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
@@ -1447,8 +1600,22 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
       b.gi.perm = sv[in_b ? 1 : 0];
     }
-    const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
-    HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+    if (tune.packet_gi) {
+      take_counters(p, 3, b);
+      { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
+      const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
+      HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+    } else {
+      // phase 1 as a ray stream (gi.hip): the pool's rays, compacted -> one ray per lane, lanes refilled -> the hash lookups over the hit records
+      stream_args(p, 1, b, 0.1f, 10000.0f);  // surfel.rgen:33-62
+      take_counters(p, 3, b);
+      HIP_TRY(dust::launch_surfel_rays(b, st));
+      // (one 1024-thread workgroup per CU: sixteen waves share one staged copy of the top-level data)
+      const uint32_t want = (p->gi_pool_size * 2u + 1023u) / 1024u;
+      const uint32_t sgrid = std::max(8u, std::min<uint32_t>((resident * block / 1024u) & ~7u, (want + 7u) & ~7u));
+      HIP_TRY(dust::launch_ray_stream(b, 3, sgrid, 1024, count, st));
+      HIP_TRY(dust::launch_surfel_shade(b, st));
+    }
     // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
     // result of applying them in surfel-index order -- in parallel over independent probe-window clusters (the serial
     // one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
@@ -1511,6 +1678,28 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.root_table = s->dev(s->layout.root_table);
   a.boxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.boxes));
   a.visits = reinterpret_cast<const dust::DevVisit*>(s->dev(s->layout.visits));
+  a.grid = s->grid;
+  a.grid.cells = reinterpret_cast<const uint32_t*>(s->dev(s->layout.grid_cells));
+  a.grid.items = reinterpret_cast<const uint16_t*>(s->dev(s->layout.grid_items));
+  a.enters = reinterpret_cast<const dust::DevEnter*>(s->dev(s->layout.enters));
+  a.stream_refill = p->tune.stream_refill; a.stream_top_iters = p->tune.stream_top_iters;
+  {  // what a ray-stream workgroup stages in LDS behind the roots, in this order, as far as the device's LDS goes (one workgroup per CU)
+    const size_t budget = p->ctx->max_lds - std::min<size_t>(p->ctx->max_lds, size_t(a.n_lds_models) * dust::kN16LdsBytes);
+    size_t at = 0;
+    auto place = [&](size_t bytes) -> uint32_t {
+      bytes = (bytes + 15) & ~size_t(15);
+      if (p->tune.no_stream_lds || at + bytes > budget) return 0xFFFFFFFFu;
+      const uint32_t off = uint32_t(at);
+      at += bytes;
+      return off;
+    };
+    const size_t n_cells = size_t(a.grid.dim[0]) * a.grid.dim[1] * a.grid.dim[2];
+    a.sl.cells = place(n_cells * 4);
+    a.sl.items = place(size_t(a.grid.n_items) * 2);
+    a.sl.boxes = place(size_t(a.n_instances) * 32);
+    a.sl.enters = place(size_t(a.n_instances) * sizeof(dust::DevEnter));
+    a.sl.total = uint32_t(at);
+  }
   for (int k = 0; k < 3; ++k) { a.world_min[k] = s->world_min[k]; a.world_max[k] = s->world_max[k]; }
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
   std::memcpy(a.cam.col2, cam->view_col2, 12); std::memcpy(a.cam.pos, cam->position, 12);
@@ -1659,6 +1848,26 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
+    if (!tune.packet_gi) {
+      // The pass as a ray stream (gi.hip): make the band's gather rays (a thread per pixel) -> trace them one per lane, lanes refilled
+      // (k_ray_stream) -> shade the hit records (a thread per pixel). Rays and hit records touch no GI state: the first two kernels may
+      // run beside the previous frame's surfel pass on the second stream; the shading waits for it (join_side).
+      dust::FrameArgs g = a;
+      stream_args(p, 0, g, 8.0f, a.cam.far_);  // final_gather.rgen:47-50
+      g.gi.fg_hits = g.gi.ray_hits;
+      take_counters(p, 2, g);
+      if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
+      HIP_TRY(dust::launch_gather_rays(g, st));
+      const uint32_t want = uint32_t((size_t(p->width) * (a.row_end - a.row_begin) + 1023u) / 1024u);
+      const uint32_t slots = ctx->side_busy ? frame_slots : resident;  // (a surfel pass beside it keeps its share)
+      const uint32_t ggrid = std::max(8u, std::min<uint32_t>((slots * block / 1024u) & ~7u, (want + 7u) & ~7u));
+      HIP_TRY(dust::launch_ray_stream(g, 2, ggrid, 1024, count, st));
+      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool the shading reads
+      dust::FrameArgs sh = a;   // (pixel order over the band)
+      sh.gi.fg_hits = g.gi.fg_hits;
+      HIP_TRY(dust::launch_final_gather_shade(sh, !sharded, st));
+      if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
+    } else {
     dust::FrameArgs g = a;
     uint32_t ggrid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
     bool pool = false;
@@ -1702,6 +1911,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       sh.gi.fg_hits = g.gi.fg_hits;
       HIP_TRY(dust::launch_final_gather_shade(sh, !sharded, st));
     }
+      }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
     // On the context's second stream, behind this frame's final gather (see DustHipContext::side): the pass is a handful of
@@ -1863,6 +2073,16 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys[0], &p->gi_sort_keys[1], &p->gi_sort_vals[0], &p->gi_sort_vals[1]}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
   HIP_TRY(p->gi_sort_scratch.alloc(dust::radix_sort_scratch_bytes(surfel_pool_size)));
+  // ray streams: a ray per pixel / two per surfel at most, the surfel rays' hit records, the gather rays' (per pixel), the counters
+  {
+    const size_t tiles = size_t((p->width + 15) / 16) * ((p->height + 15) / 16), runs = (size_t(surfel_pool_size) + 255) / 256;
+    HIP_TRY(p->gi_rays_fg.alloc(tiles * 256 * sizeof(dust::DevRay)));
+    HIP_TRY(p->gi_groups_fg.alloc(tiles * 4));
+    HIP_TRY(p->gi_fg_hits.alloc(size_t(p->width) * p->height * sizeof(dust::DevGatherHit)));
+    HIP_TRY(p->gi_rays_sf.alloc(runs * 512 * sizeof(dust::DevRay)));
+    HIP_TRY(p->gi_groups_sf.alloc(runs * 4));
+    HIP_TRY(p->gi_hits_sf.alloc(size_t(surfel_pool_size) * 2 * sizeof(dust::DevGatherHit)));
+  }
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;
   p->gi_touched_rows = 0;  // the exchange buffers follow the pool size: dust_hip_pipeline_gi_exchange re-creates them

@@ -94,7 +94,7 @@ struct DevVisit {  // what a ray needs to test and enter an instance, in one rec
 
 struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, cells_lo, hi.xyz, cells_hi}
   float lo[3], pad0;   // pad0 / pad1 (as bit patterns): the block of top-level grid cells the box is listed in, low and high corner,
-  float hi[3], pad1;   // x | y << 8 | z << 16 (DevGrid); the packet cull ignores them
+  float hi[3], pad1;   // x | y << 9 | z << 18 (DevGrid); the packet cull ignores them
 };
 
 // The top-level structure over the instances (what the reference hands to the driver as a TLAS, accel_struct/tlas.rs:37-117):
@@ -102,13 +102,29 @@ struct DevBox {  // an instance's world bounds, 32 bytes: {lo.xyz, cells_lo, hi.
 // Built on the host by dust_hip_scene_commit, part of the scene image. The per-ray walks of the incoherent passes (gi.hip,
 // k_ray_stream) step through it front to back; up to 256 cells per axis.
 struct DevGrid {
-  DUST_RO(uint32_t) cells;   // dim[0] * dim[1] * dim[2] + 1 offsets into `items`; cell (x, y, z) is entry (z * dim[1] + y) * dim[0] + x
+  DUST_RO(uint32_t) cells;   // per cell {first item : 20 bits, items : 12 bits}; cell (x, y, z) is entry (z * dim[1] + y) * dim[0] + x
   DUST_RO(uint16_t) items;   // instance ids, cell after cell, ascending inside a cell
   float lo[3], hi[3];        // the grid's world box (hi = lo + dim * cell)
   float cell[3], inv_cell[3];
   uint32_t dim[3];
-  uint32_t pad;
+  uint32_t n_items;
 };
+constexpr uint32_t kGridItemBits = 20, kGridMaxCellItems = 4095;
+
+// What a ray needs to enter an instance (walk_begin), 80 bytes = five 16-byte accesses: world -> object, the model's tight
+// bounds (multiples of 4 up to 4096: exact in 16 bits), where its root is staged, and the two arrays a step reads.
+struct DevEnter {
+  float w2o[12];
+  uint16_t bmin[3], bmax[3];
+  uint16_t model;
+  uint8_t lds_slot;      // 255: the root is read from memory
+  uint8_t extent_log2;   // 8 or 12
+  DUST_RO(uint8_t) root;
+  DUST_RO(uint64_t) dense_mask;
+};
+// Where a k_ray_stream workgroup keeps the top-level data in LDS, as byte offsets behind the staged roots (0xFFFFFFFF: the
+// section did not fit and is read from memory): instance boxes (32 B each), grid cells, grid items, enter records
+struct DevStreamLds { uint32_t boxes, cells, items, enters, total; };
 
 // One ray of a ray stream (gi.hip): 32 bytes, written by a ray-making kernel, traced by k_ray_stream, whose hit record goes to
 // ray_hits[id]. flags bit 0: any-hit (terminate on first hit: the surfel pass's sun rays)
@@ -167,9 +183,9 @@ struct DevGI {
   DevGatherHit* fg_hits;    // per pixel: k_final_gather only TRACES and leaves its hits here, k_final_gather_shade does the hash lookups and
                             // stores afterwards (null: the gather kernel shades its own rays)
   // ray streams (k_gather_rays / k_surfel_rays -> k_ray_stream -> k_final_gather_shade / k_surfel_shade)
-  DevRay* rays;             // the pass's rays, compacted (live rays only), neighbours in the frame / the pool next to each other
-  uint32_t* ray_count;      // how many: counted by the ray-making kernel, read by k_ray_stream
-  uint32_t* next_ray_count; // the counter the NEXT launch of this pass kind uses: the ray-making kernel zeroes it
+  DevRay* rays;             // the pass's rays in GROUPS: group g (a 16 x 16 pixel tile / 256 consecutive surfels) owns entries
+  uint32_t* group_count;    //   [g * group_rays, g * group_rays + group_count[g]): its live rays, compacted inside the group
+  uint32_t n_groups, group_rays;  // (no atomics, and the same order in every run)
   DevGatherHit* ray_hits;   // [ray id]: pixel index for gather rays (== fg_hits), 2 * surfel + kind for surfel rays
   float ray_tmin, ray_tmax; // gl_RayTminEXT / gl_RayTmaxEXT of the pass (final_gather.rgen:47, surfel.rgen:33-62)
 };
@@ -183,6 +199,10 @@ struct FrameArgs {
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}
+  DUST_RO(DevEnter) enters;     // n_instances compact enter records (the ray streams' instance set-up)
+  DevStreamLds sl;              // k_ray_stream: what is staged in LDS behind the roots
+  uint32_t stream_refill;       // k_ray_stream: lanes not walking at which a wave leaves the walk to do their top-level work (DUST_HIP_STREAM_REFILL)
+  uint32_t stream_top_iters;    // ... and the grid steps + box tests a lane may take in one such phase (DUST_HIP_STREAM_TOP_ITERS)
   float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];

@@ -667,6 +667,440 @@ __global__ void k_surfel_apply_racy(const FrameArgs) {
   }
 }
 
+// ==================================================================== ray streams: one ray per lane, lanes refilled
+// The incoherent passes -- final gather and surfel rays: neighbouring rays point anywhere -- as the reference's hardware runs
+// them: every ray on its own (final_gather.rgen:14-52, surfel.rgen:12-67 launch one invocation per ray; the TLAS of
+// accel_struct/tlas.rs:37-117 finds each ray its instances). Three kernels per pass instead of one:
+//   1. a ray-making kernel, a thread per pixel / surfel at full occupancy: the pass's live rays, compacted, 32 bytes each;
+//   2. k_ray_stream, persistent: a wavefront is 64 LANES that each carry one ray. A lane walks the top-level grid (DevGrid)
+//      front to back, cell by cell; every instance listed in a cell whose box its ray meets is entered (walk_begin) and walked
+//      (walk_step: trace_instance's loop body, verbatim); a finished ray's hit record is stored and the lane takes the next ray
+//      of the stream. A trip of the wave's loop steps every walking lane; when enough lanes are NOT walking, they do their
+//      top-level work together -- fetch, grid steps and box tests, then the instance set-ups in one go. This is north_star's
+//      "compaction of active rays": a lane never waits for the longest ray of a packet, only for the phase its neighbours are in;
+//   3. a shading kernel over the hit records, a thread per pixel / surfel at full occupancy: the hash lookups with their
+//      dependent chain instance -> block -> hash probe, and all stores, coalesced.
+// What a ray computes is what trace_ray / trace_instance compute for it: the same brick tests on a superset of the bricks
+// that can be accepted, the same tie rule. Only who shares a wavefront with whom changes -- never a result.
+//
+// Top-level walk. A lane steps through the grid's cells along its ray (one axis per step, exit planes from integer cell
+// coordinates). The instances of a cell are taken in list order; an instance is skipped when the PREVIOUS cell of the path
+// lies inside the block of cells the instance is listed in: it was dealt with there. (The cells of a block that lie on a
+// monotone path are consecutive, so "listed in the previous cell" is the same as "listed in any earlier cell"; the block rides
+// in the box record's spare words.) A ray is over when it has a hit in front of the current cell's exit -- every instance not
+// yet looked at is listed only in cells beyond it --, when it leaves the grid or its own [tmin, tmax], or (any-hit rays) at the
+// first hit. Boxes are grown by kGridMargin of the scene's size when they are listed (capi.cpp, build_grid): far more than
+// the rounding of the cell steps, so a ray that grazes a cell the steps skipped meets no box listed only there.
+enum : uint32_t { RS_EMPTY = 0, RS_FETCH, RS_TOP, RS_BEGIN, RS_WALK, RS_DONE };
+#ifndef DUST_STREAM_CHUNK
+#define DUST_STREAM_CHUNK 64  // rays a wave takes from its band's counter at a time
+#endif
+constexpr uint32_t kStreamChunk = DUST_STREAM_CHUNK;
+constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+
+// Cell coordinates travel as one word with a guard bit above every 8-bit field: x | y << 9 | z << 18, guards at bits 8, 17, 26.
+// "p inside the block [lo, hi]" is then two subtractions: ((p | G) - lo) keeps a field's guard bit iff p >= lo there (no borrow
+// leaves a field: 256 + p - lo fits its nine bits), likewise ((hi | G) - p).
+constexpr uint32_t kCellGuard = (1u << 8) | (1u << 17) | (1u << 26);
+struct TopState {
+  uint32_t cell, prev;  // packed as above; prev = the path's previous cell (kNoCell: none)
+  uint32_t cur, end;    // what is left of the cell's instance list (indices into DevGrid::items)
+  float t_end;          // where the ray leaves the grid or its tmax
+};
+__device__ __forceinline__ uint32_t grid_index(const DUST_CONST_AS DevGrid& g, uint32_t c) {
+  return ((c >> 18) * g.dim[1] + ((c >> 9) & 255u)) * g.dim[0] + (c & 255u);
+}
+__device__ __forceinline__ void open_cell(ArgsRef a, uint32_t c, TopState& ts) {
+  const uint32_t idx = grid_index(a.grid, c);
+  const uint32_t packed = a.sl.cells != 0xFFFFFFFFu ? reinterpret_cast<const uint32_t*>(g_lds + a.n_lds_models * kN16LdsBytes + a.sl.cells)[idx] : a.grid.cells[idx];
+  ts.cur = packed & ((1u << kGridItemBits) - 1u);
+  ts.end = ts.cur + (packed >> kGridItemBits);
+}
+// the ray's first cell; false: the ray misses the grid (no instance can be hit)
+__device__ __forceinline__ bool top_begin(ArgsRef a, V3 o, V3 d, V3 inv, float tmin, float tmax, TopState& ts) {
+  const DUST_CONST_AS DevGrid& g = a.grid;
+  float te, tx;
+  if (!slab_box(o, d, inv, g.lo, g.hi, te, tx)) return false;
+  const float t0 = fmaxf(fmaxf(te, tmin * (1.0f - 1e-5f)), 0.0f);
+  const float t1 = fminf(tx, tmax);
+  ts.t_end = t1 * (1.0f + 1e-5f) + 1e-3f;
+  if (!(t0 <= ts.t_end)) return false;  // (NaN rays end here too)
+  const float p[3] = {o.x + d.x * t0, o.y + d.y * t0, o.z + d.z * t0};
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c |= (uint32_t)f2i_clamp(floorf((p[k] - g.lo[k]) * g.inv_cell[k]), 0, (int)g.dim[k] - 1) << (9 * k);
+  ts.cell = c;
+  ts.prev = kNoCell;
+  open_cell(a, c, ts);
+  return true;
+}
+// About `budget` grid steps / box tests. Returns RS_BEGIN with `inst` = an instance to enter, RS_DONE when the ray is over, RS_TOP when
+// the budget ran out first. Two loops in turn, so that a wave's lanes share the code they run: (A) step from cell to cell until
+// one lists something, (B) test what the cell lists.
+// zero_axis (wave-uniform): some ray of the wave has a zero direction component -- the box tests then take the general slab test
+__device__ __forceinline__ uint32_t top_next(ArgsRef a, V3 o, V3 d, V3 inv, float tmax, const Hit& best, TopState& ts, uint32_t& inst,
+                                             uint32_t budget, bool zero_axis) {
+  const DUST_CONST_AS DevGrid& g = a.grid;
+  unsigned char* lbase = g_lds + a.n_lds_models * kN16LdsBytes;
+  const bool lds_items = a.sl.items != 0xFFFFFFFFu, lds_boxes_ = a.sl.boxes != 0xFFFFFFFFu;
+  for (uint32_t it = 0; it < budget;) {
+    while (ts.cur >= ts.end) {  // (A) on to the next cell: the exit planes from the integer cell coordinates, one axis per step (a tie takes
+      it += 1u;                 //     the lower axis now, the other one on the next step, at the same t). Selects only: no branch inside
+      PROF_COUNT_LANES(P_L_EMPTY4, true);
+      const uint32_t c0 = ts.cell & 255u, c1 = (ts.cell >> 9) & 255u, c2 = (ts.cell >> 18) & 255u;
+      const bool p0 = d.x > 0.0f, p1 = d.y > 0.0f, p2 = d.z > 0.0f;
+      const float q0 = (g.lo[0] + (float)(c0 + (p0 ? 1u : 0u)) * g.cell[0] - o.x) * inv.x;
+      const float q1 = (g.lo[1] + (float)(c1 + (p1 ? 1u : 0u)) * g.cell[1] - o.y) * inv.y;
+      const float q2 = (g.lo[2] + (float)(c2 + (p2 ? 1u : 0u)) * g.cell[2] - o.z) * inv.z;
+      const float t0 = d.x != 0.0f ? q0 : INFINITY, t1 = d.y != 0.0f ? q1 : INFINITY, t2 = d.z != 0.0f ? q2 : INFINITY;
+      const float tn = fminf(fminf(t0, t1), t2);
+      const bool a0 = t0 <= t1 && t0 <= t2, a1 = !a0 && t1 <= t2;  // the stepping axis: 0, else 1, else 2
+      const uint32_t step = a0 ? 1u : (a1 ? 1u << 9 : 1u << 18);
+      const uint32_t ca = a0 ? c0 : (a1 ? c1 : c2), da = a0 ? g.dim[0] : (a1 ? g.dim[1] : g.dim[2]);
+      const bool up = a0 ? p0 : (a1 ? p1 : p2);
+      const bool edge = up ? ca + 1u >= da : ca == 0u;
+      // over: no axis moves (a zero or NaN direction), what is left lies behind the hit, the ray's end, the grid's edge
+      if (!(tn < INFINITY) || (best.found && best.t < tn * (1.0f - 1e-5f) - 1e-4f) || tn > ts.t_end || edge) return RS_DONE;
+      ts.prev = ts.cell;
+      ts.cell = up ? ts.cell + step : ts.cell - step;
+      open_cell(a, ts.cell, ts);
+      if (it >= budget) return RS_TOP;
+    }
+    while (ts.cur < ts.end) {  // (B) the cell's instances
+      it += 1u;
+      PROF_COUNT_LANES(P_L_BRICK, true);
+      const uint32_t ii = lds_items ? reinterpret_cast<const uint16_t*>(lbase + a.sl.items)[ts.cur] : a.grid.items[ts.cur];
+      ts.cur += 1u;
+      f32x4 blo, bhi;
+      if (lds_boxes_) { const f32x4* lb = reinterpret_cast<const f32x4*>(lbase + a.sl.boxes); blo = lb[ii * 2u]; bhi = lb[ii * 2u + 1u]; }
+      else { blo = *(DUST_RO(f32x4))(&a.boxes[ii].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ii].hi[0]); }
+      // listed in the cell the ray came from: dealt with there (prev == kNoCell has every guard bit and more: never "inside")
+      const uint32_t rl = __float_as_uint(blo.w), rh = __float_as_uint(bhi.w);
+      const bool seen = ts.prev != kNoCell && ((((ts.prev | kCellGuard) - rl) & ((rh | kCellGuard) - ts.prev)) & kCellGuard) == kCellGuard;
+      const float lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
+      float te, tx;
+      const bool box = zero_axis ? slab_box(o, d, inv, lo, hi, te, tx) : slab_box_nonzero(o, inv, lo, hi, te, tx);
+      const float limit = best.found ? best.t : tmax;
+      if (!seen && box && !(te * (1.0f - 2e-6f) > limit)) { inst = ii; return RS_BEGIN; }
+      if (it >= budget) break;
+    }
+  }
+  return RS_TOP;
+}
+// the workgroup's LDS: the roots (as stage_roots), and behind them whatever of the top-level data fits (FrameArgs::sl)
+__device__ __forceinline__ void stage_stream(ArgsRef a) {
+  prof_begin();
+  if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
+  auto copy16 = [](unsigned char* dst, const DUST_CONST_AS void* src, uint32_t bytes) {  // bytes: a multiple of 16 (the image's sections are padded)
+    DUST_RO(u32x4) s4 = (DUST_RO(u32x4))src;
+    u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+    const uint32_t n = bytes / 16u, step = blockDim.x;
+    uint32_t i = threadIdx.x;
+    for (; i + 3u * step < n; i += 4u * step) {
+      const u32x4 v0 = s4[i], v1 = s4[i + step], v2 = s4[i + 2u * step], v3 = s4[i + 3u * step];
+      d4[i] = v0; d4[i + step] = v1; d4[i + 2u * step] = v2; d4[i + 3u * step] = v3;
+    }
+    for (; i < n; i += step) d4[i] = s4[i];
+  };
+  copy16(g_lds, a.root_table, a.n_lds_models * kN16LdsBytes);
+  unsigned char* base = g_lds + a.n_lds_models * kN16LdsBytes;
+  const uint32_t n_cells = a.grid.dim[0] * a.grid.dim[1] * a.grid.dim[2];
+  if (a.sl.boxes != 0xFFFFFFFFu) copy16(base + a.sl.boxes, a.boxes, a.n_instances * 32u);
+  if (a.sl.cells != 0xFFFFFFFFu) copy16(base + a.sl.cells, a.grid.cells, (n_cells * 4u + 15u) & ~15u);
+  if (a.sl.items != 0xFFFFFFFFu) copy16(base + a.sl.items, a.grid.items, (a.grid.n_items * 2u + 15u) & ~15u);
+  if (a.sl.enters != 0xFFFFFFFFu) copy16(base + a.sl.enters, a.enters, a.n_instances * (uint32_t)sizeof(DevEnter));
+  __syncthreads();
+  PROF_LEAVE(P_STAGE);
+}
+
+// RT 2: gather rays (rough.rint, closest hit), RT 3: surfel rays (closest hit, or any hit where DevRay::flags bit 0 is set).
+// Statistics slots (counting build): rays without the any-hit flag -> stats[0] for RT 2 / stats[1] for RT 3, any-hit rays -> stats[0].
+template <int RT, int MODE>
+__global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_stream(a0);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t lower = (1ull << lane) - 1ull;
+  const float tmin = a0.gi.ray_tmin, tmax = a0.gi.ray_tmax;
+  // The stream's groups (tiles of the frame / runs of the pool) are cut into chunks of about kStreamChunk rays; the chunks form
+  // eight bands, one per XCD (block b runs on XCD b % 8: a band's rays -- neighbours in the frame or the pool -- stay in one L2).
+  // A wave takes a chunk at a time from its band's counter, then helps the other bands.
+  const uint32_t sub = a0.gi.group_rays / kStreamChunk;        // chunks per group
+  const uint32_t chunks = a0.gi.n_groups * sub;
+  const uint32_t per = (chunks + kRegions - 1u) / kRegions;   // chunks per band
+  const uint32_t own = blockIdx.x & 7u;
+  uint32_t win_next = 0, win_end = 0, band_try = 0;
+  bool dry = chunks == 0u;
+  uint32_t state = RS_EMPTY;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+  uint32_t rid = 0, rflags = 0, pend = 0;
+  Hit best;
+  best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
+  TopState ts;
+  ts.cell = 0; ts.prev = kNoCell; ts.cur = ts.end = 0; ts.t_end = 0.0f;
+  WalkState w;
+  w.o = w.d = w.inv = mk(0, 0, 0); w.t = w.tx_stop = w.near_tol = 0.0f; w.ijk[0] = w.ijk[1] = w.ijk[2] = 0;
+  w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0; w.inst = 0;
+  w.lds_slot = -1; w.extent = 0; w.root = nullptr; w.dense_mask = nullptr;
+  LaneStats cur = {0, 0, 0, 0, 0, 0}, st_closest = {0, 0, 0, 0, 0, 0}, st_any = {0, 0, 0, 0, 0, 0};
+  u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};  // a ray on its way into the lane (RS_FETCH)
+  for (uint32_t trip = 0; trip < (1u << 26); ++trip) {  // (the bound is a fuse: every phase below makes progress)
+    PROF_COUNT(P_CAND, 1);
+    // ---- empty lanes ask for the stream's next rays, in lane order: the loads are issued here and land while the others walk
+    {
+      const uint64_t b_empty = __ballot(state == RS_EMPTY);
+      if (b_empty != 0ull && !dry) {
+        ArgsRef a = reload_args(a0);
+        PROF_ENTER(P_GRAB);
+        PROF_COUNT(P_N_TRACES, 1);
+        if (win_next == win_end) {  // the wave's chunk is used up: the next one of this band, or of the next band that has any
+          dry = true;
+          while (band_try < kRegions) {
+            const uint32_t band = (own + band_try) & 7u;
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd((uint32_t*)&a.work_counters[band * kCounterStride], 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            const uint32_t c = band * per + k;
+            if (k >= per || c >= chunks) { band_try += 1u; continue; }
+            // chunk c = part c % sub of group c / sub: the group's live rays in `sub` equal parts
+            const uint32_t grp = c / sub, part = c - grp * sub;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gi.group_count[grp]);
+            const uint32_t q = (cnt + sub - 1u) / sub;
+            const uint32_t lo = grp * a.gi.group_rays + part * q, hi = grp * a.gi.group_rays + min(cnt, (part + 1u) * q);
+            if (lo < hi) { win_next = lo; win_end = hi; dry = false; break; }
+          }
+        }
+        if (!dry) {
+          const uint32_t rank = (uint32_t)__popcll(b_empty & lower);
+          if (state == RS_EMPTY && win_next + rank < win_end) {
+            f0 = reinterpret_cast<const u32x4*>(a.gi.rays)[(size_t)(win_next + rank) * 2u];
+            f1 = reinterpret_cast<const u32x4*>(a.gi.rays)[(size_t)(win_next + rank) * 2u + 1u];
+            state = RS_FETCH;
+            PROF_COUNT_LANES(P_N_CAND, true);
+          }
+          win_next = min(win_end, win_next + (uint32_t)__popcll(b_empty));
+        }
+        PROF_LEAVE(P_GRAB);
+      }
+    }
+    if (state == RS_WALK) {
+      PROF_ENTER(P_INSTANCE);
+      PROF_COUNT(P_N_STEPS, 1);
+      PROF_COUNT_LANES(P_L_TRIPS, true);
+      const DUST_CONST_AS DevVisit& v = a0.visits[w.inst];
+      if (walk_step<RT, MODE>(w, &v.m, tmin, tmax, (rflags & 1u) != 0u, best, cur)) state = RS_TOP;
+      PROF_LEAVE(P_INSTANCE);
+    }
+    const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == RS_WALK));
+    if (n_walk > 64u - a0.stream_refill) continue;
+    ArgsRef a = reload_args(a0);
+    if (state == RS_FETCH) {  // the ray has arrived
+      o = mk(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z));
+      d = mk(__uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z));
+      rid = f0.w; rflags = f1.w;
+      best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
+      if (COUNT) { cur.rays = 1; cur.instances_tested = cur.upper_descents = cur.mid_descents = cur.bricks_tested = cur.hits = 0; }
+      // world-space reciprocals feed only the conservative box tests (1e-5 slack): v_rcp_f32's 1 ulp is enough
+      const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+      state = top_begin(a, o, d, inv, tmin, tmax, ts) ? RS_TOP : RS_DONE;
+    }
+    // ---- top-level walk of the lanes that are between two instances
+    if (state == RS_TOP) {
+      PROF_ENTER(P_CULL);
+      PROF_COUNT(P_N_CAND_ITER, 1);
+      PROF_COUNT_LANES(P_AO_SETUP, true);
+      if ((rflags & 1u) && best.found) state = RS_DONE;
+      else {
+        const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        const bool zero_axis = __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this phase)
+        state = top_next(a, o, d, inv, tmax, best, ts, pend, a.stream_top_iters, zero_axis);
+      }
+      PROF_LEAVE(P_CULL);
+    }
+    if (state == RS_DONE) {  // the ray's hit record; the lane is free
+      u32x4 rec;
+      rec.x = __float_as_uint(best.t); rec.y = best.inst; rec.z = best.block; rec.w = best.found ? 1u : 0u;
+      reinterpret_cast<u32x4*>(a.gi.ray_hits)[rid] = rec;
+      if (COUNT) {
+        if (best.found) cur.hits = 1;
+        if (rflags & 1u) add_stats(st_any, cur); else add_stats(st_closest, cur);
+      }
+      state = RS_EMPTY;
+    }
+    // ---- the instance set-ups, together
+    if (state == RS_BEGIN) {
+      PROF_ENTER(P_SETUP);
+      PROF_COUNT(P_N_VISITS, 1);
+      PROF_COUNT_LANES(P_PRIMARY_SHADE, true);
+      if (COUNT) cur.instances_tested += 1;
+      // the instance's enter record: five 16-byte reads, from LDS where it is staged
+      u32x4 e0, e1, e2, e3, e4;
+      if (a.sl.enters != 0xFFFFFFFFu) {
+        const u32x4* le = reinterpret_cast<const u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + a.sl.enters) + pend * 5u;
+        e0 = le[0]; e1 = le[1]; e2 = le[2]; e3 = le[3]; e4 = le[4];
+      } else {
+        DUST_RO(u32x4) ge = (DUST_RO(u32x4))(a.enters + pend);
+        e0 = ge[0]; e1 = ge[1]; e2 = ge[2]; e3 = ge[3]; e4 = ge[4];
+      }
+      const float m[12] = {__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z), __uint_as_float(e0.w),
+                           __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w),
+                           __uint_as_float(e2.x), __uint_as_float(e2.y), __uint_as_float(e2.z), __uint_as_float(e2.w)};
+      EnterView ev;
+      ev.bmin[0] = (float)(e3.x & 0xFFFFu); ev.bmin[1] = (float)(e3.x >> 16); ev.bmin[2] = (float)(e3.y & 0xFFFFu);
+      ev.bmax[0] = (float)(e3.y >> 16); ev.bmax[1] = (float)(e3.z & 0xFFFFu); ev.bmax[2] = (float)(e3.z >> 16);
+      const uint32_t slot = (e3.w >> 16) & 255u;
+      ev.lds_slot = slot == 255u ? -1 : (int32_t)slot;
+      ev.extent = 1u << (e3.w >> 24);
+      ev.root = (DUST_RO(uint8_t))(((uint64_t)e4.y << 32) | e4.x);
+      ev.dense_mask = (DUST_RO(uint64_t))(((uint64_t)e4.w << 32) | e4.z);
+      const V3 oo = mk(((m[0] * o.x + m[1] * o.y) + m[2] * o.z) + m[3], ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7],
+                       ((m[8] * o.x + m[9] * o.y) + m[10] * o.z) + m[11]);
+      const V3 od = mk((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z, (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
+      state = walk_begin<RT, MODE>(w, ev, pend, oo, od, tmin) ? RS_WALK : RS_TOP;
+      PROF_LEAVE(P_SETUP);
+    }
+    if (dry && !__any(state != RS_EMPTY)) break;
+  }
+  prof_end();
+  if (RT == 2) flush_stats<MODE>(a0, 0, st_closest);
+  else { flush_stats<MODE>(a0, 0, st_any); flush_stats<MODE>(a0, 1, st_closest); }
+}
+
+// A workgroup's place in its group of the stream: `first` / `second` say which of its two possible rays a thread has. Returns the
+// thread's first position inside the group (thread order: wave ballots and a scan over the waves' totals); thread 0 writes the
+// group's count. Every thread of the workgroup calls it.
+__device__ __forceinline__ uint32_t group_reserve(uint32_t* group_count, bool first, bool second) {
+  __shared__ uint32_t wave_total[16];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const uint64_t lower = (1ull << lane) - 1ull;
+  const uint64_t b1 = __ballot(first), b2 = __ballot(second);
+  if (lane == 0) wave_total[wave] = (uint32_t)(__popcll(b1) + __popcll(b2));
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (uint32_t i = 0; i < n_waves; ++i) { const uint32_t c = wave_total[i]; if (i < wave) before += c; all += c; }
+  if (threadIdx.x == 0) *group_count = all;
+  return before + (uint32_t)(__popcll(b1 & lower) + __popcll(b2 & lower));
+}
+
+// final_gather.rgen:14-44 for every pixel of the band: the frame's gather rays, 16 x 16 pixel tile by tile
+__global__ void __launch_bounds__(256) k_gather_rays(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t tiles_x = (a.width + 15u) / 16u;
+  const uint32_t ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const uint32_t px = tx * 16u + (threadIdx.x & 15u), py = a.row_begin + ty * 16u + (threadIdx.x >> 4);
+  V3 inval, loc, ad;
+  const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
+  const uint32_t at = blockIdx.x * 256u + group_reserve(a.gi.group_count + blockIdx.x, live, false);
+  if (live) {
+    u32x4 r0, r1;
+    r0.x = __float_as_uint(loc.x); r0.y = __float_as_uint(loc.y); r0.z = __float_as_uint(loc.z); r0.w = py * a.width + px;
+    r1.x = __float_as_uint(ad.x); r1.y = __float_as_uint(ad.y); r1.z = __float_as_uint(ad.z); r1.w = 0u;
+    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u] = r0;
+    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u + 1u] = r1;
+  }
+}
+
+// surfel.rgen:12-67: where surfel i's two rays start and where they point. Returns false for a dead slot.
+struct SurfelRays { V3 n, org, cos_dir; bool lit; };
+__device__ __forceinline__ bool surfel_rays(ArgsRef a, uint32_t i, const DevSurfel& e, SurfelRays& r) {
+  const bool live = e.direction < 6u;
+  r.n = faceid2normal(live ? e.direction : 0u);
+  r.org = mk(e.x + 2.01f * r.n.x, e.y + 2.01f * r.n.y, e.z + 2.01f * r.n.z);
+  r.cos_dir = mk(0, 0, 1);
+  r.lit = live && dot3(mk(a.sky[48], a.sky[49], a.sky[50]), r.n) > 0.0f;
+  if (live) {
+    const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+    const uint32_t tex = ((DUST_RO(uint32_t))a.noise5)[((ny0 + 47u + a.rand) % 128u) * 128u + ((nx0 + 16u + a.rand) % 128u)];
+    const V3 ns = mk(div_const((float)(tex & 255u), 255.0f) * 2.0f - 1.0f, div_const((float)((tex >> 8) & 255u), 255.0f) * 2.0f - 1.0f,
+                     div_const((float)((tex >> 16) & 255u), 255.0f) * 2.0f - 1.0f);
+    r.cos_dir = normalize3(rotate_by_normal(r.n, ns));
+  }
+  return live;
+}
+// the surfel pass's rays, in the pool's position order (gi.perm) or pool order: per live surfel the cosine ray (id 2 i), and the
+// sun ray (id 2 i + 1, any-hit) where the sun is above the surfel's face
+__global__ void __launch_bounds__(256) k_surfel_rays(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;
+  const bool in_range = slot < a.gi.pool_size && i < a.gi.pool_size;
+  DevSurfel e;
+  e.x = e.y = e.z = 0.0f; e.direction = 0xFFFFFFFFu;
+  if (in_range) e = a.gi.pool[i];
+  SurfelRays r;
+  const bool live = surfel_rays(a, i, e, r) && in_range;
+  const bool lit = live && r.lit;
+  const uint32_t at = blockIdx.x * 512u + group_reserve(a.gi.group_count + blockIdx.x, live, lit);
+  if (live) {
+    u32x4 r0, r1;
+    r0.x = __float_as_uint(r.org.x); r0.y = __float_as_uint(r.org.y); r0.z = __float_as_uint(r.org.z); r0.w = 2u * i;
+    r1.x = __float_as_uint(r.cos_dir.x); r1.y = __float_as_uint(r.cos_dir.y); r1.z = __float_as_uint(r.cos_dir.z); r1.w = 0u;
+    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u] = r0;
+    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u + 1u] = r1;
+    if (lit) {
+      r0.w = 2u * i + 1u;
+      r1.x = __float_as_uint(a.sun_dir[0]); r1.y = __float_as_uint(a.sun_dir[1]); r1.z = __float_as_uint(a.sun_dir[2]); r1.w = 1u;
+      reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)(at + 1u) * 2u] = r0;
+      reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)(at + 1u) * 2u + 1u] = r1;
+    }
+  }
+}
+// surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27 over the hit records: a thread per surfel, in pool order --
+// what k_surfel_trace does behind its trace, with the hash probes of a whole workgroup in flight together
+__global__ void __launch_bounds__(256) k_surfel_shade(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.gi.pool_size) return;
+  const DevSurfel e = a.gi.pool[i];
+  SurfelRays r;
+  const bool live = surfel_rays(a, i, e, r);
+  const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
+  f32x4 pay = {0.0f, 0.0f, 0.0f, 0.0f};
+  DevHashRequest rq;
+  rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
+  DevSurfel repl;
+  repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
+  if (live) {
+    if (r.lit) {  // surfel/nee.rmiss:15-27
+      const u32x4 hs = reinterpret_cast<const u32x4*>(a.gi.ray_hits)[2u * i + 1u];
+      if (hs.w == 0u) {
+        const float dn = dot3(r.n, sd);
+        pay.x = a.sun_term[0] * dn; pay.y = a.sun_term[1] * dn; pay.z = a.sun_term[2] * dn;
+      }
+    }
+    const u32x4 hc = reinterpret_cast<const u32x4*>(a.gi.ray_hits)[2u * i];
+    Hit h;
+    h.t = __uint_as_float(hc.x); h.inst = hc.y; h.block = hc.z; h.voxel = 0; h.found = hc.w != 0u;
+    rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
+    rq.dir_flags = e.direction & 0xFFu;
+    if (!h.found) {  // surfel.rmiss:14-26
+      const V3 sk = sky_radiance(a.sky, normalize3(r.cos_dir));
+      rq.vx = sk.x; rq.vy = sk.y; rq.vz = sk.z;
+      rq.dir_flags |= 0x100u;
+    } else {         // surfel.rchit:35-102
+      HashKey key;
+      DevSurfel sf;
+      uint32_t alb;
+      brick_surfel(a, h, r.org, r.cos_dir, key, sf, alb);
+      V3 rad;
+      uint32_t count = 0, entry;
+      const bool found = hash_get(a.gi, key, a.frame_index, rad, count, entry);
+      const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
+      const float rnd0 = div_const((float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)], 255.0f);
+      if (found) {
+        rad = modulate_by_avg_albedo(rad, alb);
+        rq.vx = rad.x; rq.vy = rad.y; rq.vz = rad.z;
+        rq.dir_flags |= 0x100u;
+      } else if (rnd0 > 1.0f / (float)(count + 2u)) {
+        repl = sf;
+      }
+    }
+  }
+  reinterpret_cast<f32x4*>(a.gi.sun_payload)[i] = pay;
+  a.gi.requests[i] = rq;
+  a.gi.replacement[i] = repl;
+}
+
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_gi_export, dim3(512), dim3(256), 0, s, a);
   return hipGetLastError();
@@ -710,11 +1144,40 @@ hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(k_surfel_apply_clusters, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }
+hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t s) {
+  const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.row_end - a.row_begin + 15u) / 16u);
+  hipLaunchKernelGGL(k_gather_rays, dim3(tiles), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_rays(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_rays, dim3((a.gi.pool_size + 255u) / 256u), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_shade, dim3((a.gi.pool_size + 255u) / 256u), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+// rt 2: gather rays, 3: surfel rays; the stream is a.gi.rays / group_count, the hit records go to a.gi.ray_hits
+hipError_t launch_ray_stream(const FrameArgs& a_in, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = (size_t)a_in.n_lds_models * kN16LdsBytes + a_in.sl.total;
+  const FrameArgs a = with_schedule(a_in, grid, block);
+  const int mode = (count ? 1 : 0) | (a.deep ? 2 : 0);
+#define DUST_STREAM_CASE(RT_, M_) hipLaunchKernelGGL((k_ray_stream<RT_, M_>), dim3(grid), dim3(block), lds, s, a)
+  if (rt == 2) {
+    switch (mode) { case 0: DUST_STREAM_CASE(2, 0); break; case 1: DUST_STREAM_CASE(2, 1); break; case 2: DUST_STREAM_CASE(2, 2); break; default: DUST_STREAM_CASE(2, 3); break; }
+  } else {
+    switch (mode) { case 0: DUST_STREAM_CASE(3, 0); break; case 1: DUST_STREAM_CASE(3, 1); break; case 2: DUST_STREAM_CASE(3, 2); break; default: DUST_STREAM_CASE(3, 3); break; }
+  }
+#undef DUST_STREAM_CASE
+  return hipGetLastError();
+}
 hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_kernels left after the build's static LDS)
   const void* fns[] = {
       (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
       (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>,
-      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>};
+      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>,
+      (const void*)k_ray_stream<2, 0>, (const void*)k_ray_stream<2, 1>, (const void*)k_ray_stream<2, 2>, (const void*)k_ray_stream<2, 3>,
+      (const void*)k_ray_stream<3, 0>, (const void*)k_ray_stream<3, 1>, (const void*)k_ray_stream<3, 2>, (const void*)k_ray_stream<3, 3>};
   for (const void* f : fns) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;
@@ -723,3 +1186,13 @@ hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_k
 }
 
 }  // namespace dust
+
+#ifdef DUST_PROFILE
+extern "C" int dust_gi_profile_read(unsigned long long* out, int n) {  // profiling build only: this translation unit's section buckets, read and cleared
+  unsigned long long h[dust::kProfBuckets] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dust::g_prof_out), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < dust::kProfBuckets; ++i) out[i] = h[i];
+  unsigned long long z[dust::kProfBuckets] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_prof_out), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif

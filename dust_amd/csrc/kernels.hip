@@ -719,10 +719,12 @@ extern "C" int dust_hip_wave_times(unsigned long long* out) {  // 8192 x 6, of t
 #endif
 #ifdef DUST_PROFILE
 // profiling build only (tools/kernel_sections.py): read and clear the section cycle counters
+extern "C" int dust_gi_profile_read(unsigned long long* out, int n);  // gi.hip's copy of the buckets
 extern "C" int dust_hip_profile_read(unsigned long long* out, int n) {
-  unsigned long long h[dust::kProfBuckets] = {};
+  unsigned long long h[dust::kProfBuckets] = {}, g[dust::kProfBuckets] = {};
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dust::g_prof_out), sizeof h) != hipSuccess) return -1;
-  for (int i = 0; i < n && i < dust::kProfBuckets; ++i) out[i] = h[i];
+  if (dust_gi_profile_read(g, dust::kProfBuckets) != 0) return -1;
+  for (int i = 0; i < n && i < dust::kProfBuckets; ++i) out[i] = h[i] + g[i];
   unsigned long long z[dust::kProfBuckets] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_prof_out), z, sizeof z) == hipSuccess ? 0 : -1;
 }

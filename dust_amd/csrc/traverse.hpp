@@ -1135,8 +1135,16 @@ struct ModelLite {  // the two-level part of a DevModel, as find_brick reads it
   DUST_RO(DevL2Cell) l2_cells;
 };
 // trace_instance's prologue: false when the ray misses the model's bounds
-template <int RT, int MODE>
-__device__ __forceinline__ bool walk_begin(WalkState& w, ModelRef m, uint32_t inst, V3 o, V3 d, float tmin) {
+// (Model: a DevModel record, or any view with its bmin / bmax / lds_slot / extent / root / dense_mask members: EnterView)
+struct EnterView {
+  float bmin[3], bmax[3];
+  int32_t lds_slot;
+  uint32_t extent;
+  DUST_RO(uint8_t) root;
+  DUST_RO(uint64_t) dense_mask;
+};
+template <int RT, int MODE, class Model>
+__device__ __forceinline__ bool walk_begin(WalkState& w, const Model& m, uint32_t inst, V3 o, V3 d, float tmin) {
   w.o = o; w.d = d; w.inst = inst;
   w.lds_slot = m.lds_slot; w.extent = m.extent; w.root = m.root; w.dense_mask = m.dense_mask;
   w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);

@@ -7,7 +7,7 @@ CSRC = os.path.join(ROOT, "dust_amd", "csrc")
 tag = sys.argv[1] if len(sys.argv) > 1 else "rNN"
 print(f"# dust_amd/csrc/*.hip code objects (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage), {tag}")
 print(f"{'kernel':<58}{'VGPR':>5}{'SGPR':>6}{'scratch B/lane':>15}{'SGPR spill':>11}{'VGPR spill':>11}{'waves/SIMD':>11}")
-for src in ("kernels.hip", "radix.hip", "edit.hip", "denoise.hip"):
+for src in ("kernels.hip", "gi.hip", "radix.hip", "edit.hip", "denoise.hip"):
     out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", ".", "--cuda-device-only",
                           "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True).stderr
     cur = None

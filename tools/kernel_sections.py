@@ -60,6 +60,22 @@ def report(title, b, ms):
           f"4-cell, {100.0 * b[19] / lt:.0f} % an empty 16-cell (or larger)")
 
 
+def report_stream(title, b, ms):
+    """k_ray_stream (gi.hip): cycles by phase, and how many lanes each phase's trips served"""
+    tot = b[0] or 1
+    print(f"\n== {title}: {ms:.3f} ms (instrumented), {tot / 1e9:.2f} G wave-cycles")
+    for name, x in (("stage (roots, grid, boxes, enter records -> LDS)", b[9]), ("walk steps", b[4]), ("top-level walk (grid steps, box tests)", b[2]),
+                    ("instance set-up (walk_begin)", b[20]), ("fetch (chunk counter, ray load)", b[1]),
+                    ("loop control, ballots, hit stores, idle at the end", b[0] - b[9] - b[4] - b[2] - b[20] - b[1])):
+        print(f"  {name:52s}{100.0 * x / tot:6.1f} %")
+    rays = max(1, b[12])
+    trips = max(1, b[23])
+    print(f"  rays {b[12]}; loop trips {b[23]} ({64.0 * b[23] / rays:.2f} per 64 rays)")
+    for name, t, l in (("walk", b[15], b[16]), ("top-level", b[13], b[22]), ("set-up", b[14], b[21]), ("fetch", b[11], b[12])):
+        print(f"  {name:10s} trips {t:10d} ({100.0 * t / trips:5.1f} % of loop trips), lanes per trip {l / max(1, t):5.1f} ({100.0 * l / max(1, t) / 64.0:4.1f} % lane activity), per ray {l / rays:.2f}")
+    print(f"  top-level work per ray: {b[18] / rays:.2f} grid steps, {b[17] / rays:.2f} box tests")
+
+
 def main():
     lib = L.load()
     lib.dust_hip_profile_read.restype = ctypes.c_int
@@ -95,7 +111,11 @@ def main():
                                 ("k_final_gather", L.PASS_FINAL_GATHER, 3), ("k_surfel_trace", L.PASS_SURFEL, 4)):
         pipe.render(scene, cam, sky, passes, 5, synth.frame_rand(1, 5))
         ctx.sync()
-        report(title, read(lib), pipe.pass_stats(slot).ms)
+        b = read(lib)
+        if b[23] and slot >= 3:
+            report_stream(title + " -> k_ray_stream", b, pipe.pass_stats(slot).ms)
+        else:
+            report(title, b, pipe.pass_stats(slot).ms)
 
 
 if __name__ == "__main__":
