@@ -42,7 +42,7 @@ hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t);
 hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_rays(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t);
-hipError_t launch_ray_stream(const FrameArgs& a, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_ray_walk(const FrameArgs& a, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_accumulate(const FrameArgs& a, hipStream_t);
 hipError_t launch_tone_map(const uint16_t* src, const uint32_t* albedo, uint16_t* dst, uint32_t n_pixels, uint32_t* hist, float* avg,
                            float min_log, float log_range, float time_coeff, const float conv[9], uint32_t tf, hipStream_t s);
@@ -381,7 +381,9 @@ struct Tuning {
   uint32_t stream_refill = 16;  // DUST_HIP_STREAM_REFILL, DUST_HIP_STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
   uint32_t stream_top_iters = 8;
   bool no_stream_lds = false;   // DUST_HIP_NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
-  bool packet_gi = false;       // DUST_HIP_PACKET_GI: the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace: rounds 1-4) instead of as ray streams
+  bool packet_gi = true;        // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace); DUST_HIP_RAY_STREAM: as ray streams instead --
+                                // binned per ray over the top-level grid, then one ray per lane with lanes refilled (gi.hip): built and measured in round 5, slower on
+                                // every scene but the 4096^3 tree's gather (docs/EXPERIMENTS.md)
   bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
                                 // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -408,8 +410,7 @@ struct Tuning {
     t.no_stream_lds = std::getenv("DUST_HIP_NO_STREAM_LDS") != nullptr;
     t.stream_refill = std::min(64u, std::max(1u, num("DUST_HIP_STREAM_REFILL", 16)));
     t.stream_top_iters = std::max(1u, num("DUST_HIP_STREAM_TOP_ITERS", 8));
-    t.packet_gi = std::getenv("DUST_HIP_PACKET_GI") != nullptr || t.ray_lanes || std::getenv("DUST_HIP_GATHER_SPLIT") != nullptr || (t.debug & 12u) != 0 ||
-                  std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;  // (switches of the packet kernels select them)
+    t.packet_gi = std::getenv("DUST_HIP_RAY_STREAM") == nullptr;
     t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
     t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
     t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
@@ -462,7 +463,7 @@ struct DustHipPipeline {
   DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
   DeviceBuffer gi_fg_hits;  // per pixel: the hit record of its gather ray (k_ray_stream / k_final_gather -> k_final_gather_shade)
   // ray streams (gi.hip): the compacted rays of the two GI passes, the surfel rays' hit records, and per pass two ray counters used in turn
-  DeviceBuffer gi_rays_fg, gi_rays_sf, gi_hits_sf, gi_groups_fg, gi_groups_sf;
+  DeviceBuffer gi_rays_fg, gi_rays_sf, gi_hits_sf, gi_groups_fg, gi_groups_sf, gi_unbinned;
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 64x64 tile grouped by ray direction bin
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
   uint32_t gi_touched_rows = 0;
@@ -1263,7 +1264,8 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
     g.lo[a] = float(double(s->world_min[a]) - 2.0 * margin);
     ext[a] = std::max(double(s->world_max[a]) + 2.0 * margin - double(g.lo[a]), 1e-3 * big + 1.0);
   }
-  static const double density0 = [] { const char* e = std::getenv("DUST_HIP_GRID_DENSITY"); return e ? std::max(0.01, std::atof(e)) : 12.0; }();
+  const char* density_env = std::getenv("DUST_HIP_GRID_DENSITY");  // (per commit: ~100 ns, and tests vary it)
+  const double density0 = density_env ? std::max(0.001, std::atof(density_env)) : 12.0;
   ranges.resize(n * 2);
   std::vector<uint32_t> count;
   for (double density = density0;; density *= 0.5) {  // (coarser until a cell's list and the item array fit the packed cell word: never, for scenes of any sane shape)
@@ -1564,6 +1566,7 @@ static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a)
 // The ray stream of pass kind `kind` (0: final gather, 1: surfel pass) for the launch about to be made: its buffers, this launch's
 // ray counter (zero: the previous launch of the kind zeroed it) and the one the next launch will use.
 static void stream_args(DustHipPipeline* p, int kind, dust::FrameArgs& a, float tmin, float tmax) {
+  a.gi.unbinned = static_cast<uint32_t*>(p->gi_unbinned.p) + kind * 2;
   a.gi.rays = static_cast<dust::DevRay*>(kind == 0 ? p->gi_rays_fg.p : p->gi_rays_sf.p);
   a.gi.group_count = static_cast<uint32_t*>(kind == 0 ? p->gi_groups_fg.p : p->gi_groups_sf.p);
   if (kind == 0) {  // a group = a 16 x 16 pixel tile of the band (k_gather_rays)
@@ -1609,11 +1612,13 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       // phase 1 as a ray stream (gi.hip): the pool's rays, compacted -> one ray per lane, lanes refilled -> the hash lookups over the hit records
       stream_args(p, 1, b, 0.1f, 10000.0f);  // surfel.rgen:33-62
       take_counters(p, 3, b);
+      b.gi.count_unbinned = count ? 1u : 0u;
+      if (count) HIP_TRY(hipMemsetAsync(b.gi.unbinned, 0, 2 * 4, st));
       HIP_TRY(dust::launch_surfel_rays(b, st));
       // (one 1024-thread workgroup per CU: sixteen waves share one staged copy of the top-level data)
       const uint32_t want = (p->gi_pool_size * 2u + 1023u) / 1024u;
       const uint32_t sgrid = std::max(8u, std::min<uint32_t>((resident * block / 1024u) & ~7u, (want + 7u) & ~7u));
-      HIP_TRY(dust::launch_ray_stream(b, 3, sgrid, 1024, count, st));
+      HIP_TRY(dust::launch_ray_walk(b, 3, sgrid, 1024, count, st));
       HIP_TRY(dust::launch_surfel_shade(b, st));
     }
     // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
@@ -1683,22 +1688,28 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.grid.items = reinterpret_cast<const uint16_t*>(s->dev(s->layout.grid_items));
   a.enters = reinterpret_cast<const dust::DevEnter*>(s->dev(s->layout.enters));
   a.stream_refill = p->tune.stream_refill; a.stream_top_iters = p->tune.stream_top_iters;
-  {  // what a ray-stream workgroup stages in LDS behind the roots, in this order, as far as the device's LDS goes (one workgroup per CU)
-    const size_t budget = p->ctx->max_lds - std::min<size_t>(p->ctx->max_lds, size_t(a.n_lds_models) * dust::kN16LdsBytes);
-    size_t at = 0;
-    auto place = [&](size_t bytes) -> uint32_t {
-      bytes = (bytes + 15) & ~size_t(15);
-      if (p->tune.no_stream_lds || at + bytes > budget) return 0xFFFFFFFFu;
-      const uint32_t off = uint32_t(at);
-      at += bytes;
-      return off;
+  {  // what the ray-stream kernels stage in LDS, as far as it goes. The ray-making kernels (256 threads, many workgroups per CU): grid cells,
+     // items and instance boxes within 40 KB; k_ray_walk (one 1024-thread workgroup per CU): the enter records behind its roots.
+    auto layout = [&](size_t budget, bool bin) {
+      dust::DevStreamLds l;
+      size_t at = 0;
+      auto place = [&](size_t bytes) -> uint32_t {
+        bytes = (bytes + 15) & ~size_t(15);
+        if (p->tune.no_stream_lds || at + bytes > budget) return 0xFFFFFFFFu;
+        const uint32_t off = uint32_t(at);
+        at += bytes;
+        return off;
+      };
+      const size_t n_cells = size_t(a.grid.dim[0]) * a.grid.dim[1] * a.grid.dim[2];
+      l.cells = bin ? place(n_cells * 4) : 0xFFFFFFFFu;
+      l.items = bin ? place(size_t(a.grid.n_items) * 2) : 0xFFFFFFFFu;
+      l.boxes = bin ? place(size_t(a.n_instances) * 32) : 0xFFFFFFFFu;
+      l.enters = bin ? 0xFFFFFFFFu : place(size_t(a.n_instances) * sizeof(dust::DevEnter));
+      l.total = uint32_t(at);
+      return l;
     };
-    const size_t n_cells = size_t(a.grid.dim[0]) * a.grid.dim[1] * a.grid.dim[2];
-    a.sl.cells = place(n_cells * 4);
-    a.sl.items = place(size_t(a.grid.n_items) * 2);
-    a.sl.boxes = place(size_t(a.n_instances) * 32);
-    a.sl.enters = place(size_t(a.n_instances) * sizeof(dust::DevEnter));
-    a.sl.total = uint32_t(at);
+    a.sl_bin = layout(40 * 1024, true);
+    a.sl_walk = layout(p->ctx->max_lds - std::min<size_t>(p->ctx->max_lds, size_t(a.n_lds_models) * dust::kN16LdsBytes), false);
   }
   for (int k = 0; k < 3; ++k) { a.world_min[k] = s->world_min[k]; a.world_max[k] = s->world_max[k]; }
   std::memcpy(a.cam.col0, cam->view_col0, 12); std::memcpy(a.cam.col1, cam->view_col1, 12);
@@ -1856,12 +1867,14 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       stream_args(p, 0, g, 8.0f, a.cam.far_);  // final_gather.rgen:47-50
       g.gi.fg_hits = g.gi.ray_hits;
       take_counters(p, 2, g);
+      g.gi.count_unbinned = count ? 1u : 0u;
+      if (count) HIP_TRY(hipMemsetAsync(g.gi.unbinned, 0, 2 * 4, st));
       if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
       HIP_TRY(dust::launch_gather_rays(g, st));
       const uint32_t want = uint32_t((size_t(p->width) * (a.row_end - a.row_begin) + 1023u) / 1024u);
       const uint32_t slots = ctx->side_busy ? frame_slots : resident;  // (a surfel pass beside it keeps its share)
       const uint32_t ggrid = std::max(8u, std::min<uint32_t>((slots * block / 1024u) & ~7u, (want + 7u) & ~7u));
-      HIP_TRY(dust::launch_ray_stream(g, 2, ggrid, 1024, count, st));
+      HIP_TRY(dust::launch_ray_walk(g, 2, ggrid, 1024, count, st));
       HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool the shading reads
       dust::FrameArgs sh = a;   // (pixel order over the band)
       sh.gi.fg_hits = g.gi.fg_hits;
@@ -2081,6 +2094,8 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
     HIP_TRY(p->gi_fg_hits.alloc(size_t(p->width) * p->height * sizeof(dust::DevGatherHit)));
     HIP_TRY(p->gi_rays_sf.alloc(runs * 512 * sizeof(dust::DevRay)));
     HIP_TRY(p->gi_groups_sf.alloc(runs * 4));
+    HIP_TRY(p->gi_unbinned.alloc(4 * 4));
+    HIP_TRY(hipMemsetAsync(p->gi_unbinned.p, 0, 4 * 4, p->ctx->stream));
     HIP_TRY(p->gi_hits_sf.alloc(size_t(surfel_pool_size) * 2 * sizeof(dust::DevGatherHit)));
   }
   p->gi_capacity = hash_capacity;

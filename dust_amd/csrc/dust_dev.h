@@ -122,13 +122,16 @@ struct DevEnter {
   DUST_RO(uint8_t) root;
   DUST_RO(uint64_t) dense_mask;
 };
-// Where a k_ray_stream workgroup keeps the top-level data in LDS, as byte offsets behind the staged roots (0xFFFFFFFF: the
-// section did not fit and is read from memory): instance boxes (32 B each), grid cells, grid items, enter records
+// Where a workgroup of the ray-stream kernels keeps top-level data in LDS, as byte offsets (0xFFFFFFFF: the section is not
+// staged -- it did not fit, or the kernel does not read it -- and comes from memory): grid cells, grid items, instance boxes
+// (32 B each) for the ray-making kernels, from offset 0; enter records for k_ray_walk, behind its staged roots
 struct DevStreamLds { uint32_t boxes, cells, items, enters, total; };
 
-// One ray of a ray stream (gi.hip): 32 bytes, written by a ray-making kernel, traced by k_ray_stream, whose hit record goes to
-// ray_hits[id]. flags bit 0: any-hit (terminate on first hit: the surfel pass's sun rays)
-struct DevRay { float ox, oy, oz; uint32_t id; float dx, dy, dz; uint32_t flags; };
+// One ray of a ray stream (gi.hip): 48 bytes, written by a ray-making kernel -- which also walks the top-level grid and lists the
+// instances whose box the ray meets --, walked by k_ray_walk, whose hit record goes to ray_hits[id].
+// flags bit 0: any-hit (terminate on first hit: the surfel pass's sun rays). cand[0..6]: instance ids in the order the grid walk
+// met them (front to back by cell), cand[7]: how many, | 0x8000 when there are more than seven
+struct DevRay { float ox, oy, oz; uint32_t id; float dx, dy, dz; uint32_t flags; uint16_t cand[8]; };
 
 struct DevCamera {
   float col0[3], col1[3], col2[3], pos[3];
@@ -188,6 +191,8 @@ struct DevGI {
   uint32_t n_groups, group_rays;  // (no atomics, and the same order in every run)
   DevGatherHit* ray_hits;   // [ray id]: pixel index for gather rays (== fg_hits), 2 * surfel + kind for surfel rays
   float ray_tmin, ray_tmax; // gl_RayTminEXT / gl_RayTmaxEXT of the pass (final_gather.rgen:47, surfel.rgen:33-62)
+  uint32_t* unbinned;       // [2]: rays the ray-making kernel settled itself (no instance box on their way), closest-hit / any-hit;
+  uint32_t count_unbinned;  //   kept only in a counting frame (count_unbinned != 0), for the pass statistics
 };
 
 struct FrameArgs {
@@ -200,9 +205,9 @@ struct FrameArgs {
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}
   DUST_RO(DevEnter) enters;     // n_instances compact enter records (the ray streams' instance set-up)
-  DevStreamLds sl;              // k_ray_stream: what is staged in LDS behind the roots
-  uint32_t stream_refill;       // k_ray_stream: lanes not walking at which a wave leaves the walk to do their top-level work (DUST_HIP_STREAM_REFILL)
-  uint32_t stream_top_iters;    // ... and the grid steps + box tests a lane may take in one such phase (DUST_HIP_STREAM_TOP_ITERS)
+  DevStreamLds sl_bin, sl_walk; // what the ray-making kernels / k_ray_walk stage in LDS
+  uint32_t stream_refill;       // k_ray_walk: lanes not walking at which a wave leaves the walk to set the others up (DUST_HIP_STREAM_REFILL)
+  uint32_t stream_top_iters;    // ... and the grid steps + box tests per phase of a lane that walks the grid itself (candidate overflow)
   float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];

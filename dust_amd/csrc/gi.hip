@@ -667,36 +667,41 @@ __global__ void k_surfel_apply_racy(const FrameArgs) {
   }
 }
 
-// ==================================================================== ray streams: one ray per lane, lanes refilled
+// ==================================================================== ray streams: bin, then walk one ray per lane
 // The incoherent passes -- final gather and surfel rays: neighbouring rays point anywhere -- as the reference's hardware runs
 // them: every ray on its own (final_gather.rgen:14-52, surfel.rgen:12-67 launch one invocation per ray; the TLAS of
 // accel_struct/tlas.rs:37-117 finds each ray its instances). Three kernels per pass instead of one:
-//   1. a ray-making kernel, a thread per pixel / surfel at full occupancy: the pass's live rays, compacted, 32 bytes each;
-//   2. k_ray_stream, persistent: a wavefront is 64 LANES that each carry one ray. A lane walks the top-level grid (DevGrid)
-//      front to back, cell by cell; every instance listed in a cell whose box its ray meets is entered (walk_begin) and walked
-//      (walk_step: trace_instance's loop body, verbatim); a finished ray's hit record is stored and the lane takes the next ray
-//      of the stream. A trip of the wave's loop steps every walking lane; when enough lanes are NOT walking, they do their
-//      top-level work together -- fetch, grid steps and box tests, then the instance set-ups in one go. This is north_star's
-//      "compaction of active rays": a lane never waits for the longest ray of a packet, only for the phase its neighbours are in;
-//   3. a shading kernel over the hit records, a thread per pixel / surfel at full occupancy: the hash lookups with their
-//      dependent chain instance -> block -> hash probe, and all stores, coalesced.
+//   1. a ray-making + BINNING kernel, a thread per pixel / surfel at full occupancy (k_gather_rays, k_surfel_rays): the thread
+//      makes its ray and walks the top-level grid (DevGrid, staged in LDS) along all of it, listing the instances whose world box
+//      the ray meets -- front to back, up to seven (DevRay::cand). A ray that meets none has its miss recorded at once; the
+//      others are written to the pass's stream, compacted inside their group (a 16 x 16 pixel tile / 256 surfels): no atomics,
+//      the same order in every run;
+//   2. k_ray_walk, persistent: a wavefront is 64 LANES that each carry one ray of the stream through its candidates: enter the
+//      next one (walk_begin), walk it (walk_step: trace_instance's loop body, verbatim), until the candidates are used up or
+//      the ray is settled; the hit record is stored and the lane takes the stream's next ray. A trip of the wave's loop steps
+//      every walking lane; when enough lanes are NOT walking they are set up together. This is north_star's "compaction of
+//      active rays": a lane never waits for the longest ray of a packet, only for the phase its neighbours are in;
+//   3. a shading kernel over the hit records, a thread per pixel / surfel at full occupancy (k_final_gather_shade,
+//      k_surfel_shade): the hash lookups with their dependent chain instance -> block -> hash probe, and all stores, coalesced.
 // What a ray computes is what trace_ray / trace_instance compute for it: the same brick tests on a superset of the bricks
 // that can be accepted, the same tie rule. Only who shares a wavefront with whom changes -- never a result.
+// (Round 5 first built 1 + 2 as ONE kernel -- a lane walked the grid itself between two instances and stopped at its hit --: it
+// ran at 15 % lane activity, three times the instructions of the packet kernels. docs/EXPERIMENTS.md, round 5.)
 //
-// Top-level walk. A lane steps through the grid's cells along its ray (one axis per step, exit planes from integer cell
-// coordinates). The instances of a cell are taken in list order; an instance is skipped when the PREVIOUS cell of the path
-// lies inside the block of cells the instance is listed in: it was dealt with there. (The cells of a block that lie on a
-// monotone path are consecutive, so "listed in the previous cell" is the same as "listed in any earlier cell"; the block rides
-// in the box record's spare words.) A ray is over when it has a hit in front of the current cell's exit -- every instance not
-// yet looked at is listed only in cells beyond it --, when it leaves the grid or its own [tmin, tmax], or (any-hit rays) at the
-// first hit. Boxes are grown by kGridMargin of the scene's size when they are listed (capi.cpp, build_grid): far more than
-// the rounding of the cell steps, so a ray that grazes a cell the steps skipped meets no box listed only there.
-enum : uint32_t { RS_EMPTY = 0, RS_FETCH, RS_TOP, RS_BEGIN, RS_WALK, RS_DONE };
+// Top-level walk. A ray steps through the grid's cells (one axis per step, exit planes from integer cell coordinates). The
+// instances of a cell are taken in list order; an instance is skipped when the PREVIOUS cell of the path lies inside the block
+// of cells the instance is listed in: it was dealt with there. (The cells of a block that lie on a monotone path are
+// consecutive, so "listed in the previous cell" is the same as "listed in any earlier cell"; the block rides in the box
+// record's spare words.) Boxes are grown by kGridMargin of the scene's size when they are listed (capi.cpp, build_grid): far
+// more than the rounding of the cell steps, so a ray that grazes a cell the steps skipped meets no box listed only there.
+enum : uint32_t { RS_EMPTY = 0, RS_FETCH, RS_NEXT, RS_TOP, RS_BEGIN, RS_WALK, RS_DONE };
 #ifndef DUST_STREAM_CHUNK
 #define DUST_STREAM_CHUNK 64  // rays a wave takes from its band's counter at a time
 #endif
 constexpr uint32_t kStreamChunk = DUST_STREAM_CHUNK;
 constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+constexpr uint32_t kMaxRayCand = 7;      // DevRay::cand[0..6]; cand[7] = how many | kCandOverflow
+constexpr uint32_t kCandOverflow = 0x8000u;
 
 // Cell coordinates travel as one word with a guard bit above every 8-bit field: x | y << 9 | z << 18, guards at bits 8, 17, 26.
 // "p inside the block [lo, hi]" is then two subtractions: ((p | G) - lo) keeps a field's guard bit iff p >= lo there (no borrow
@@ -707,17 +712,22 @@ struct TopState {
   uint32_t cur, end;    // what is left of the cell's instance list (indices into DevGrid::items)
   float t_end;          // where the ray leaves the grid or its tmax
 };
+// where the top-level data is read from: LDS sections behind `base` (offsets of a DevStreamLds), or memory
+struct TopSource {
+  const unsigned char* base;
+  uint32_t cells, items, boxes;  // byte offsets, 0xFFFFFFFF: not staged
+};
 __device__ __forceinline__ uint32_t grid_index(const DUST_CONST_AS DevGrid& g, uint32_t c) {
   return ((c >> 18) * g.dim[1] + ((c >> 9) & 255u)) * g.dim[0] + (c & 255u);
 }
-__device__ __forceinline__ void open_cell(ArgsRef a, uint32_t c, TopState& ts) {
+__device__ __forceinline__ void open_cell(ArgsRef a, const TopSource& src, uint32_t c, TopState& ts) {
   const uint32_t idx = grid_index(a.grid, c);
-  const uint32_t packed = a.sl.cells != 0xFFFFFFFFu ? reinterpret_cast<const uint32_t*>(g_lds + a.n_lds_models * kN16LdsBytes + a.sl.cells)[idx] : a.grid.cells[idx];
+  const uint32_t packed = src.cells != 0xFFFFFFFFu ? reinterpret_cast<const uint32_t*>(src.base + src.cells)[idx] : a.grid.cells[idx];
   ts.cur = packed & ((1u << kGridItemBits) - 1u);
   ts.end = ts.cur + (packed >> kGridItemBits);
 }
 // the ray's first cell; false: the ray misses the grid (no instance can be hit)
-__device__ __forceinline__ bool top_begin(ArgsRef a, V3 o, V3 d, V3 inv, float tmin, float tmax, TopState& ts) {
+__device__ __forceinline__ bool top_begin(ArgsRef a, const TopSource& src, V3 o, V3 d, V3 inv, float tmin, float tmax, TopState& ts) {
   const DUST_CONST_AS DevGrid& g = a.grid;
   float te, tx;
   if (!slab_box(o, d, inv, g.lo, g.hi, te, tx)) return false;
@@ -731,18 +741,19 @@ __device__ __forceinline__ bool top_begin(ArgsRef a, V3 o, V3 d, V3 inv, float t
   for (int k = 0; k < 3; ++k) c |= (uint32_t)f2i_clamp(floorf((p[k] - g.lo[k]) * g.inv_cell[k]), 0, (int)g.dim[k] - 1) << (9 * k);
   ts.cell = c;
   ts.prev = kNoCell;
-  open_cell(a, c, ts);
+  open_cell(a, src, c, ts);
   return true;
 }
-// About `budget` grid steps / box tests. Returns RS_BEGIN with `inst` = an instance to enter, RS_DONE when the ray is over, RS_TOP when
-// the budget ran out first. Two loops in turn, so that a wave's lanes share the code they run: (A) step from cell to cell until
-// one lists something, (B) test what the cell lists.
+// About `budget` grid steps / box tests. Returns RS_BEGIN with `inst` = an instance whose box the ray meets in front of `limit`
+// (the ray's hit so far, or its tmax), RS_DONE when the ray is over -- out of the grid or of [tmin, tmax], or with a hit in front of
+// the current cell's exit: every instance not yet looked at is listed only in cells beyond it --, RS_TOP when the budget ran
+// out first. Two loops in turn, so that a wave's lanes share the code they run: (A) step from cell to cell until one lists
+// something, (B) test what the cell lists.
 // zero_axis (wave-uniform): some ray of the wave has a zero direction component -- the box tests then take the general slab test
-__device__ __forceinline__ uint32_t top_next(ArgsRef a, V3 o, V3 d, V3 inv, float tmax, const Hit& best, TopState& ts, uint32_t& inst,
+__device__ __forceinline__ uint32_t top_next(ArgsRef a, const TopSource& src, V3 o, V3 d, V3 inv, float limit, bool found, TopState& ts, uint32_t& inst,
                                              uint32_t budget, bool zero_axis) {
   const DUST_CONST_AS DevGrid& g = a.grid;
-  unsigned char* lbase = g_lds + a.n_lds_models * kN16LdsBytes;
-  const bool lds_items = a.sl.items != 0xFFFFFFFFu, lds_boxes_ = a.sl.boxes != 0xFFFFFFFFu;
+  const bool lds_items = src.items != 0xFFFFFFFFu, lds_boxes_ = src.boxes != 0xFFFFFFFFu;
   for (uint32_t it = 0; it < budget;) {
     while (ts.cur >= ts.end) {  // (A) on to the next cell: the exit planes from the integer cell coordinates, one axis per step (a tie takes
       it += 1u;                 //     the lower axis now, the other one on the next step, at the same t). Selects only: no branch inside
@@ -760,65 +771,92 @@ __device__ __forceinline__ uint32_t top_next(ArgsRef a, V3 o, V3 d, V3 inv, floa
       const bool up = a0 ? p0 : (a1 ? p1 : p2);
       const bool edge = up ? ca + 1u >= da : ca == 0u;
       // over: no axis moves (a zero or NaN direction), what is left lies behind the hit, the ray's end, the grid's edge
-      if (!(tn < INFINITY) || (best.found && best.t < tn * (1.0f - 1e-5f) - 1e-4f) || tn > ts.t_end || edge) return RS_DONE;
+      if (!(tn < INFINITY) || (found && limit < tn * (1.0f - 1e-5f) - 1e-4f) || tn > ts.t_end || edge) return RS_DONE;
       ts.prev = ts.cell;
       ts.cell = up ? ts.cell + step : ts.cell - step;
-      open_cell(a, ts.cell, ts);
+      open_cell(a, src, ts.cell, ts);
       if (it >= budget) return RS_TOP;
     }
     while (ts.cur < ts.end) {  // (B) the cell's instances
       it += 1u;
       PROF_COUNT_LANES(P_L_BRICK, true);
-      const uint32_t ii = lds_items ? reinterpret_cast<const uint16_t*>(lbase + a.sl.items)[ts.cur] : a.grid.items[ts.cur];
+      const uint32_t ii = lds_items ? reinterpret_cast<const uint16_t*>(src.base + src.items)[ts.cur] : a.grid.items[ts.cur];
       ts.cur += 1u;
       f32x4 blo, bhi;
-      if (lds_boxes_) { const f32x4* lb = reinterpret_cast<const f32x4*>(lbase + a.sl.boxes); blo = lb[ii * 2u]; bhi = lb[ii * 2u + 1u]; }
+      if (lds_boxes_) { const f32x4* lb = reinterpret_cast<const f32x4*>(src.base + src.boxes); blo = lb[ii * 2u]; bhi = lb[ii * 2u + 1u]; }
       else { blo = *(DUST_RO(f32x4))(&a.boxes[ii].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ii].hi[0]); }
-      // listed in the cell the ray came from: dealt with there (prev == kNoCell has every guard bit and more: never "inside")
+      // listed in the cell the ray came from: dealt with there
       const uint32_t rl = __float_as_uint(blo.w), rh = __float_as_uint(bhi.w);
       const bool seen = ts.prev != kNoCell && ((((ts.prev | kCellGuard) - rl) & ((rh | kCellGuard) - ts.prev)) & kCellGuard) == kCellGuard;
       const float lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
       float te, tx;
       const bool box = zero_axis ? slab_box(o, d, inv, lo, hi, te, tx) : slab_box_nonzero(o, inv, lo, hi, te, tx);
-      const float limit = best.found ? best.t : tmax;
       if (!seen && box && !(te * (1.0f - 2e-6f) > limit)) { inst = ii; return RS_BEGIN; }
       if (it >= budget) break;
     }
   }
   return RS_TOP;
 }
-// the workgroup's LDS: the roots (as stage_roots), and behind them whatever of the top-level data fits (FrameArgs::sl)
-__device__ __forceinline__ void stage_stream(ArgsRef a) {
-  prof_begin();
-  if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
-  auto copy16 = [](unsigned char* dst, const DUST_CONST_AS void* src, uint32_t bytes) {  // bytes: a multiple of 16 (the image's sections are padded)
-    DUST_RO(u32x4) s4 = (DUST_RO(u32x4))src;
-    u32x4* d4 = reinterpret_cast<u32x4*>(dst);
-    const uint32_t n = bytes / 16u, step = blockDim.x;
-    uint32_t i = threadIdx.x;
-    for (; i + 3u * step < n; i += 4u * step) {
-      const u32x4 v0 = s4[i], v1 = s4[i + step], v2 = s4[i + 2u * step], v3 = s4[i + 3u * step];
-      d4[i] = v0; d4[i + step] = v1; d4[i + 2u * step] = v2; d4[i + 3u * step] = v3;
-    }
-    for (; i < n; i += step) d4[i] = s4[i];
-  };
-  copy16(g_lds, a.root_table, a.n_lds_models * kN16LdsBytes);
-  unsigned char* base = g_lds + a.n_lds_models * kN16LdsBytes;
+// a ray-making workgroup's LDS: whatever of the top-level data fits (FrameArgs::sl_bin), from offset 0
+__device__ __forceinline__ void copy16(unsigned char* dst, const DUST_CONST_AS void* src, uint32_t bytes) {  // bytes: a multiple of 16 (the image's sections are padded)
+  DUST_RO(u32x4) s4 = (DUST_RO(u32x4))src;
+  u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+  const uint32_t n = bytes / 16u, step = blockDim.x;
+  uint32_t i = threadIdx.x;
+  for (; i + 3u * step < n; i += 4u * step) {
+    const u32x4 v0 = s4[i], v1 = s4[i + step], v2 = s4[i + 2u * step], v3 = s4[i + 3u * step];
+    d4[i] = v0; d4[i + step] = v1; d4[i + 2u * step] = v2; d4[i + 3u * step] = v3;
+  }
+  for (; i < n; i += step) d4[i] = s4[i];
+}
+__device__ __forceinline__ TopSource stage_bin(ArgsRef a) {
   const uint32_t n_cells = a.grid.dim[0] * a.grid.dim[1] * a.grid.dim[2];
-  if (a.sl.boxes != 0xFFFFFFFFu) copy16(base + a.sl.boxes, a.boxes, a.n_instances * 32u);
-  if (a.sl.cells != 0xFFFFFFFFu) copy16(base + a.sl.cells, a.grid.cells, (n_cells * 4u + 15u) & ~15u);
-  if (a.sl.items != 0xFFFFFFFFu) copy16(base + a.sl.items, a.grid.items, (a.grid.n_items * 2u + 15u) & ~15u);
-  if (a.sl.enters != 0xFFFFFFFFu) copy16(base + a.sl.enters, a.enters, a.n_instances * (uint32_t)sizeof(DevEnter));
+  if (a.sl_bin.cells != 0xFFFFFFFFu) copy16(g_lds + a.sl_bin.cells, a.grid.cells, (n_cells * 4u + 15u) & ~15u);
+  if (a.sl_bin.items != 0xFFFFFFFFu) copy16(g_lds + a.sl_bin.items, a.grid.items, (a.grid.n_items * 2u + 15u) & ~15u);
+  if (a.sl_bin.boxes != 0xFFFFFFFFu) copy16(g_lds + a.sl_bin.boxes, a.boxes, a.n_instances * 32u);
   __syncthreads();
-  PROF_LEAVE(P_STAGE);
+  TopSource src;
+  src.base = g_lds; src.cells = a.sl_bin.cells; src.items = a.sl_bin.items; src.boxes = a.sl_bin.boxes;
+  return src;
+}
+// The whole top-level walk of one ray: the instances whose box it meets in [tmin, tmax], in the order the walk finds them (front to
+// back by cell), as DevRay::cand -- eight 16-bit words: up to seven instance ids, then the count (| kCandOverflow when there
+// are more: k_ray_walk then walks the grid itself). Returns the count.
+__device__ __forceinline__ uint32_t bin_ray(ArgsRef a, const TopSource& src, bool live, V3 o, V3 d, float tmin, float tmax, u32x4& cand) {
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  uint32_t n = 0, over = 0;
+  const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));  // (conservative box tests: 1 ulp is enough)
+  const bool zero_axis = __any(live && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));
+  TopState ts;
+  if (live && top_begin(a, src, o, d, inv, tmin, tmax, ts)) {
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {  // (a path has at most 3 x 256 cells; the bound is a fuse)
+      uint32_t inst = 0;
+      if (top_next(a, src, o, d, inv, tmax, false, ts, inst, 0x7FFFFFFFu, zero_axis) != RS_BEGIN) break;
+      if (n == kMaxRayCand) { over = kCandOverflow; break; }
+      const uint32_t v = inst << ((n & 1u) * 16u);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) w[k] |= (n >> 1) == k ? v : 0u;
+      n += 1u;
+    }
+  }
+  w[3] |= (n | over) << 16;
+  cand.x = w[0]; cand.y = w[1]; cand.z = w[2]; cand.w = w[3];
+  return n;
 }
 
 // RT 2: gather rays (rough.rint, closest hit), RT 3: surfel rays (closest hit, or any hit where DevRay::flags bit 0 is set).
-// Statistics slots (counting build): rays without the any-hit flag -> stats[0] for RT 2 / stats[1] for RT 3, any-hit rays -> stats[0].
+// Statistics slots (counting build): rays without the any-hit flag -> stats[0] for RT 2 / stats[1] for RT 3, any-hit rays -> stats[0];
+// the rays that met no box never reach this kernel: the ray-making kernels counted them (gi.unbinned) and block 0 adds them here.
 template <int RT, int MODE>
-__global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
+__global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
   ArgsRef a0 = launch_args();
-  stage_stream(a0);
+  // the workgroup's LDS: the roots (as stage_roots), behind them the enter records when they fit (FrameArgs::sl_walk)
+  prof_begin();
+  if (blockIdx.x == 0 && threadIdx.x < kRegions) a0.next_work_counters[threadIdx.x * kCounterStride] = 0u;
+  copy16(g_lds, a0.root_table, a0.n_lds_models * kN16LdsBytes);
+  if (a0.sl_walk.enters != 0xFFFFFFFFu) copy16(g_lds + a0.n_lds_models * kN16LdsBytes + a0.sl_walk.enters, a0.enters, a0.n_instances * (uint32_t)sizeof(DevEnter));
+  __syncthreads();
+  PROF_LEAVE(P_STAGE);
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t lower = (1ull << lane) - 1ull;
   const float tmin = a0.gi.ray_tmin, tmax = a0.gi.ray_tmax;
@@ -833,7 +871,8 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
   bool dry = chunks == 0u;
   uint32_t state = RS_EMPTY;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-  uint32_t rid = 0, rflags = 0, pend = 0;
+  uint32_t rid = 0, rflags = 0, pend = 0, ci = 0;
+  u32x4 cand = {0u, 0u, 0u, 0u};
   Hit best;
   best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
   TopState ts;
@@ -843,7 +882,9 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
   w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0; w.inst = 0;
   w.lds_slot = -1; w.extent = 0; w.root = nullptr; w.dense_mask = nullptr;
   LaneStats cur = {0, 0, 0, 0, 0, 0}, st_closest = {0, 0, 0, 0, 0, 0}, st_any = {0, 0, 0, 0, 0, 0};
-  u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};  // a ray on its way into the lane (RS_FETCH)
+  TopSource memsrc;  // (a ray with more candidates than its record holds walks the grid itself, out of memory: rare)
+  memsrc.base = g_lds; memsrc.cells = memsrc.items = memsrc.boxes = 0xFFFFFFFFu;
+  u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u}, f2 = {0u, 0u, 0u, 0u};  // a ray on its way into the lane (RS_FETCH)
   for (uint32_t trip = 0; trip < (1u << 26); ++trip) {  // (the bound is a fuse: every phase below makes progress)
     PROF_COUNT(P_CAND, 1);
     // ---- empty lanes ask for the stream's next rays, in lane order: the loads are issued here and land while the others walk
@@ -862,7 +903,7 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             const uint32_t c = band * per + k;
             if (k >= per || c >= chunks) { band_try += 1u; continue; }
-            // chunk c = part c % sub of group c / sub: the group's live rays in `sub` equal parts
+            // chunk c = part c % sub of group c / sub: the group's rays in `sub` equal parts
             const uint32_t grp = c / sub, part = c - grp * sub;
             const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gi.group_count[grp]);
             const uint32_t q = (cnt + sub - 1u) / sub;
@@ -873,8 +914,8 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
         if (!dry) {
           const uint32_t rank = (uint32_t)__popcll(b_empty & lower);
           if (state == RS_EMPTY && win_next + rank < win_end) {
-            f0 = reinterpret_cast<const u32x4*>(a.gi.rays)[(size_t)(win_next + rank) * 2u];
-            f1 = reinterpret_cast<const u32x4*>(a.gi.rays)[(size_t)(win_next + rank) * 2u + 1u];
+            const u32x4* r = reinterpret_cast<const u32x4*>(a.gi.rays) + (size_t)(win_next + rank) * 3u;
+            f0 = r[0]; f1 = r[1]; f2 = r[2];
             state = RS_FETCH;
             PROF_COUNT_LANES(P_N_CAND, true);
           }
@@ -888,7 +929,7 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
       PROF_COUNT(P_N_STEPS, 1);
       PROF_COUNT_LANES(P_L_TRIPS, true);
       const DUST_CONST_AS DevVisit& v = a0.visits[w.inst];
-      if (walk_step<RT, MODE>(w, &v.m, tmin, tmax, (rflags & 1u) != 0u, best, cur)) state = RS_TOP;
+      if (walk_step<RT, MODE>(w, &v.m, tmin, tmax, (rflags & 1u) != 0u, best, cur)) state = RS_NEXT;
       PROF_LEAVE(P_INSTANCE);
     }
     const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == RS_WALK));
@@ -897,24 +938,34 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
     if (state == RS_FETCH) {  // the ray has arrived
       o = mk(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z));
       d = mk(__uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z));
-      rid = f0.w; rflags = f1.w;
+      rid = f0.w; rflags = f1.w; cand = f2; ci = 0;
       best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
       if (COUNT) { cur.rays = 1; cur.instances_tested = cur.upper_descents = cur.mid_descents = cur.bricks_tested = cur.hits = 0; }
-      // world-space reciprocals feed only the conservative box tests (1e-5 slack): v_rcp_f32's 1 ulp is enough
-      const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-      state = top_begin(a, o, d, inv, tmin, tmax, ts) ? RS_TOP : RS_DONE;
+      state = RS_NEXT;
     }
-    // ---- top-level walk of the lanes that are between two instances
+    // ---- the ray's next candidate, or its end
+    if (state == RS_NEXT) {
+      const uint32_t n = (cand.w >> 16) & 0xFFu;
+      if ((rflags & 1u) && best.found) state = RS_DONE;  // an any-hit ray is settled by its first hit
+      else if (ci < n) {
+        const uint32_t word = (ci >> 1) == 0u ? cand.x : ((ci >> 1) == 1u ? cand.y : ((ci >> 1) == 2u ? cand.z : cand.w));
+        pend = (word >> ((ci & 1u) * 16u)) & 0xFFFFu;
+        ci += 1u;
+        state = RS_BEGIN;
+      } else if ((cand.w >> 16) & kCandOverflow) {  // more instances than the record holds: from here the lane walks the grid itself
+        cand.w &= 0xFFFFu;                          // (from the start: the instances it meets again give the same hits)
+        const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        state = top_begin(a, memsrc, o, d, inv, tmin, tmax, ts) ? RS_TOP : RS_DONE;
+        rflags |= 2u;
+      } else state = (rflags & 2u) ? RS_TOP : RS_DONE;
+    }
     if (state == RS_TOP) {
       PROF_ENTER(P_CULL);
       PROF_COUNT(P_N_CAND_ITER, 1);
       PROF_COUNT_LANES(P_AO_SETUP, true);
-      if ((rflags & 1u) && best.found) state = RS_DONE;
-      else {
-        const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-        const bool zero_axis = __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this phase)
-        state = top_next(a, o, d, inv, tmax, best, ts, pend, a.stream_top_iters, zero_axis);
-      }
+      const V3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+      const bool zero_axis = __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this phase)
+      state = top_next(a, memsrc, o, d, inv, best.found ? best.t : tmax, best.found, ts, pend, a.stream_top_iters, zero_axis);
       PROF_LEAVE(P_CULL);
     }
     if (state == RS_DONE) {  // the ray's hit record; the lane is free
@@ -935,8 +986,8 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
       if (COUNT) cur.instances_tested += 1;
       // the instance's enter record: five 16-byte reads, from LDS where it is staged
       u32x4 e0, e1, e2, e3, e4;
-      if (a.sl.enters != 0xFFFFFFFFu) {
-        const u32x4* le = reinterpret_cast<const u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + a.sl.enters) + pend * 5u;
+      if (a.sl_walk.enters != 0xFFFFFFFFu) {
+        const u32x4* le = reinterpret_cast<const u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + a.sl_walk.enters) + pend * 5u;
         e0 = le[0]; e1 = le[1]; e2 = le[2]; e3 = le[3]; e4 = le[4];
       } else {
         DUST_RO(u32x4) ge = (DUST_RO(u32x4))(a.enters + pend);
@@ -956,12 +1007,16 @@ __global__ void __launch_bounds__(1024, 4) k_ray_stream(const FrameArgs) {
       const V3 oo = mk(((m[0] * o.x + m[1] * o.y) + m[2] * o.z) + m[3], ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7],
                        ((m[8] * o.x + m[9] * o.y) + m[10] * o.z) + m[11]);
       const V3 od = mk((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z, (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
-      state = walk_begin<RT, MODE>(w, ev, pend, oo, od, tmin) ? RS_WALK : RS_TOP;
+      state = walk_begin<RT, MODE>(w, ev, pend, oo, od, tmin) ? RS_WALK : RS_NEXT;
       PROF_LEAVE(P_SETUP);
     }
     if (dry && !__any(state != RS_EMPTY)) break;
   }
   prof_end();
+  if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) {  // the rays that met no instance box (counted by the ray-making kernel): traced, missed
+    if (RT == 2) st_closest.rays += a0.gi.unbinned[0];
+    else { st_any.rays += a0.gi.unbinned[1]; st_closest.rays += a0.gi.unbinned[0]; }
+  }
   if (RT == 2) flush_stats<MODE>(a0, 0, st_closest);
   else { flush_stats<MODE>(a0, 0, st_any); flush_stats<MODE>(a0, 1, st_closest); }
 }
@@ -981,23 +1036,40 @@ __device__ __forceinline__ uint32_t group_reserve(uint32_t* group_count, bool fi
   if (threadIdx.x == 0) *group_count = all;
   return before + (uint32_t)(__popcll(b1 & lower) + __popcll(b2 & lower));
 }
+__device__ __forceinline__ void put_ray(ArgsRef a, uint32_t at, V3 o, uint32_t id, V3 d, uint32_t flags, u32x4 cand) {
+  u32x4 r0, r1;
+  r0.x = __float_as_uint(o.x); r0.y = __float_as_uint(o.y); r0.z = __float_as_uint(o.z); r0.w = id;
+  r1.x = __float_as_uint(d.x); r1.y = __float_as_uint(d.y); r1.z = __float_as_uint(d.z); r1.w = flags;
+  u32x4* r = reinterpret_cast<u32x4*>(a.gi.rays) + (size_t)at * 3u;
+  r[0] = r0; r[1] = r1; r[2] = cand;
+}
+__device__ __forceinline__ void put_miss(ArgsRef a, uint32_t id) {  // the hit record of a ray that meets no instance box
+  u32x4 rec;
+  rec.x = __float_as_uint(a.gi.ray_tmax); rec.y = 0u; rec.z = 0u; rec.w = 0u;
+  reinterpret_cast<u32x4*>(a.gi.ray_hits)[id] = rec;
+}
+// (counting build of the frame only: how many rays the binning settled itself; one atomic per workgroup)
+__device__ __forceinline__ void count_unbinned(ArgsRef a, uint32_t which, bool mine) {
+  if (!a.gi.count_unbinned) return;
+  const uint32_t n = (uint32_t)__popcll(__ballot(mine));
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&a.gi.unbinned[which], n);
+}
 
-// final_gather.rgen:14-44 for every pixel of the band: the frame's gather rays, 16 x 16 pixel tile by tile
+// final_gather.rgen:14-44 for every pixel of the band, 16 x 16 pixel tile by tile: the pixel's gather ray, binned
 __global__ void __launch_bounds__(256) k_gather_rays(const FrameArgs) {
   ArgsRef a = launch_args();
+  const TopSource src = stage_bin(a);
   const uint32_t tiles_x = (a.width + 15u) / 16u;
   const uint32_t ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const uint32_t px = tx * 16u + (threadIdx.x & 15u), py = a.row_begin + ty * 16u + (threadIdx.x >> 4);
   V3 inval, loc, ad;
   const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
-  const uint32_t at = blockIdx.x * 256u + group_reserve(a.gi.group_count + blockIdx.x, live, false);
-  if (live) {
-    u32x4 r0, r1;
-    r0.x = __float_as_uint(loc.x); r0.y = __float_as_uint(loc.y); r0.z = __float_as_uint(loc.z); r0.w = py * a.width + px;
-    r1.x = __float_as_uint(ad.x); r1.y = __float_as_uint(ad.y); r1.z = __float_as_uint(ad.z); r1.w = 0u;
-    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u] = r0;
-    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u + 1u] = r1;
-  }
+  u32x4 cand;
+  const bool walk = bin_ray(a, src, live, loc, ad, a.gi.ray_tmin, a.gi.ray_tmax, cand) != 0u;
+  const uint32_t at = blockIdx.x * 256u + group_reserve(a.gi.group_count + blockIdx.x, walk, false);
+  if (walk) put_ray(a, at, loc, py * a.width + px, ad, 0u, cand);
+  else if (live) put_miss(a, py * a.width + px);
+  count_unbinned(a, 0, live && !walk);
 }
 
 // surfel.rgen:12-67: where surfel i's two rays start and where they point. Returns false for a dead slot.
@@ -1017,10 +1089,11 @@ __device__ __forceinline__ bool surfel_rays(ArgsRef a, uint32_t i, const DevSurf
   }
   return live;
 }
-// the surfel pass's rays, in the pool's position order (gi.perm) or pool order: per live surfel the cosine ray (id 2 i), and the
+// the surfel pass's rays, in the pool's position order (gi.perm) or pool order, binned: per live surfel the cosine ray (id 2 i), and the
 // sun ray (id 2 i + 1, any-hit) where the sun is above the surfel's face
 __global__ void __launch_bounds__(256) k_surfel_rays(const FrameArgs) {
   ArgsRef a = launch_args();
+  const TopSource src = stage_bin(a);
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;
   const bool in_range = slot < a.gi.pool_size && i < a.gi.pool_size;
@@ -1030,20 +1103,17 @@ __global__ void __launch_bounds__(256) k_surfel_rays(const FrameArgs) {
   SurfelRays r;
   const bool live = surfel_rays(a, i, e, r) && in_range;
   const bool lit = live && r.lit;
-  const uint32_t at = blockIdx.x * 512u + group_reserve(a.gi.group_count + blockIdx.x, live, lit);
-  if (live) {
-    u32x4 r0, r1;
-    r0.x = __float_as_uint(r.org.x); r0.y = __float_as_uint(r.org.y); r0.z = __float_as_uint(r.org.z); r0.w = 2u * i;
-    r1.x = __float_as_uint(r.cos_dir.x); r1.y = __float_as_uint(r.cos_dir.y); r1.z = __float_as_uint(r.cos_dir.z); r1.w = 0u;
-    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u] = r0;
-    reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)at * 2u + 1u] = r1;
-    if (lit) {
-      r0.w = 2u * i + 1u;
-      r1.x = __float_as_uint(a.sun_dir[0]); r1.y = __float_as_uint(a.sun_dir[1]); r1.z = __float_as_uint(a.sun_dir[2]); r1.w = 1u;
-      reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)(at + 1u) * 2u] = r0;
-      reinterpret_cast<u32x4*>(a.gi.rays)[(size_t)(at + 1u) * 2u + 1u] = r1;
-    }
-  }
+  const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
+  u32x4 cand_cos, cand_sun;
+  const bool walk_cos = bin_ray(a, src, live, r.org, r.cos_dir, a.gi.ray_tmin, a.gi.ray_tmax, cand_cos) != 0u;
+  const bool walk_sun = bin_ray(a, src, lit, r.org, sd, a.gi.ray_tmin, a.gi.ray_tmax, cand_sun) != 0u;
+  const uint32_t at = blockIdx.x * 512u + group_reserve(a.gi.group_count + blockIdx.x, walk_cos, walk_sun);
+  if (walk_cos) put_ray(a, at, r.org, 2u * i, r.cos_dir, 0u, cand_cos);
+  else if (live) put_miss(a, 2u * i);
+  if (walk_sun) put_ray(a, at + (walk_cos ? 1u : 0u), r.org, 2u * i + 1u, sd, 1u, cand_sun);
+  else if (lit) put_miss(a, 2u * i + 1u);
+  count_unbinned(a, 0, live && !walk_cos);
+  count_unbinned(a, 1, lit && !walk_sun);
 }
 // surfel.rchit:35-102 + surfel.rmiss:14-26 + surfel/nee.rmiss:15-27 over the hit records: a thread per surfel, in pool order --
 // what k_surfel_trace does behind its trace, with the hash probes of a whole workgroup in flight together
@@ -1146,11 +1216,11 @@ hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
 }
 hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t s) {
   const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.row_end - a.row_begin + 15u) / 16u);
-  hipLaunchKernelGGL(k_gather_rays, dim3(tiles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_gather_rays, dim3(tiles), dim3(256), a.sl_bin.total, s, a);
   return hipGetLastError();
 }
 hipError_t launch_surfel_rays(const FrameArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_surfel_rays, dim3((a.gi.pool_size + 255u) / 256u), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_surfel_rays, dim3((a.gi.pool_size + 255u) / 256u), dim3(256), a.sl_bin.total, s, a);
   return hipGetLastError();
 }
 hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t s) {
@@ -1158,11 +1228,11 @@ hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 // rt 2: gather rays, 3: surfel rays; the stream is a.gi.rays / group_count, the hit records go to a.gi.ray_hits
-hipError_t launch_ray_stream(const FrameArgs& a_in, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
-  const size_t lds = (size_t)a_in.n_lds_models * kN16LdsBytes + a_in.sl.total;
+hipError_t launch_ray_walk(const FrameArgs& a_in, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
+  const size_t lds = (size_t)a_in.n_lds_models * kN16LdsBytes + a_in.sl_walk.total;
   const FrameArgs a = with_schedule(a_in, grid, block);
   const int mode = (count ? 1 : 0) | (a.deep ? 2 : 0);
-#define DUST_STREAM_CASE(RT_, M_) hipLaunchKernelGGL((k_ray_stream<RT_, M_>), dim3(grid), dim3(block), lds, s, a)
+#define DUST_STREAM_CASE(RT_, M_) hipLaunchKernelGGL((k_ray_walk<RT_, M_>), dim3(grid), dim3(block), lds, s, a)
   if (rt == 2) {
     switch (mode) { case 0: DUST_STREAM_CASE(2, 0); break; case 1: DUST_STREAM_CASE(2, 1); break; case 2: DUST_STREAM_CASE(2, 2); break; default: DUST_STREAM_CASE(2, 3); break; }
   } else {
@@ -1176,8 +1246,9 @@ hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_k
       (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
       (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>,
       (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>,
-      (const void*)k_ray_stream<2, 0>, (const void*)k_ray_stream<2, 1>, (const void*)k_ray_stream<2, 2>, (const void*)k_ray_stream<2, 3>,
-      (const void*)k_ray_stream<3, 0>, (const void*)k_ray_stream<3, 1>, (const void*)k_ray_stream<3, 2>, (const void*)k_ray_stream<3, 3>};
+      (const void*)k_ray_walk<2, 0>, (const void*)k_ray_walk<2, 1>, (const void*)k_ray_walk<2, 2>, (const void*)k_ray_walk<2, 3>,
+      (const void*)k_ray_walk<3, 0>, (const void*)k_ray_walk<3, 1>, (const void*)k_ray_walk<3, 2>, (const void*)k_ray_walk<3, 3>,
+      (const void*)k_gather_rays, (const void*)k_surfel_rays};
   for (const void* f : fns) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;

@@ -116,7 +116,8 @@ def test_surfel_position_sort_only_regroups(monkeypatch):
 
 
 _SWITCHES = ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
-             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RAY_LANES")
+             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RAY_LANES", "DUST_HIP_RAY_STREAM", "DUST_HIP_NO_STREAM_LDS",
+             "DUST_HIP_STREAM_REFILL")
 
 
 def _castle_gi_states(monkeypatch, settings, frames=3):
@@ -155,14 +156,19 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     wave on one, bit 8) nor of which rays share a wavefront
     (octant-ordered gather packets, position-ordered surfels), which wave traces which tile when (cost-ordered hand-out), where
     the cull reads its boxes from, the launch shape, or whether gather rays run a packet at a time or as refilled ray lanes
-    (DUST_HIP_RAY_LANES: a lane shades its finished ray and takes the work item's next one while its neighbours walk on).
+    (DUST_HIP_RAY_LANES: a lane shades its finished ray and takes the work item's next one while its neighbours walk on), or
+    as ray streams (DUST_HIP_RAY_STREAM: every ray finds its instances in the top-level grid and is walked on a lane of its own).
     Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
     _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
                                                        {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
                                                        {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"},
-                                                       {"DUST_HIP_RAY_LANES": "1"}, {"DUST_HIP_RAY_LANES": "1", "DUST_HIP_DEBUG": "4"}],
+                                                       {"DUST_HIP_RAY_LANES": "1"}, {"DUST_HIP_RAY_LANES": "1", "DUST_HIP_DEBUG": "4"},
+                                                       # the passes as ray streams (gi.hip: binned per ray over the top-level grid, one ray per lane):
+                                                       # top-level data in LDS / in memory, lanes refilled one by one / only when all are done
+                                                       {"DUST_HIP_RAY_STREAM": "1"}, {"DUST_HIP_RAY_STREAM": "1", "DUST_HIP_NO_STREAM_LDS": "1", "DUST_HIP_STREAM_REFILL": "1"},
+                                                       {"DUST_HIP_RAY_STREAM": "1", "DUST_HIP_STREAM_REFILL": "64", "DUST_HIP_NO_SURFEL_SORT": "1"}],
                                           frames=5)
     assert (st[0][0][:, 0] != 0).sum() > 50
     for other in st[1:]:

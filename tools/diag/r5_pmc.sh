@@ -17,7 +17,7 @@ for v in stream packet; do
     DUST_HIP_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_r5" -o ${v}_$i -- \
         python "$R/bench.py" --workload gi --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${v}_$i.log" 2>&1
   done
-  python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_r5" -name "${v}_*_results.db" | sort) | grep -E "k_ray_stream<., 0>|k_final_gather<0>|k_surfel_trace<0>|k_primary_ao<0>" > "$out/r5_pmc_$v.txt" 2>&1
+  python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_r5" -name "${v}_*_results.db" | sort) | grep -E "k_ray_walk<., 0>|k_final_gather<0>|k_surfel_trace<0>|k_primary_ao<0>" > "$out/r5_pmc_$v.txt" 2>&1
 done
 cat "$out/r5_pmc_stream.txt" "$out/r5_pmc_packet.txt" | cut -c1-130
 rm -rf "$out/pmc_r5"

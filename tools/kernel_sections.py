@@ -61,7 +61,7 @@ def report(title, b, ms):
 
 
 def report_stream(title, b, ms):
-    """k_ray_stream (gi.hip): cycles by phase, and how many lanes each phase's trips served"""
+    """k_ray_walk (gi.hip): cycles by phase, and how many lanes each phase's trips served"""
     tot = b[0] or 1
     print(f"\n== {title}: {ms:.3f} ms (instrumented), {tot / 1e9:.2f} G wave-cycles")
     for name, x in (("stage (roots, grid, boxes, enter records -> LDS)", b[9]), ("walk steps", b[4]), ("top-level walk (grid steps, box tests)", b[2]),
@@ -113,7 +113,7 @@ def main():
         ctx.sync()
         b = read(lib)
         if b[23] and slot >= 3:
-            report_stream(title + " -> k_ray_stream", b, pipe.pass_stats(slot).ms)
+            report_stream(title + " -> k_ray_walk", b, pipe.pass_stats(slot).ms)
         else:
             report(title, b, pipe.pass_stats(slot).ms)
 
