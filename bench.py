@@ -79,6 +79,9 @@ def parse(argv=None):
                     help="N > 1, row bands: native = the library's own RCCL path (dust_hip_comm_create / dust_hip_gather_bands / "
                          "dust_hip_gi_exchange_run: grouped send / receive on the communicator's stream, enqueued by the call that follows the "
                          "band's render call); torch = the same collectives through torch.distributed (round 3)")
+    ap.add_argument("--props", type=int, default=0,
+                    help="castle workloads: this many small extra instances scattered over the scene (curves.many_instances uses 4000: the packet "
+                         "cull then goes through its 64-wide hierarchy, cull_instances in traverse.hpp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--camera", choices=["still", "orbit"], default="still",
                     help="orbit: the headline becomes the MOVING view (the eye swaying along its circle round the castle, the teapot of "
@@ -201,6 +204,9 @@ class HipBackend:
             if info is None:
                 info = {"n_models": len(desc.models), "n_instances": len(desc.instances), "n_voxels": int(sum(len(m) for _, m in desc.models))}
             out["real_castle"] = real
+            if getattr(args, "props", 0):   # seeded props: 8 small models, arbitrary rotations about the vertical (y) axis, on and above the ground
+                P.scatter_props(desc, int(args.props), args.scale)
+                info = dict(info, n_models=len(desc.models), n_instances=len(desc.instances), props=int(args.props))
             scene = P.hip_scene(self.ctx, desc)
             s = args.scale
             eye, target = (122.0 * s, 300.61 * s, 54.45 * s), (0.0, 0.0, 0.0)  # examples/castle.rs:120-129, fov pi/4
@@ -637,10 +643,19 @@ def extra_curves(args, be, noise0, noise5, base):
         rec = curve("deep", args.width, args.height, sc)
         rec["scene"] = f"procedural 4096^3 tree, {args.deep_occupancy:.2%} brick occupancy, {sc['n_bricks']} bricks (BASELINE configs[4] on one GPU)"
         return rec
+    def many_instances():
+        a = argparse.Namespace(**vars(args))
+        a.props = 4000
+        sc = be.build_scene(a)
+        rec = curve("primary_ao", args.width, args.height, sc)
+        rec["scene"] = f"the castle + 4000 scattered props: {sc['info']['n_instances']} instances of {sc['info']['n_models']} models"
+        return rec
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
     run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
     run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))
     run("deep", deep)
+    if not getattr(args, "props", 0):
+        run("many_instances", many_instances)
     return out
 
 

@@ -273,7 +273,7 @@ struct HostInstance {
 // stream (tlas.rs:37-65 rebuilds the TLAS inside the frame's command stream the same way): no allocation, no wait, and the
 // kernels' pointers stay what they were until instances are added.
 struct SceneLayout {
-  size_t models = 0, root_table = 0, instances = 0, boxes = 0, visits = 0, enters = 0, grid_cells = 0, grid_items = 0, total = 0;
+  size_t models = 0, root_table = 0, instances = 0, boxes = 0, visits = 0, enters = 0, gboxes = 0, sboxes = 0, grid_cells = 0, grid_items = 0, total = 0;
   size_t cap_cells = 0, cap_items = 0;  // entries the two grid sections hold (a commit that needs more lays the image out again)
   static SceneLayout make(size_t n_inst, size_t n_models, size_t n_roots, size_t n_cells, size_t n_items) {
     SceneLayout l;
@@ -284,6 +284,8 @@ struct SceneLayout {
     l.boxes = place((n_inst + 1) * sizeof(dust::DevBox));
     l.visits = place((n_inst + 1) * sizeof(dust::DevVisit));
     l.enters = place((n_inst + 1) * sizeof(dust::DevEnter));
+    l.gboxes = place(((n_inst + 63) / 64 + 1) * sizeof(dust::DevBox));  // the packet cull's hierarchy (scenes beyond kFlatCullMax instances)
+    l.sboxes = place((n_inst + 1) * sizeof(dust::DevBox));
     // the top-level grid last, with room to spare: its size follows the instances' positions, not only their number
     l.cap_cells = n_cells + n_cells / 2 + 64;
     l.cap_items = n_items + n_items / 2 + 256;
@@ -324,6 +326,8 @@ struct DustHipScene : RefCounted {
   dust::DevGrid grid{};
   std::vector<uint32_t> grid_cells;
   std::vector<uint16_t> grid_items;
+  std::vector<uint32_t> slot_order;  // large scenes: the instances along a space-filling curve (made by a structural commit; a moved instance keeps its slot)
+  uint32_t n_groups = 0;             // ... and how many groups of 64 consecutive slots (0: the cull tests every box)
   std::vector<float> world_boxes;  // per instance {lo[3], hi[3]}: what derive_instance writes into the image, kept for the grid
   uint32_t n_lds_models = 0;
   uint64_t revision = 0;  // bumped by every commit (what the cost-ordered hand-out keys its view on)
@@ -1409,6 +1413,43 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
         vs[i].pad0 = bx[i].pad0; vs[i].pad1 = bx[i].pad1;
       }
       std::memcpy(img + s->layout.grid_cells, s->grid_cells.data(), s->grid_cells.size() * sizeof(uint32_t));
+      // the packet cull's 64-wide hierarchy (kernels: cull_instances): slots along a Morton curve through the boxes' centres -- ordered
+      // by structural commits, refitted by every commit --, a box per 64 consecutive slots
+      s->n_groups = n > dust::kFlatCullMax && !std::getenv("DUST_HIP_FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
+      if (s->n_groups) {
+        if (full || s->slot_order.size() != n) {
+          std::vector<std::pair<uint32_t, uint32_t>> keyed(n);
+          auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
+          for (size_t i = 0; i < n; ++i) {
+            uint32_t c[3];
+            for (int a = 0; a < 3; ++a) {
+              const double span = std::max(1e-6, double(s->world_max[a]) - double(s->world_min[a]));
+              const double mid = 0.5 * (double(s->world_boxes[i * 6 + a]) + double(s->world_boxes[i * 6 + 3 + a]));
+              c[a] = uint32_t(std::min(1023.0, std::max(0.0, (mid - double(s->world_min[a])) / span * 1024.0)));
+            }
+            keyed[i] = {spread(c[0]) | (spread(c[1]) << 1) | (spread(c[2]) << 2), uint32_t(i)};
+          }
+          std::sort(keyed.begin(), keyed.end());
+          s->slot_order.resize(n);
+          for (size_t k = 0; k < n; ++k) s->slot_order[k] = keyed[k].second;
+        }
+        dust::DevBox* sb = reinterpret_cast<dust::DevBox*>(img + s->layout.sboxes);
+        dust::DevBox* gb = reinterpret_cast<dust::DevBox*>(img + s->layout.gboxes);
+        for (uint32_t g = 0; g < s->n_groups; ++g) {
+          dust::DevBox u;
+          for (int a = 0; a < 3; ++a) { u.lo[a] = 1e30f; u.hi[a] = -1e30f; }
+          u.pad0 = u.pad1 = 0.0f;
+          for (size_t k = size_t(g) * 64; k < std::min(n, size_t(g + 1) * 64); ++k) {
+            const uint32_t i = s->slot_order[k];
+            sb[k] = bx[i];
+            std::memcpy(&sb[k].pad0, &i, 4);
+            for (int a = 0; a < 3; ++a) { u.lo[a] = std::min(u.lo[a], bx[i].lo[a]); u.hi[a] = std::max(u.hi[a], bx[i].hi[a]); }
+          }
+          gb[g] = u;
+        }
+      } else {
+        s->slot_order.clear();
+      }
       if (n_items) std::memcpy(img + s->layout.grid_items, s->grid_items.data(), n_items * sizeof(uint16_t));
     }
     // upload: the whole image into the next slot of the ring, on the copy stream, and wait for it here (a ~100 KB copy: ~20 us of host
@@ -1687,6 +1728,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.grid.cells = reinterpret_cast<const uint32_t*>(s->dev(s->layout.grid_cells));
   a.grid.items = reinterpret_cast<const uint16_t*>(s->dev(s->layout.grid_items));
   a.enters = reinterpret_cast<const dust::DevEnter*>(s->dev(s->layout.enters));
+  a.gboxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.gboxes));
+  a.sboxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.sboxes));
+  a.n_groups = s->n_groups;
   a.stream_refill = p->tune.stream_refill; a.stream_top_iters = p->tune.stream_top_iters;
   {  // what the ray-stream kernels stage in LDS, as far as it goes. The ray-making kernels (256 threads, many workgroups per CU): grid cells,
      // items and instance boxes within 40 KB; k_ray_walk (one 1024-thread workgroup per CU): the enter records behind its roots.
@@ -1748,9 +1792,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   if (lds > ctx->max_lds) return fail(DUST_ERR_INVALID_ARGUMENT, "staged roots and candidate lists exceed the device's LDS");
   // the instance boxes ride along when the workgroups of a CU still fit side by side (the packet cull reads all of them, per packet)
   a.n_lds_boxes = 0;
-  if (!tune.no_lds_boxes && (lds + size_t(a.n_instances) * 32) * bpc <= 160 * 1024 && lds + size_t(a.n_instances) * 32 <= ctx->max_lds) {
-    a.n_lds_boxes = a.n_instances;
-    lds += size_t(a.n_instances) * 32;
+  const uint32_t cull_boxes = a.n_groups ? a.n_groups : a.n_instances;  // (a large scene stages the boxes of its groups of 64)
+  if (!tune.no_lds_boxes && (lds + size_t(cull_boxes) * 32) * bpc <= 160 * 1024 && lds + size_t(cull_boxes) * 32 <= ctx->max_lds) {
+    a.n_lds_boxes = cull_boxes;
+    lds += size_t(cull_boxes) * 32;
   }
   while (bpc > 1 && lds * bpc > 160 * 1024) --bpc;
   const uint32_t total_tiles = a.tiles_x * a.tiles_y;

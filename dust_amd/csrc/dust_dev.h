@@ -42,6 +42,7 @@ constexpr uint32_t kN16LdsBytes = 640;   // mask + prefix only (root child_base 
 constexpr uint32_t kTileW = DUST_TILE_W, kTileH = DUST_TILE_H;  // pixels of one ray packet (kTileW * kTileH == 64 lanes)
 constexpr uint32_t kRegions = 8;          // work bands = XCDs (finer sub-queues per band measured 2.5 % slower: more empty-queue probes at the tail)
 constexpr uint32_t kCounterStride = 64;  // u32s between the per-region work counters (256 B: no two share a cache line)
+constexpr uint32_t kFlatCullMax = 256;   // instances up to which the packet cull tests every box (four rounds of 64); above: cull_instances' hierarchy
 constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
 constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
@@ -205,6 +206,11 @@ struct FrameArgs {
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}
   DUST_RO(DevEnter) enters;     // n_instances compact enter records (the ray streams' instance set-up)
+  // Large scenes (more than kFlatCullMax instances; n_groups != 0): the packet cull's 64-wide hierarchy. The instances in the order
+  // of a space-filling curve through their boxes' centres, every 64 consecutive ones a group:
+  DUST_RO(DevBox) gboxes;       //   n_groups group boxes (the union of the group's instance boxes)
+  DUST_RO(DevBox) sboxes;       //   n_instances instance boxes in that order; pad0 (as a bit pattern) = the instance's id
+  uint32_t n_groups;
   DevStreamLds sl_bin, sl_walk; // what the ray-making kernels / k_ray_walk stage in LDS
   uint32_t stream_refill;       // k_ray_walk: lanes not walking at which a wave leaves the walk to set the others up (DUST_HIP_STREAM_REFILL)
   uint32_t stream_top_iters;    // ... and the grid steps + box tests per phase of a lane that walks the grid itself (candidate overflow)

@@ -924,15 +924,12 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
   const bool in_lds = a.n_lds_boxes != 0;
   const f32x4* lbox = reinterpret_cast<const f32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
   uint32_t n = 0;
-  for (uint32_t base = 0; base < n_inst; base += 64) {
-    const uint32_t i = base + lane;
-    const uint32_t ic = i < n_inst ? i : n_inst - 1u;  // clamp instead of branching around the loads
-    f32x4 blo, bhi;
-    if (in_lds) { blo = lbox[ic * 2u]; bhi = lbox[ic * 2u + 1u]; }
-    else { blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]); }
+  // one box against the bundle: passes, and the earliest time any ray of the bundle can enter it
+  auto test = [&](f32x4 blo, f32x4 bhi, bool valid, float& t_lo) {
     const float wlo[3] = {blo.x, blo.y, blo.z}, whi[3] = {bhi.x, bhi.y, bhi.z};
-    float t_lo = 0.0f, t_hi = tmax;
-    bool pass = i < n_inst;
+    float t_hi = tmax;
+    t_lo = 0.0f;
+    bool pass = valid;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float c1 = whi[k] - org.lo[k], c2 = wlo[k] - org.hi[k];
@@ -941,16 +938,56 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
       t_lo = fmaxf(t_lo, fmaxf(lo1[k] ? q1 : 0.0f, lo2[k] ? q2 : 0.0f));
       pass = pass & !(z1[k] & (c1 < 0.0f)) & !(z2[k] & (c2 > 0.0f));
     }
-    pass = pass & !(t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f);
+    return pass & !(t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f);
+  };
+  // one word per candidate: earliest entry of any ray of the packet (upper 16 bits of the float, i.e. rounded DOWN: stays
+  // conservative, and absorbs the reciprocal's rounding) above the 16-bit instance id -- unsigned compare orders by entry
+  // time, then id
+  auto append = [&](bool pass, float t_lo, uint32_t id) {
     const uint64_t bal = __ballot(pass);
     if (pass) {
       const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      // one word per candidate: earliest entry of any ray of the packet (upper 16 bits of the float, i.e. rounded
-      // DOWN: stays conservative, and absorbs the reciprocal's rounding) above the 16-bit instance id -- unsigned
-      // compare orders by entry time, then id
-      if (pos < kMaxCand) cand[pos] = (__float_as_uint(t_lo) & 0xFFFF0000u) | (i & 0xFFFFu);
+      if (pos < kMaxCand) cand[pos] = (__float_as_uint(t_lo) & 0xFFFF0000u) | (id & 0xFFFFu);
     }
     n += (uint32_t)__popcll(bal);
+  };
+  if (a.n_groups == 0u) {  // a few hundred instances at most: every box, 64 at a time
+    for (uint32_t base = 0; base < n_inst; base += 64) {
+      const uint32_t i = base + lane;
+      const uint32_t ic = i < n_inst ? i : n_inst - 1u;  // clamp instead of branching around the loads
+      f32x4 blo, bhi;
+      if (in_lds) { blo = lbox[ic * 2u]; bhi = lbox[ic * 2u + 1u]; }
+      else { blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]); }
+      float t_lo;
+      const bool pass = test(blo, bhi, i < n_inst, t_lo);
+      append(pass, t_lo, i);
+    }
+  } else {
+    // Thousands of instances (the reference's TLAS, accel_struct/tlas.rs:79-117, holds one entry per entity): a 64-wide hierarchy.
+    // dust_hip_scene_commit orders the instances along a space-filling curve and boxes every 64 consecutive ones (a GROUP); the
+    // bundle is tested against the group boxes, 64 at a time, and only the groups it meets have their 64 instance boxes looked at
+    // (one coalesced 2 KB read each: a slot's record carries the instance's id). The groups that passed are also left as a bit
+    // mask in the list's sort staging area: if the list overflows, trace_ray walks those groups instead of every instance.
+    for (uint32_t gbase = 0; gbase < a.n_groups; gbase += 64) {
+      const uint32_t g = gbase + lane;
+      const uint32_t gc = g < a.n_groups ? g : a.n_groups - 1u;
+      f32x4 glo, ghi;
+      if (in_lds) { glo = lbox[gc * 2u]; ghi = lbox[gc * 2u + 1u]; }
+      else { glo = *(DUST_RO(f32x4))(&a.gboxes[gc].lo[0]); ghi = *(DUST_RO(f32x4))(&a.gboxes[gc].hi[0]); }
+      float t_g;
+      uint64_t groups = __ballot(test(glo, ghi, g < a.n_groups, t_g));
+      if (lane == 0) { cand[kMaxCand + (gbase >> 5)] = (uint32_t)groups; cand[kMaxCand + (gbase >> 5) + 1u] = (uint32_t)(groups >> 32); }
+      while (groups != 0ull) {
+        const uint32_t gi = gbase + (uint32_t)__builtin_ctzll(groups);
+        groups &= groups - 1ull;
+        const uint32_t slot = gi * 64u + lane;
+        const uint32_t sc = slot < n_inst ? slot : n_inst - 1u;
+        const f32x4 blo = *(DUST_RO(f32x4))(&a.sboxes[sc].lo[0]), bhi = *(DUST_RO(f32x4))(&a.sboxes[sc].hi[0]);
+        float t_lo;
+        const bool pass = test(blo, bhi, slot < n_inst, t_lo);
+        append(pass, t_lo, __float_as_uint(blo.w));
+      }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -987,6 +1024,7 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
   PROF_COUNT(P_N_TRACES, 1);
   PROF_COUNT(P_N_CAND, ncand);
   const bool all = ncand > kMaxCand || (a_in.debug & 4u);  // debug bit 4: ignore the list, walk every instance in index order
+  const bool by_groups = ncand > kMaxCand && a_in.n_groups != 0u && !(a_in.debug & 4u);
   const uint32_t n = all ? a_in.n_instances : ncand;
   // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
   // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
@@ -1057,6 +1095,13 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
     float lo[3], hi[3];
     if (all) {  // more instances than the list holds: walk every instance box in index order
       ii = ci;
+      if (by_groups) {  // ... a large scene's in slot order, the groups the bundle's cull let through only (their mask sits behind the list)
+        if ((ci & 63u) == 0u) {
+          const uint32_t gbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[kMaxCand + (ci >> 11)]);
+          if (!((gbits >> ((ci >> 6) & 31u)) & 1u)) { ci += 63u; continue; }
+        }
+        ii = __float_as_uint(a.sboxes[ci].pad0);
+      }
     } else {
       const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[ci]);  // same address in every lane: LDS broadcast
       ii = c & 0xFFFFu;
@@ -1581,7 +1626,7 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
     for (; i < n16; i += step) dst[i] = src[i];
   }
   {  // the instance boxes the packet cull streams through, when they fit as well
-    DUST_RO(u32x4) bsrc = (DUST_RO(u32x4))a.boxes;
+    DUST_RO(u32x4) bsrc = (DUST_RO(u32x4))(a.n_groups ? a.gboxes : a.boxes);  // (n_lds_boxes of them: instance boxes, or the group boxes of a large scene)
     u32x4* bdst = lds_boxes(a);
     for (uint32_t i = threadIdx.x; i < a.n_lds_boxes * 2u; i += blockDim.x) bdst[i] = bsrc[i];
   }

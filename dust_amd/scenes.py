@@ -62,6 +62,29 @@ class SceneDesc:
         return sum(len(b) for b, _ in self.models)
 
 
+def scatter_props(desc: SceneDesc, n, scale=1.0, seed=0xB0B):
+    """Adds 8 small models and n instances of them to a castle scene (y up, ground at y = 0, +-640 in x and z at scale 1), with
+    arbitrary rotations about the vertical axis: the scene of bench.py --props / curves.many_instances (thousands of TLAS entries,
+    accel_struct/tlas.rs:79-117)."""
+    rng = np.random.default_rng(seed)
+    first = len(desc.models)
+    for _ in range(8):
+        sz = tuple(int(v) for v in rng.integers(10, 25, 3))
+        solid = rng.random(sz) < 0.55
+        solid[1:-1, 1:-1, 1:-1] &= rng.random((sz[0] - 2, sz[1] - 2, sz[2] - 2)) < 0.3
+        x, y, z = np.nonzero(solid)
+        xyzi = np.stack([x, y, z, rng.integers(0, 255, x.size)], axis=1).astype(np.uint8)
+        desc.models.append(api.flatten_model(xyzi, sz, desc.palette))
+    for _ in range(int(n)):
+        ang = float(rng.uniform(0.0, 2.0 * np.pi))
+        c, sn = np.cos(ang), np.sin(ang)
+        m = np.zeros((3, 4), np.float32)
+        m[:, :3] = np.array([[c, 0.0, sn], [0.0, 1.0, 0.0], [-sn, 0.0, c]], np.float32)
+        m[:, 3] = (rng.uniform(-640.0, 640.0) * scale, rng.uniform(0.0, 60.0) * scale, rng.uniform(-640.0, 640.0) * scale)
+        desc.instances.append((first + int(rng.integers(0, 8)), m.reshape(12)))
+    return desc
+
+
 def hip_scene(ctx, desc: SceneDesc):
     models = [api.Model(ctx, b, m, desc.palette) for b, m in desc.models]
     s = api.Scene(ctx)

@@ -95,6 +95,8 @@ def main():
     else:
         data, info = synth.castle_scene()
         desc = P.SceneDesc.from_vox(data)
+        if "--props" in sys.argv:   # the castle + N scattered props (bench.py --props): the cull's 64-wide hierarchy
+            P.scatter_props(desc, int(sys.argv[sys.argv.index("--props") + 1]))
         scene = P.hip_scene(ctx, desc)
         eye = (122.0, 300.61, 54.45)
     pipe = api.StandardPipeline(ctx, W, H)
