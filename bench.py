@@ -79,6 +79,10 @@ def parse(argv=None):
                     help="N > 1, row bands: native = the library's own RCCL path (dust_hip_comm_create / dust_hip_gather_bands / "
                          "dust_hip_gi_exchange_run: grouped send / receive on the communicator's stream, enqueued by the call that follows the "
                          "band's render call); torch = the same collectives through torch.distributed (round 3)")
+    ap.add_argument("--denoise", action="store_true",
+                    help="primary_ao: every frame is also filtered (DUST_PASS_DENOISE, the reference's NRD step). On N > 1 GPUs with row bands and the "
+                         "native communicator: ONE dust_hip_gather_planes moves the five planes the filter reads (+ the two the tone map reads) to rank 0, "
+                         "which filters the whole frame")
     ap.add_argument("--props", type=int, default=0,
                     help="castle workloads: this many small extra instances scattered over the scene (curves.many_instances uses 4000: the packet "
                          "cull then goes through its 64-wide hierarchy, cull_instances in traverse.hpp)")
@@ -218,11 +222,28 @@ class HipBackend:
     def make_comm(self, dist, ctx):
         """The library's RCCL communicator for one context (lane): rank 0 makes the id, torch.distributed carries it."""
         torch = self.torch
+        # every rank makes the same collectives whatever fails where: the id travels unconditionally (all zero = "rank 0 could not make one"),
+        # then the ranks agree on whether every one of them got its communicator -- a rank that raised alone would leave the others in a
+        # collective it never joins
         uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        err = None
         if self.rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(self.api.Comm.unique_id()), dtype=torch.uint8))
+            try:
+                uid.copy_(torch.frombuffer(bytearray(self.api.Comm.unique_id()), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001 -- e.g. no librccl on this node
+                err = e
         dist.broadcast(uid, src=0)
-        return self.api.Comm.create(ctx, self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
+        comm = None
+        if err is None and bool(uid.any().item()):
+            try:
+                comm = self.api.Comm.create(ctx, self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
+            except Exception as e:  # noqa: BLE001
+                err = e
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok.item()):
+            raise RuntimeError(f"native communicator unavailable on at least one rank ({err or 'another rank failed'})")
+        return comm
 
     def noise(self):
         return self.assets.noise()   # the reference's STBN textures if --assets holds them (sha256), else the stand-ins
@@ -254,8 +275,9 @@ class NativeGather:
     """AsyncGather's interface over the library's own collectives (dust_hip_gather_bands): slot b is render target b of lane b % D;
     the gather of step k moves every rank's rows of that target to the root's copy of it, in place, on the communicator's stream."""
 
-    def __init__(self, comms, pipes, plane, cuts, slots, rotate, world):
+    def __init__(self, comms, pipes, plane, cuts, slots, rotate, world, planes=None):
         self.comms, self.pipes, self.plane, self.slots, self.rotate, self.world = comms, pipes, plane, slots, rotate, world
+        self.planes = planes
         self.cuts = (ctypes.c_uint32 * len(cuts))(*[int(v) for v in cuts])
         self.tickets = [0] * slots
         self.root = 0
@@ -269,7 +291,10 @@ class NativeGather:
     def submit_slot(self, b, k):
         self.root = k % self.world if self.rotate else 0
         lane = b % len(self.comms)
-        self.tickets[b] = self.comms[lane].gather_bands(self.pipes[lane], self.plane, self.cuts, self.root)
+        if self.planes:   # --denoise: every plane the root's filter and tone map read, in one collective
+            self.tickets[b] = self.comms[lane].gather_planes(self.pipes[lane], self.planes, self.cuts, self.root)
+        else:
+            self.tickets[b] = self.comms[lane].gather_bands(self.pipes[lane], self.plane, self.cuts, self.root)
 
     def finish(self):
         for c in self.comms:
@@ -294,6 +319,9 @@ def measure_curve(be, dist, args, lanes, shard):
     if gi_mode:  # diffuse GI through the surfel-fed spatial hash
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
     bands = shard == "bands"
+    denoise = bool(getattr(args, "denoise", False)) and not gi_mode
+    if denoise and world == 1:
+        passes |= L.PASS_DENOISE   # one GPU: the filter is one more pass of the frame
     per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
     emulate = os.environ.get("DUST_BENCH_EMULATE_BAND")  # "r/N" on ONE GPU: this rank renders band r of N, nothing is gathered --
     emulate = emulate if (emulate and bands and world == 1) else None   # what a rank of an N-GPU strong-scaling run does between collectives
@@ -356,8 +384,10 @@ def measure_curve(be, dist, args, lanes, shard):
         native = bool(agreed.item())
     if native:
         row_cuts = band_cuts if band_cuts else [min(H, r * per_rows) for r in range(world)] + [H]
-        gather = NativeGather([lane.comm for lane in lanes], [lane.pipe for lane in lanes], L.PLANE_ILLUMINANCE, row_cuts, S, rotate=assemble == "rotate",
-                              world=world)
+        # --denoise: the root keeps the filter's history, so it stays rank 0; every plane the filter and the tone map read travels
+        dn_planes = (L.PLANE_ILLUMINANCE, L.PLANE_DEPTH, L.PLANE_NORMAL, L.PLANE_MOTION, L.PLANE_VOXEL_ID, L.PLANE_DENOISED, L.PLANE_ALBEDO) if denoise else None
+        gather = NativeGather([lane.comm for lane in lanes], [lane.pipe for lane in lanes], L.PLANE_ILLUMINANCE, row_cuts, S,
+                              rotate=assemble == "rotate" and not denoise, world=world, planes=dn_planes)
     else:
         gather = sharding.AsyncGather(dist, targets[0][send[0]:send[0] + (per_rows if bands else send[1] - send[0])], depth=S, rotate=assemble == "rotate", slices=slices)
     pix_stats = []
@@ -406,6 +436,9 @@ def measure_curve(be, dist, args, lanes, shard):
             pipe.render(scene, cam, sky, passes | cs, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         if world > 1 and native:
             gather.submit_slot(k % S, k)   # grouped send / receive of the bands' rows, in place in the root's target, on the communicator's stream
+            if denoise and rank == 0:      # the root filters the gathered frame (its stream waits for the gather on the device, not the host)
+                gather.wait_slot(k % S)
+                pipe.render(scene, cam, sky, L.PASS_DENOISE, frame_index=frame_index, rand=synth.frame_rand(1, frame_index))
         elif world > 1:
             gather.submit_view(targets[k % S][send[0]:send[1]])  # asynchronous gather, straight from the target
 
@@ -489,7 +522,7 @@ def measure_curve(be, dist, args, lanes, shard):
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
             "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts,
-            "comm": "native" if native else "torch"}
+            "comm": "native" if native else "torch", "denoise": denoise}
 
 
 def compact(curve, gi_mode):
@@ -794,11 +827,11 @@ def run_rank(args, be, dist):
                    "frame": [W, H], "spp_per_step": 1 if bands_main else world, "parallelism": parallelism(main_curve),
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": sc["n_bricks"], "scene_build_s": round(sc["t_load"], 3), "untimed_steps_before_timing": main_curve["settle"],
-                   "frames_in_flight": main_curve["frames_in_flight"],
+                   "frames_in_flight": main_curve["frames_in_flight"], "denoise": bool(main_curve.get("denoise")),
                    "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(main_curve["rays_per_step"])},
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),
-                                  "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"],
+                                  "rays_per_step_all_gpus": int(c["rays_per_step"]), "parallelism": parallelism(c), "frames_in_flight": c["frames_in_flight"], "denoise": bool(c.get("denoise")),
                                   **({"collectives": "libdust_hip.so's own RCCL path (dust_hip_gather_bands / dust_hip_gi_exchange_run)" if c.get("comm") == "native"
                                       else "torch.distributed (RCCL)"} if world > 1 else {}),
                                   "settle_steps": c["settle"], **({"band_rows": c["band_cuts"]} if c.get("band_cuts") else {}),

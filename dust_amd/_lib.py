@@ -181,6 +181,7 @@ SYMBOLS = {
     "dust_hip_comm_destroy": (None, [_P]),
     "dust_hip_comm_info": (C.c_int, [_P, _u32p, _u32p, _u32p]),
     "dust_hip_gather_bands": (C.c_int, [_P, _P, C.c_int, _u32p, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "dust_hip_gather_planes": (C.c_int, [_P, _P, C.c_uint32, _u32p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "dust_hip_comm_wait": (C.c_int, [_P, C.c_uint64]),
     "dust_hip_comm_sync": (C.c_int, [_P]),
     "dust_hip_gi_exchange_run": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

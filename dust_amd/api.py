@@ -552,6 +552,16 @@ class Comm:
         L.check(self._lib.dust_hip_gather_bands(pipe._h, self._h, plane, c, root, C.c_void_p(dst_ptr) if dst_ptr else None, dst_bytes, C.byref(t)))
         return t.value
 
+    def gather_planes(self, pipe, planes, cuts, root=0):
+        """several planes (an iterable of DUST_PLANE_* indices) in one collective, each into the root pipeline's own plane -> ticket"""
+        c = cuts if isinstance(cuts, C.Array) else (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        mask = 0
+        for pl in planes:
+            mask |= 1 << int(pl)
+        t = C.c_uint64()
+        L.check(self._lib.dust_hip_gather_planes(pipe._h, self._h, mask, c, root, C.byref(t)))
+        return t.value
+
     def gi_exchange(self, pipe, row_begin, row_end, band_rows, frame_index):
         L.check(self._lib.dust_hip_gi_exchange_run(pipe._h, self._h, row_begin, row_end, band_rows, frame_index))
 

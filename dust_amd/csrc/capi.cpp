@@ -193,6 +193,7 @@ struct DustHipContext : RefCounted {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_side_done = nullptr;
   bool side_busy = false;
+  std::vector<hipStream_t> extra_streams;  // communicators' gather streams (comm.hip): they read pipelines' planes, so every wait for the context covers them
   hipStream_t copy = nullptr;  // scene commits upload on a stream of their own (the copy engine), beside the frame in flight -- never between two frames
 };
 // wait for everything enqueued on the context's stream (and remember that we did: scene commits recycle their pinned staging
@@ -200,6 +201,8 @@ struct DustHipContext : RefCounted {
 static hipError_t sync_stream(DustHipContext* c) {
   hipError_t e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess && c->side) { e = hipStreamSynchronize(c->side); c->side_busy = false; }
+  for (hipStream_t x : c->extra_streams)
+    if (e == hipSuccess) e = hipStreamSynchronize(x);
   if (e == hipSuccess) ++c->sync_epoch;
   return e;
 }
@@ -1592,7 +1595,7 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     h.recorded = true; h.measured = true;
     if (still) h.refresh = std::min(kOrderRefreshMax, h.refresh * 2u);
   }
-  h.moving = !still;
+  h.moving = !still && h.view != p->view_key && h.measured && h.view != 0;  // (the first launch of a view that stands still is not a moving one)
   h.view = p->view_key;
   return DUST_OK;
 }
@@ -2349,4 +2352,20 @@ void context_retain(DustHipContext* c) { retain(c); }
 void context_release(DustHipContext* c) { release(c); }
 DustHipContext* pipeline_context(DustHipPipeline* p) { return p->ctx; }
 void pipeline_size(DustHipPipeline* p, uint32_t* width, uint32_t* height) { *width = p->width; *height = p->height; }
+DustStatus gi_exchange_view(DustHipPipeline* p, uint32_t padded_rows, DustHipGiExchange* out) {
+  if (!p->gi_touched.p || p->gi_touched_rows != padded_rows)
+    return fail(DUST_ERR_NOT_READY, "the GI exchange buffers were not prepared for this world x band_rows: call dust_hip_pipeline_gi_exchange(p, world * band_rows) "
+                                    "BEFORE the frame's final gather (a later call would re-create them and drop the frame's stamps)");
+  out->pool_size = p->gi_pool_size;
+  out->width = p->width;
+  out->touched_rows = padded_rows;
+  out->slot_owner = p->gi_owner.p;
+  out->touched = p->gi_touched.p;
+  out->merged = p->gi_merged.p;
+  return DUST_OK;
+}
+void context_add_stream(DustHipContext* c, hipStream_t s) { c->extra_streams.push_back(s); }
+void context_remove_stream(DustHipContext* c, hipStream_t s) {
+  c->extra_streams.erase(std::remove(c->extra_streams.begin(), c->extra_streams.end(), s), c->extra_streams.end());
+}
 }  // namespace dust_internal

@@ -14,4 +14,10 @@ void context_retain(DustHipContext*);
 void context_release(DustHipContext*);
 DustHipContext* pipeline_context(DustHipPipeline*);
 void pipeline_size(DustHipPipeline*, uint32_t* width, uint32_t* height);
+// the exchange buffers dust_hip_pipeline_gi_exchange(p, padded_rows) made, WITHOUT (re)making them: DUST_ERR_NOT_READY when the
+// pipeline's buffers were prepared for another padded_rows (or not at all) -- a frame's stamps must not be dropped by a re-allocation
+DustStatus gi_exchange_view(DustHipPipeline*, uint32_t padded_rows, DustHipGiExchange* out);
+// a stream of another object (a communicator's) that reads the context's pipelines: sync_stream waits for it too
+void context_add_stream(DustHipContext*, hipStream_t);
+void context_remove_stream(DustHipContext*, hipStream_t);
 }  // namespace dust_internal

@@ -14,7 +14,14 @@
 // librccl is opened on first use (dlopen): a single-GPU host never loads it, and the library has no link-time dependency on it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>) && !defined(DUST_NO_RCCL_HEADERS)
 #include <rccl/rccl.h>
+#define DUST_HAVE_RCCL 1
+#else   // a build host without the RCCL headers: loopback groups only, RCCL communicators report DUST_ERR_UNSUPPORTED
+#define DUST_HAVE_RCCL 0
+#define DUST_HIP_NCCL_ID_BYTES 128
+typedef struct ncclComm* ncclComm_t;
+#endif
 
 #include <cstring>
 #include <memory>
@@ -28,6 +35,7 @@ namespace {
 
 using dust_internal::set_error;
 
+#if DUST_HAVE_RCCL
 struct Rccl {
   void* lib = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -67,11 +75,14 @@ Rccl* rccl() {  // opened once; null (with the reason in last_error) when the no
   });
   return r.lib ? &r : nullptr;
 }
+#endif
 DustStatus no_rccl() { return set_error(DUST_ERR_UNSUPPORTED, "RCCL is not available on this node (librccl.so could not be opened)"); }
+#if DUST_HAVE_RCCL
 DustStatus nccl_fail(ncclResult_t e, const char* what) {
   Rccl* r = rccl();
   return set_error(DUST_ERR_HIP, std::string(what) + ": " + (r ? r->GetErrorString(e) : "rccl error"));
 }
+#endif
 DustStatus hip_fail(hipError_t e, const char* what) { return set_error(DUST_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
 #define NCCL_TRY(expr) do { ncclResult_t e_ = (expr); if (e_ != ncclSuccess) return nccl_fail(e_, #expr); } while (0)
@@ -83,7 +94,7 @@ constexpr uint32_t kMaxWorld = 64;
 struct LocalCall {
   int op = 0;  // 0 none, 1 gather_bands, 2 gi_exchange
   DustHipPipeline* pipe = nullptr;
-  DustHipPlane plane = DUST_PLANE_ILLUMINANCE;
+  uint32_t planes = 0;  // bit i: plane i travels
   std::vector<uint32_t> cuts;
   uint32_t root = 0;
   void* dst = nullptr;
@@ -148,18 +159,21 @@ DustStatus check_cuts(const uint32_t* cuts, uint32_t world, uint32_t height) {
 DustStatus run_local_gather(LocalGroup& g, hipStream_t st) {
   const LocalCall& c0 = g.calls[0];
   for (const LocalCall& c : g.calls)
-    if (c.plane != c0.plane || c.root != c0.root || c.cuts != c0.cuts) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks of a gather disagree about plane, root or cuts");
+    if (c.planes != c0.planes || c.root != c0.root || c.cuts != c0.cuts) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks of a gather disagree about planes, root or cuts");
   const LocalCall& root = g.calls[c0.root];
-  PlaneView rv;
-  DUST_TRY(plane_view(root.pipe, root.plane, &rv));
-  uint8_t* dst = root.dst ? static_cast<uint8_t*>(root.dst) : rv.ptr;
-  if (root.dst && root.dst_bytes < rv.row_bytes * rv.height) return set_error(DUST_ERR_INVALID_ARGUMENT, "gather destination smaller than the plane");
-  for (uint32_t r = 0; r < g.world; ++r) {
-    PlaneView v;
-    DUST_TRY(plane_view(g.calls[r].pipe, c0.plane, &v));
-    if (v.row_bytes != rv.row_bytes || v.height != rv.height) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' frames differ in size");
-    const size_t off = size_t(c0.cuts[r]) * v.row_bytes, n = size_t(c0.cuts[r + 1] - c0.cuts[r]) * v.row_bytes;
-    if (n && v.ptr + off != dst + off) HIP_TRY(hipMemcpyAsync(dst + off, v.ptr + off, n, hipMemcpyDeviceToDevice, st));
+  for (uint32_t pl = 0; pl < DUST_PLANE_COUNT; ++pl) {
+    if (!((c0.planes >> pl) & 1u)) continue;
+    PlaneView rv;
+    DUST_TRY(plane_view(root.pipe, DustHipPlane(pl), &rv));
+    uint8_t* dst = root.dst ? static_cast<uint8_t*>(root.dst) : rv.ptr;
+    if (root.dst && root.dst_bytes < rv.row_bytes * rv.height) return set_error(DUST_ERR_INVALID_ARGUMENT, "gather destination smaller than the plane");
+    for (uint32_t r = 0; r < g.world; ++r) {
+      PlaneView v;
+      DUST_TRY(plane_view(g.calls[r].pipe, DustHipPlane(pl), &v));
+      if (v.row_bytes != rv.row_bytes || v.height != rv.height) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' frames differ in size");
+      const size_t off = size_t(c0.cuts[r]) * v.row_bytes, n = size_t(c0.cuts[r + 1] - c0.cuts[r]) * v.row_bytes;
+      if (n && v.ptr + off != dst + off) HIP_TRY(hipMemcpyAsync(dst + off, v.ptr + off, n, hipMemcpyDeviceToDevice, st));
+    }
   }
   return DUST_OK;
 }
@@ -170,7 +184,7 @@ DustStatus run_local_gi(LocalGroup& g, hipStream_t st) {
   for (uint32_t r = 0; r < W; ++r) {
     if (g.calls[r].band_rows != c0.band_rows || g.calls[r].frame_index != c0.frame_index) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks of a GI exchange disagree about band rows or frame");
     ex[r].struct_size = sizeof(DustHipGiExchange);
-    DUST_TRY(dust_hip_pipeline_gi_exchange(g.calls[r].pipe, W * c0.band_rows, &ex[r]));
+    DUST_TRY(dust_internal::gi_exchange_view(g.calls[r].pipe, W * c0.band_rows, &ex[r]));
     if (ex[r].pool_size != ex[0].pool_size || ex[r].width != ex[0].width) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' GI buffers differ in size");
   }
   // the pointer tables the reduction kernels read (uploaded from `host`, which the wait below keeps alive until the copy is done)
@@ -205,8 +219,15 @@ DustStatus run_local_gi(LocalGroup& g, hipStream_t st) {
 // rank `c`'s part of a collective on a loopback group: remember it; the call that completes the group runs it for everyone
 DustStatus local_call(DustHipComm* c, LocalCall&& call) {
   LocalGroup& g = *c->local;
-  if (g.calls[c->rank].op != 0) return set_error(DUST_ERR_INVALID_ARGUMENT, "this rank already has a collective pending: every rank of the group must make the call before any makes the next");
-  if (g.pending && g.op != call.op) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks of a loopback group are in different collectives");
+  // a call that cannot join the pending collective fails AND drops what was pending (the other ranks' records hold raw pipeline
+  // pointers: nothing of a broken collective is kept around for a later call to complete)
+  auto drop = [&g](const char* why) {
+    for (LocalCall& lc : g.calls) lc = LocalCall();
+    g.pending = 0;
+    return set_error(DUST_ERR_INVALID_ARGUMENT, why);
+  };
+  if (g.calls[c->rank].op != 0) return drop("this rank already has a collective pending: every rank of the group must make the call before any makes the next (the pending collective was dropped)");
+  if (g.pending && g.op != call.op) return drop("the ranks of a loopback group are in different collectives (the pending collective was dropped)");
   const int op = g.op = call.op;
   g.calls[c->rank] = std::move(call);
   if (++g.pending < g.world) return DUST_OK;
@@ -225,6 +246,7 @@ extern "C" {
 
 DustStatus dust_hip_comm_unique_id(uint8_t id[DUST_HIP_COMM_ID_BYTES]) {
   if (!id) return set_error(DUST_ERR_INVALID_ARGUMENT, "null id");
+#if DUST_HAVE_RCCL
   Rccl* r = rccl();
   if (!r) return no_rccl();
   static_assert(DUST_HIP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
@@ -232,10 +254,14 @@ DustStatus dust_hip_comm_unique_id(uint8_t id[DUST_HIP_COMM_ID_BYTES]) {
   NCCL_TRY(r->GetUniqueId(&u));
   std::memcpy(id, u.internal, DUST_HIP_COMM_ID_BYTES);
   return DUST_OK;
+#else
+  return no_rccl();
+#endif
 }
 
 DustStatus dust_hip_comm_create(DustHipContext* ctx, uint32_t rank, uint32_t world, const uint8_t id[DUST_HIP_COMM_ID_BYTES], DustHipComm** out) {
   if (!ctx || !id || !out || world == 0 || world > kMaxWorld || rank >= world) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+#if DUST_HAVE_RCCL
   Rccl* r = rccl();
   if (!r) return no_rccl();
   HIP_TRY(hipSetDevice(dust_internal::context_device(ctx)));
@@ -257,9 +283,14 @@ DustStatus dust_hip_comm_create(DustHipContext* ctx, uint32_t rank, uint32_t wor
   }
   c->ctx = ctx;
   dust_internal::context_retain(ctx);
+  dust_internal::context_add_stream(ctx, c->stream);  // (gathers read pipelines' planes on it: every wait for the context covers it)
   c->rank = rank; c->world = world;
   *out = c.release();
   return DUST_OK;
+#else
+  (void)rank;
+  return no_rccl();
+#endif
 }
 
 DustStatus dust_hip_comm_create_local(DustHipContext* ctx, uint32_t world, DustHipComm** out) {
@@ -288,7 +319,10 @@ void dust_hip_comm_destroy(DustHipComm* c) {
   if (!c) return;
   (void)hipSetDevice(dust_internal::context_device(c->ctx));
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+#if DUST_HAVE_RCCL
   if (c->nccl) { if (Rccl* r = rccl()) (void)r->CommDestroy(c->nccl); }
+#endif
+  if (c->stream) dust_internal::context_remove_stream(c->ctx, c->stream);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   for (hipEvent_t ev : c->ev_done) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -304,51 +338,74 @@ DustStatus dust_hip_comm_info(const DustHipComm* c, uint32_t* rank, uint32_t* wo
   return DUST_OK;
 }
 
-DustStatus dust_hip_gather_bands(DustHipPipeline* p, DustHipComm* c, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes,
-                                 uint64_t* ticket) {
-  if (!p || !c || plane >= DUST_PLANE_COUNT || root >= c->world) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad gather arguments");
+static DustStatus gather_planes(DustHipPipeline* p, DustHipComm* c, uint32_t planes, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes, uint64_t* ticket) {
+  if (!p || !c || planes == 0 || (planes >> DUST_PLANE_COUNT) != 0 || root >= c->world) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad gather arguments");
   if (ticket) *ticket = 0;
   if (dust_internal::pipeline_context(p) != c->ctx) return set_error(DUST_ERR_INVALID_ARGUMENT, "pipeline and communicator belong to different contexts");
-  PlaneView v;
-  DUST_TRY(plane_view(p, plane, &v));
-  DUST_TRY(check_cuts(cuts, c->world, v.height));
+  uint32_t height = 0, width = 0;
+  dust_internal::pipeline_size(p, &width, &height);
+  DUST_TRY(check_cuts(cuts, c->world, height));
   HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
   if (c->local) {
     LocalCall call;
-    call.op = 1; call.pipe = p; call.plane = plane; call.cuts.assign(cuts, cuts + c->world + 1); call.root = root; call.dst = dst; call.dst_bytes = dst_bytes;
+    call.op = 1; call.pipe = p; call.planes = planes; call.cuts.assign(cuts, cuts + c->world + 1); call.root = root; call.dst = dst; call.dst_bytes = dst_bytes;
     return local_call(c, std::move(call));
   }
+#if DUST_HAVE_RCCL
   Rccl* r = rccl();
   if (!r) return no_rccl();
   const bool is_root = c->rank == root;
-  uint8_t* out = is_root ? (dst ? static_cast<uint8_t*>(dst) : v.ptr) : nullptr;
-  if (is_root && dst && dst_bytes < v.row_bytes * v.height) return set_error(DUST_ERR_INVALID_ARGUMENT, "gather destination smaller than the plane");
   // behind the frame that has just been enqueued on the context's stream, on the communicator's own stream
   const hipStream_t main = dust_internal::context_stream(c->ctx);
   HIP_TRY(hipEventRecord(c->ev_ready, main));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
-  NCCL_TRY(r->GroupStart());
-  ncclResult_t ne = ncclSuccess;
-  if (is_root) {
-    for (uint32_t q = 0; q < c->world && ne == ncclSuccess; ++q) {
-      const size_t off = size_t(cuts[q]) * v.row_bytes, n = size_t(cuts[q + 1] - cuts[q]) * v.row_bytes;
-      if (q != root && n) ne = r->Recv(out + off, n, ncclChar, int(q), c->nccl, c->stream);
+  PlaneView views[DUST_PLANE_COUNT];
+  for (uint32_t pl = 0; pl < DUST_PLANE_COUNT; ++pl)
+    if ((planes >> pl) & 1u) {
+      DUST_TRY(plane_view(p, DustHipPlane(pl), &views[pl]));
+      if (is_root && dst && dst_bytes < views[pl].row_bytes * views[pl].height) return set_error(DUST_ERR_INVALID_ARGUMENT, "gather destination smaller than the plane");
     }
-  } else {
-    const size_t off = size_t(cuts[c->rank]) * v.row_bytes, n = size_t(cuts[c->rank + 1] - cuts[c->rank]) * v.row_bytes;
-    if (n) ne = r->Send(v.ptr + off, n, ncclChar, int(root), c->nccl, c->stream);
+  NCCL_TRY(r->GroupStart());  // ONE group for every plane and peer: all transfers of the frame are in flight together, each peer over its own link
+  ncclResult_t ne = ncclSuccess;
+  for (uint32_t pl = 0; pl < DUST_PLANE_COUNT && ne == ncclSuccess; ++pl) {
+    if (!((planes >> pl) & 1u)) continue;
+    const PlaneView& v = views[pl];
+    uint8_t* out = is_root ? (dst ? static_cast<uint8_t*>(dst) : v.ptr) : nullptr;
+    if (is_root) {
+      for (uint32_t q = 0; q < c->world && ne == ncclSuccess; ++q) {
+        const size_t off = size_t(cuts[q]) * v.row_bytes, n = size_t(cuts[q + 1] - cuts[q]) * v.row_bytes;
+        if (q != root && n) ne = r->Recv(out + off, n, ncclChar, int(q), c->nccl, c->stream);
+      }
+    } else {
+      const size_t off = size_t(cuts[c->rank]) * v.row_bytes, n = size_t(cuts[c->rank + 1] - cuts[c->rank]) * v.row_bytes;
+      if (n) ne = r->Send(v.ptr + off, n, ncclChar, int(root), c->nccl, c->stream);
+    }
   }
   const ncclResult_t ge = r->GroupEnd();
   if (ne != ncclSuccess) return nccl_fail(ne, "ncclSend / ncclRecv");
   if (ge != ncclSuccess) return nccl_fail(ge, "ncclGroupEnd");
-  if (is_root && out != v.ptr) {  // the root's own rows
-    const size_t off = size_t(cuts[root]) * v.row_bytes, n = size_t(cuts[root + 1] - cuts[root]) * v.row_bytes;
-    if (n) HIP_TRY(hipMemcpyAsync(out + off, v.ptr + off, n, hipMemcpyDeviceToDevice, c->stream));
-  }
+  if (is_root && dst)   // the root's own rows (one plane: gather_bands with a destination)
+    for (uint32_t pl = 0; pl < DUST_PLANE_COUNT; ++pl)
+      if ((planes >> pl) & 1u) {
+        const PlaneView& v = views[pl];
+        const size_t off = size_t(cuts[root]) * v.row_bytes, n = size_t(cuts[root + 1] - cuts[root]) * v.row_bytes;
+        if (n && dst != v.ptr) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(dst) + off, v.ptr + off, n, hipMemcpyDeviceToDevice, c->stream));
+      }
   const uint64_t t = c->next_ticket++;
   HIP_TRY(hipEventRecord(c->ev_done[t % DustHipComm::kTickets], c->stream));
   if (ticket) *ticket = t;
   return DUST_OK;
+#else
+  return no_rccl();
+#endif
+}
+DustStatus dust_hip_gather_bands(DustHipPipeline* p, DustHipComm* c, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes,
+                                 uint64_t* ticket) {
+  if (plane >= DUST_PLANE_COUNT) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad gather arguments");
+  return gather_planes(p, c, 1u << plane, cuts, root, dst, dst_bytes, ticket);
+}
+DustStatus dust_hip_gather_planes(DustHipPipeline* p, DustHipComm* c, uint32_t plane_mask, const uint32_t* cuts, uint32_t root, uint64_t* ticket) {
+  return gather_planes(p, c, plane_mask, cuts, root, nullptr, 0, ticket);
 }
 
 DustStatus dust_hip_comm_wait(DustHipComm* c, uint64_t ticket) {
@@ -380,11 +437,12 @@ DustStatus dust_hip_gi_exchange_run(DustHipPipeline* p, DustHipComm* c, uint32_t
   }
   DustHipGiExchange ex;
   ex.struct_size = sizeof ex;
-  DUST_TRY(dust_hip_pipeline_gi_exchange(p, c->world * band_rows, &ex));
+  DUST_TRY(dust_internal::gi_exchange_view(p, c->world * band_rows, &ex));
   if (c->world == 1) {  // nothing to exchange: the band is the frame
     DUST_TRY(dust_hip_gi_export(p, row_begin, row_end));
     return dust_hip_gi_import(p, row_begin, row_end, frame_index);
   }
+#if DUST_HAVE_RCCL
   Rccl* r = rccl();
   if (!r) return no_rccl();
   const hipStream_t st = dust_internal::context_stream(c->ctx);
@@ -394,6 +452,9 @@ DustStatus dust_hip_gi_exchange_run(DustHipPipeline* p, DustHipComm* c, uint32_t
   DUST_TRY(dust_hip_gi_export(p, row_begin, row_end));
   NCCL_TRY(r->AllReduce(ex.merged, ex.merged, size_t(ex.pool_size) * 4, ncclInt32, ncclSum, c->nccl, st));  // one contributor per slot: exact
   return dust_hip_gi_import(p, row_begin, row_end, frame_index);
+#else
+  return no_rccl();
+#endif
 }
 
 }  // extern "C"

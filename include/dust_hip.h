@@ -432,6 +432,12 @@ DustStatus dust_hip_comm_info(const DustHipComm*, uint32_t* rank, uint32_t* worl
  * Before a source target or `dst` is used again: dust_hip_comm_wait with that ticket. */
 DustStatus dust_hip_gather_bands(DustHipPipeline*, DustHipComm*, DustHipPlane plane, const uint32_t* cuts, uint32_t root, void* dst, size_t dst_bytes,
                                  uint64_t* ticket);
+/* The same for SEVERAL planes at once (plane_mask bit i = DustHipPlane i), each into the root pipeline's own plane: one RCCL group for
+ * every plane and peer, one ticket. What a frame needs on the root before a pass that reads across rows -- the denoiser, which stands
+ * in for the reference's NRD dispatch (crates/render/src/pipeline/nrd.rs:272-617; examples/castle.rs:190-231 runs render -> NRD -> tone
+ * map in that order): gather illuminance | depth | normal | motion | voxel id (| denoised | albedo for the tone map), then
+ * dust_hip_render_frame(root pipeline, passes = DUST_PASS_DENOISE) on the whole frame. */
+DustStatus dust_hip_gather_planes(DustHipPipeline*, DustHipComm*, uint32_t plane_mask, const uint32_t* cuts, uint32_t root, uint64_t* ticket);
 /* the context's stream waits (on the device) for gather `ticket` and every earlier one (0: for all enqueued so far) -- a host that
  * alternates two render targets waits for the gather that last read a target, not for the one still reading the other /
  * the host waits for every gather and for the context */

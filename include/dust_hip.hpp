@@ -375,6 +375,12 @@ class DeviceComm {
     check(dust_hip_gather_bands(p.raw(), h_, plane, cuts.data(), root, dst, dst_bytes, &ticket));
     return ticket;
   }
+  // several planes (bit i of the mask = DustHipPlane i) in one collective, each into the root pipeline's own plane
+  uint64_t gather_planes(StandardPipeline& p, uint32_t plane_mask, const std::vector<uint32_t>& cuts, uint32_t root) {
+    uint64_t ticket = 0;
+    check(dust_hip_gather_planes(p.raw(), h_, plane_mask, cuts.data(), root, &ticket));
+    return ticket;
+  }
   void gi_exchange(StandardPipeline& p, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index) {
     check(dust_hip_gi_exchange_run(p.raw(), h_, row_begin, row_end, band_rows, frame_index));
   }

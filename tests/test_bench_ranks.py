@@ -46,6 +46,8 @@ class StubPipe:
         r0, r1 = rows if rows[1] else (0, H)
         self.n_render += 1
         self.last = {"passes": passes, "rows": (r0, r1), "frame": frame_index}
+        if passes == L.PASS_DENOISE:
+            self.calls.append(("denoise", frame_index, (r0, r1)))
         if passes & L.PASS_PRIMARY and self.target is None:
             self.px = (r1 - r0) * W   # (a frame into the pipeline's own plane: the cost-measuring launch before the targets exist)
         elif passes & L.PASS_PRIMARY:
@@ -96,6 +98,10 @@ class StubComm:
         self.n += 1
         StubComm.log.append(("gather", root, self.n))
         return self.n
+    def gather_planes(self, pipe, planes, cuts, root=0):
+        assert L.PLANE_DEPTH in planes and L.PLANE_ILLUMINANCE in planes and root == 0   # --denoise: the filter's planes, to the rank that keeps its history
+        StubComm.log.append(("gather_planes", tuple(planes)))
+        return self.gather_bands(pipe, L.PLANE_ILLUMINANCE, cuts, root)
     def wait(self, ticket=0): StubComm.log.append(("wait", ticket))
     def sync(self): StubComm.log.append(("sync",))
     def gi_exchange(self, pipe, r0, r1, band_rows, frame_index):
@@ -135,7 +141,7 @@ class StubBackend:
 
 
 args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", str(W), "--height", str(H),
-                    "--workload", workload, "--no-cpu-baseline"])
+                    "--workload", workload, "--no-cpu-baseline"] + (["--denoise"] if os.environ.get("BENCH_DENOISE") == "1" else []))
 bench.SETTLE_STEPS = 2
 # the ranks' own clocks disagree about how many more settle frames are due (rank 0: as many as allowed, rank 1: none); every step
 # holds a collective, so they must settle on one count or the job hangs
@@ -171,7 +177,12 @@ if rank == 0:
         assert "libdust_hip" in strong["collectives"], strong
         kinds = [c[0] for c in StubComm.log]
         assert kinds.count("gather") >= 3 + 7 + 1 and "wait" in kinds and "sync" in kinds, kinds
-        assert {c[1] for c in StubComm.log if c[0] == "gather"} == {0, 1}
+        if os.environ.get("BENCH_DENOISE") == "1":   # the filter's history lives on rank 0: every gather goes there, all seven planes at once,
+            assert {c[1] for c in StubComm.log if c[0] == "gather"} == {0} and "gather_planes" in kinds   # and rank 0 filters the whole frame
+            assert any(c[0] == "denoise" and c[2] == (0, H) for c in calls if isinstance(c, tuple)), calls[:12]
+            assert strong["denoise"] is True
+        else:
+            assert {c[1] for c in StubComm.log if c[0] == "gather"} == {0, 1}
         assert all(c[1] > 0 for c in StubComm.log if c[0] == "wait")
         if gi:
             assert ("gi_exchange", 0, 24, 24, 1) in StubComm.log, StubComm.log[:8]
@@ -187,7 +198,7 @@ dist.destroy_process_group()
 '''
 
 
-def _run(workload, native=False):
+def _run(workload, native=False, denoise=False):
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -195,7 +206,7 @@ def _run(workload, native=False):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
-                   BENCH_WORKLOAD=workload, BENCH_NATIVE="1" if native else "0")
+                   BENCH_WORKLOAD=workload, BENCH_NATIVE="1" if native else "0", BENCH_DENOISE="1" if denoise else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT={ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
@@ -218,6 +229,11 @@ def test_bench_rank_function_two_ranks_native_collectives():
     one gi_exchange call per frame) has executed before an 8-GPU node runs it over RCCL"""
     _run("primary_ao", native=True)
     _run("gi", native=True)
+
+
+def test_bench_rank_function_two_ranks_denoised_frames():
+    """--denoise on two ranks: one gather_planes per frame to rank 0 (which keeps the filter's history), then DUST_PASS_DENOISE there"""
+    _run("primary_ao", native=True, denoise=True)
 
 
 def test_bench_gpus_without_devices_says_so():

@@ -74,8 +74,13 @@ def test_loopback_refuses_what_a_collective_cannot_be():
     comms[0].gather_bands(p[0], L.PLANE_DEPTH, [0, 16, 32])
     with pytest.raises(L.DustError):
         comms[0].gather_bands(p[0], L.PLANE_DEPTH, [0, 16, 32])       # rank 0 is already waiting in this collective
+    # (a call that cannot join drops what was pending -- records that hold raw pipeline pointers are not kept for a later call to complete)
+    comms[0].gather_bands(p[0], L.PLANE_DEPTH, [0, 16, 32])
     with pytest.raises(L.DustError):
         comms[1].gather_bands(p[1], L.PLANE_DEPTH, [0, 8, 32])        # ranks disagree about the cuts
+    comms[0].gather_bands(p[0], L.PLANE_DEPTH, [0, 16, 32])
+    with pytest.raises(L.DustError):
+        comms[1].gi_exchange(p[1], 16, 32, 16, 1)                     # ranks are in different collectives
     # (the failed collective is dropped: the group starts clean)
     for r in range(2):
         comms[r].gather_bands(p[r], L.PLANE_DEPTH, [0, 16, 32])
@@ -160,3 +165,69 @@ def test_rccl_communicator_of_one_rank():
     p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, 2, 6)
     comm.sync()
     del comm
+
+
+def test_gi_exchange_refuses_buffers_prepared_for_another_size():
+    """dust_hip_gi_exchange_run never re-creates the exchange buffers (that would drop the stamps the frame's final gather has just
+    written): buffers prepared for another world x band_rows are an error, not a silent re-allocation."""
+    ctx = api.Context(device=0)
+    comms = api.Comm.local(ctx, 2)
+    pipes = [api.StandardPipeline(ctx, 64, 40) for _ in range(2)]
+    for p in pipes:
+        p.configure_gi(1 << 10, 128)
+    with pytest.raises(L.DustError):
+        comms[0].gi_exchange(pipes[0], 0, 24, 24, 1)        # (never prepared: the call that completes the group reports it ...)
+        comms[1].gi_exchange(pipes[1], 24, 40, 24, 1)
+    for p in pipes:
+        p.gi_exchange(40)                                   # prepared for 40 padded rows; the run asks for 2 x 24 = 48
+    with pytest.raises(L.DustError):
+        comms[0].gi_exchange(pipes[0], 0, 24, 24, 1)
+        comms[1].gi_exchange(pipes[1], 24, 40, 24, 1)
+    for p in pipes:
+        p.gi_exchange(48)
+    comms[0].gi_exchange(pipes[0], 0, 24, 24, 1)
+    comms[1].gi_exchange(pipes[1], 24, 40, 24, 1)
+    comms[0].sync()
+
+
+@pytest.mark.parametrize("world", [8, 3])
+def test_denoised_frame_on_n_ranks_equals_the_single_device_frame(world):
+    """The reference denoises every frame (crates/render/src/pipeline/nrd.rs:272-617; examples/castle.rs:190-231: render -> NRD -> tone
+    map). On N ranks: every rank renders its band, ONE dust_hip_gather_planes moves the five planes the filter reads (illuminance,
+    depth, normal, motion, voxel id) to the root, the root filters the whole frame and tone-maps it. Four frames (the filter's history
+    builds up on the root): the denoised and the display planes equal the single pipeline's, bit for bit."""
+    W, H = 200, 152
+    ctx = api.Context(device=0)
+    scene = _scene(ctx)
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    sky = P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
+    planes = (L.PLANE_ILLUMINANCE, L.PLANE_DEPTH, L.PLANE_NORMAL, L.PLANE_MOTION, L.PLANE_VOXEL_ID, L.PLANE_DENOISED, L.PLANE_ALBEDO)
+    ref = api.StandardPipeline(ctx, W, H)
+    ref.set_noise(5, n5)
+    comms = api.Comm.local(ctx, world)
+    pipes = []
+    for r in range(world):
+        p = api.StandardPipeline(ctx, W, H)
+        p.set_noise(5, n5)
+        pipes.append(p)
+    cuts = [sharding.band_rows(r, world, H)[0] for r in range(world)] + [H]
+    root = 0
+    for f in range(1, 5):
+        eye = (122.0 * 0.15 + 0.3 * f, 300.61 * 0.15, 54.45 * 0.15 - 0.2 * f)   # a slowly moving view: reprojection, disocclusion
+        cam = P.camera_for(eye)
+        rnd = synth.frame_rand(5, f)
+        ref.render(scene, cam, sky, passes | L.PASS_DENOISE, f, rnd)
+        ref.tone_map()
+        for r in range(world):
+            if cuts[r] < cuts[r + 1]:
+                pipes[r].render(scene, cam, sky, passes, f, rnd, rows=(cuts[r], cuts[r + 1]))
+        for r in range(world):
+            comms[r].gather_planes(pipes[r], planes, cuts, root=root)
+        comms[root].wait()
+        pipes[root].render(scene, cam, sky, L.PASS_DENOISE, f, rnd)
+        pipes[root].tone_map()
+        comms[root].sync()
+        for pl in (L.PLANE_DENOISED, L.PLANE_ACCUM, L.PLANE_OUTPUT):
+            a, b = ref.read_plane(pl), pipes[root].read_plane(pl)
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (f, pl)
