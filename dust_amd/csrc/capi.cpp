@@ -1610,18 +1610,18 @@ static void take_counters(DustHipPipeline* p, uint32_t kind, dust::FrameArgs& a)
 // The ray stream of pass kind `kind` (0: final gather, 1: surfel pass) for the launch about to be made: its buffers, this launch's
 // ray counter (zero: the previous launch of the kind zeroed it) and the one the next launch will use.
 static void stream_args(DustHipPipeline* p, int kind, dust::FrameArgs& a, float tmin, float tmax) {
-  a.gi.unbinned = static_cast<uint32_t*>(p->gi_unbinned.p) + kind * 2;
-  a.gi.rays = static_cast<dust::DevRay*>(kind == 0 ? p->gi_rays_fg.p : p->gi_rays_sf.p);
-  a.gi.group_count = static_cast<uint32_t*>(kind == 0 ? p->gi_groups_fg.p : p->gi_groups_sf.p);
+  a.stream.unbinned = static_cast<uint32_t*>(p->gi_unbinned.p) + kind * 2;
+  a.stream.rays = static_cast<dust::DevRay*>(kind == 0 ? p->gi_rays_fg.p : p->gi_rays_sf.p);
+  a.stream.group_count = static_cast<uint32_t*>(kind == 0 ? p->gi_groups_fg.p : p->gi_groups_sf.p);
   if (kind == 0) {  // a group = a 16 x 16 pixel tile of the band (k_gather_rays)
-    a.gi.n_groups = ((p->width + 15u) / 16u) * ((a.row_end - a.row_begin + 15u) / 16u);
-    a.gi.group_rays = 256;
+    a.stream.n_groups = ((p->width + 15u) / 16u) * ((a.row_end - a.row_begin + 15u) / 16u);
+    a.stream.group_rays = 256;
   } else {          // a group = 256 consecutive surfels of the (ordered) pool, two rays each (k_surfel_rays)
-    a.gi.n_groups = (p->gi_pool_size + 255u) / 256u;
-    a.gi.group_rays = 512;
+    a.stream.n_groups = (p->gi_pool_size + 255u) / 256u;
+    a.stream.group_rays = 512;
   }
-  a.gi.ray_hits = static_cast<dust::DevGatherHit*>(kind == 0 ? p->gi_fg_hits.p : p->gi_hits_sf.p);
-  a.gi.ray_tmin = tmin; a.gi.ray_tmax = tmax;
+  a.stream.ray_hits = static_cast<dust::DevGatherHit*>(kind == 0 ? p->gi_fg_hits.p : p->gi_hits_sf.p);
+  a.stream.ray_tmin = tmin; a.stream.ray_tmax = tmax;
   a.tile_order = nullptr; a.tile_cost = nullptr; a.band_cuts = nullptr;  // (the stream hands out rays, not tiles)
   a.tiles_x = a.tiles_y = 1;
 }
@@ -1656,8 +1656,8 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       // phase 1 as a ray stream (gi.hip): the pool's rays, compacted -> one ray per lane, lanes refilled -> the hash lookups over the hit records
       stream_args(p, 1, b, 0.1f, 10000.0f);  // surfel.rgen:33-62
       take_counters(p, 3, b);
-      b.gi.count_unbinned = count ? 1u : 0u;
-      if (count) HIP_TRY(hipMemsetAsync(b.gi.unbinned, 0, 2 * 4, st));
+      b.stream.count_unbinned = count ? 1u : 0u;
+      if (count) HIP_TRY(hipMemsetAsync(b.stream.unbinned, 0, 2 * 4, st));
       HIP_TRY(dust::launch_surfel_rays(b, st));
       // (one 1024-thread workgroup per CU: sixteen waves share one staged copy of the top-level data)
       const uint32_t want = (p->gi_pool_size * 2u + 1023u) / 1024u;
@@ -1913,10 +1913,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       // run beside the previous frame's surfel pass on the second stream; the shading waits for it (join_side).
       dust::FrameArgs g = a;
       stream_args(p, 0, g, 8.0f, a.cam.far_);  // final_gather.rgen:47-50
-      g.gi.fg_hits = g.gi.ray_hits;
+      g.gi.fg_hits = g.stream.ray_hits;
       take_counters(p, 2, g);
-      g.gi.count_unbinned = count ? 1u : 0u;
-      if (count) HIP_TRY(hipMemsetAsync(g.gi.unbinned, 0, 2 * 4, st));
+      g.stream.count_unbinned = count ? 1u : 0u;
+      if (count) HIP_TRY(hipMemsetAsync(g.stream.unbinned, 0, 2 * 4, st));
       if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
       HIP_TRY(dust::launch_gather_rays(g, st));
       const uint32_t want = uint32_t((size_t(p->width) * (a.row_end - a.row_begin) + 1023u) / 1024u);

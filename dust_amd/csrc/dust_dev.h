@@ -186,7 +186,10 @@ struct DevGI {
   DevSurfel* merged;        // multi-GPU: per slot, the winning surfel after the exchange
   DevGatherHit* fg_hits;    // per pixel: k_final_gather only TRACES and leaves its hits here, k_final_gather_shade does the hash lookups and
                             // stores afterwards (null: the gather kernel shades its own rays)
-  // ray streams (k_gather_rays / k_surfel_rays -> k_ray_stream -> k_final_gather_shade / k_surfel_shade)
+};
+
+struct DevStream {
+  // ray streams (k_gather_rays / k_surfel_rays -> k_ray_walk -> k_final_gather_shade / k_surfel_shade)
   DevRay* rays;             // the pass's rays in GROUPS: group g (a 16 x 16 pixel tile / 256 consecutive surfels) owns entries
   uint32_t* group_count;    //   [g * group_rays, g * group_rays + group_count[g]): its live rays, compacted inside the group
   uint32_t n_groups, group_rays;  // (no atomics, and the same order in every run)
@@ -205,15 +208,6 @@ struct FrameArgs {
   DUST_RO(uint8_t) root_table;  // n_lds_models x kN16LdsBytes, packed copy of those roots (mask + prefix)
   DUST_RO(DevBox) boxes;        // n_instances world boxes (copy of DevInstance::wmin/wmax, packed)
   DUST_RO(DevVisit) visits;     // n_instances {world -> object, model record}
-  DUST_RO(DevEnter) enters;     // n_instances compact enter records (the ray streams' instance set-up)
-  // Large scenes (more than kFlatCullMax instances; n_groups != 0): the packet cull's 64-wide hierarchy. The instances in the order
-  // of a space-filling curve through their boxes' centres, every 64 consecutive ones a group:
-  DUST_RO(DevBox) gboxes;       //   n_groups group boxes (the union of the group's instance boxes)
-  DUST_RO(DevBox) sboxes;       //   n_instances instance boxes in that order; pad0 (as a bit pattern) = the instance's id
-  uint32_t n_groups;
-  DevStreamLds sl_bin, sl_walk; // what the ray-making kernels / k_ray_walk stage in LDS
-  uint32_t stream_refill;       // k_ray_walk: lanes not walking at which a wave leaves the walk to set the others up (DUST_HIP_STREAM_REFILL)
-  uint32_t stream_top_iters;    // ... and the grid steps + box tests per phase of a lane that walks the grid itself (candidate overflow)
   float world_min[3], world_max[3];  // union of the instances' world boxes
   DevCamera cam;
   float sky[56];
@@ -245,12 +239,23 @@ struct FrameArgs {
   uint32_t accum_count;       // frames already in `accum`
   // hash-fed GI (final gather + surfel passes)
   DevGI gi;
-  DevGrid grid;               // top-level structure over the instances (per-ray walks of the GI passes)
   uint32_t deep;              // the scene holds a 4096^3 model with its per-cell table: launch the DEEP kernel variants
   uint32_t prio_floor;        // lowest issue priority this launch's waves run at (the surfel pass on the second stream, beside the next frame's kernels: 3)
   uint32_t debug;             // DUST_HIP_DEBUG ablation bits (1: skip tracing, 2: skip culling, 4: walk every instance in
                               // index order instead of the packet's sorted candidate list, 8: gather / surfel rays take the
                               // wave-uniform candidate walk of the coherent ray types); 0 in production
+  // ---- round 5, appended (the fields above keep the offsets the packet kernels were tuned with: their scalar loads come in aligned runs)
+  DUST_RO(DevEnter) enters;     // n_instances compact enter records (the ray streams' instance set-up)
+  // Large scenes (more than kFlatCullMax instances; n_groups != 0): the packet cull's 64-wide hierarchy. The instances in the order
+  // of a space-filling curve through their boxes' centres, every 64 consecutive ones a group:
+  DUST_RO(DevBox) gboxes;       //   n_groups group boxes (the union of the group's instance boxes)
+  DUST_RO(DevBox) sboxes;       //   n_instances instance boxes in that order; pad0 (as a bit pattern) = the instance's id
+  uint32_t n_groups;
+  DevStreamLds sl_bin, sl_walk; // what the ray-making kernels / k_ray_walk stage in LDS
+  uint32_t stream_refill;       // k_ray_walk: lanes not walking at which a wave leaves the walk to set the others up (DUST_HIP_STREAM_REFILL)
+  uint32_t stream_top_iters;    // ... and the grid steps + box tests per phase of a lane that walks the grid itself (candidate overflow)
+  DevGrid grid;               // top-level structure over the instances (per-ray walks of the GI passes)
+  DevStream stream;           // the pass's ray stream (DUST_HIP_RAY_STREAM)
 };
 
 }  // namespace dust

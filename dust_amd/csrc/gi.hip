@@ -859,12 +859,12 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
   PROF_LEAVE(P_STAGE);
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t lower = (1ull << lane) - 1ull;
-  const float tmin = a0.gi.ray_tmin, tmax = a0.gi.ray_tmax;
+  const float tmin = a0.stream.ray_tmin, tmax = a0.stream.ray_tmax;
   // The stream's groups (tiles of the frame / runs of the pool) are cut into chunks of about kStreamChunk rays; the chunks form
   // eight bands, one per XCD (block b runs on XCD b % 8: a band's rays -- neighbours in the frame or the pool -- stay in one L2).
   // A wave takes a chunk at a time from its band's counter, then helps the other bands.
-  const uint32_t sub = a0.gi.group_rays / kStreamChunk;        // chunks per group
-  const uint32_t chunks = a0.gi.n_groups * sub;
+  const uint32_t sub = a0.stream.group_rays / kStreamChunk;        // chunks per group
+  const uint32_t chunks = a0.stream.n_groups * sub;
   const uint32_t per = (chunks + kRegions - 1u) / kRegions;   // chunks per band
   const uint32_t own = blockIdx.x & 7u;
   uint32_t win_next = 0, win_end = 0, band_try = 0;
@@ -905,16 +905,16 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
             if (k >= per || c >= chunks) { band_try += 1u; continue; }
             // chunk c = part c % sub of group c / sub: the group's rays in `sub` equal parts
             const uint32_t grp = c / sub, part = c - grp * sub;
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gi.group_count[grp]);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.stream.group_count[grp]);
             const uint32_t q = (cnt + sub - 1u) / sub;
-            const uint32_t lo = grp * a.gi.group_rays + part * q, hi = grp * a.gi.group_rays + min(cnt, (part + 1u) * q);
+            const uint32_t lo = grp * a.stream.group_rays + part * q, hi = grp * a.stream.group_rays + min(cnt, (part + 1u) * q);
             if (lo < hi) { win_next = lo; win_end = hi; dry = false; break; }
           }
         }
         if (!dry) {
           const uint32_t rank = (uint32_t)__popcll(b_empty & lower);
           if (state == RS_EMPTY && win_next + rank < win_end) {
-            const u32x4* r = reinterpret_cast<const u32x4*>(a.gi.rays) + (size_t)(win_next + rank) * 3u;
+            const u32x4* r = reinterpret_cast<const u32x4*>(a.stream.rays) + (size_t)(win_next + rank) * 3u;
             f0 = r[0]; f1 = r[1]; f2 = r[2];
             state = RS_FETCH;
             PROF_COUNT_LANES(P_N_CAND, true);
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
     if (state == RS_DONE) {  // the ray's hit record; the lane is free
       u32x4 rec;
       rec.x = __float_as_uint(best.t); rec.y = best.inst; rec.z = best.block; rec.w = best.found ? 1u : 0u;
-      reinterpret_cast<u32x4*>(a.gi.ray_hits)[rid] = rec;
+      reinterpret_cast<u32x4*>(a.stream.ray_hits)[rid] = rec;
       if (COUNT) {
         if (best.found) cur.hits = 1;
         if (rflags & 1u) add_stats(st_any, cur); else add_stats(st_closest, cur);
@@ -1014,8 +1014,8 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
   }
   prof_end();
   if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) {  // the rays that met no instance box (counted by the ray-making kernel): traced, missed
-    if (RT == 2) st_closest.rays += a0.gi.unbinned[0];
-    else { st_any.rays += a0.gi.unbinned[1]; st_closest.rays += a0.gi.unbinned[0]; }
+    if (RT == 2) st_closest.rays += a0.stream.unbinned[0];
+    else { st_any.rays += a0.stream.unbinned[1]; st_closest.rays += a0.stream.unbinned[0]; }
   }
   if (RT == 2) flush_stats<MODE>(a0, 0, st_closest);
   else { flush_stats<MODE>(a0, 0, st_any); flush_stats<MODE>(a0, 1, st_closest); }
@@ -1040,19 +1040,19 @@ __device__ __forceinline__ void put_ray(ArgsRef a, uint32_t at, V3 o, uint32_t i
   u32x4 r0, r1;
   r0.x = __float_as_uint(o.x); r0.y = __float_as_uint(o.y); r0.z = __float_as_uint(o.z); r0.w = id;
   r1.x = __float_as_uint(d.x); r1.y = __float_as_uint(d.y); r1.z = __float_as_uint(d.z); r1.w = flags;
-  u32x4* r = reinterpret_cast<u32x4*>(a.gi.rays) + (size_t)at * 3u;
+  u32x4* r = reinterpret_cast<u32x4*>(a.stream.rays) + (size_t)at * 3u;
   r[0] = r0; r[1] = r1; r[2] = cand;
 }
 __device__ __forceinline__ void put_miss(ArgsRef a, uint32_t id) {  // the hit record of a ray that meets no instance box
   u32x4 rec;
-  rec.x = __float_as_uint(a.gi.ray_tmax); rec.y = 0u; rec.z = 0u; rec.w = 0u;
-  reinterpret_cast<u32x4*>(a.gi.ray_hits)[id] = rec;
+  rec.x = __float_as_uint(a.stream.ray_tmax); rec.y = 0u; rec.z = 0u; rec.w = 0u;
+  reinterpret_cast<u32x4*>(a.stream.ray_hits)[id] = rec;
 }
 // (counting build of the frame only: how many rays the binning settled itself; one atomic per workgroup)
 __device__ __forceinline__ void count_unbinned(ArgsRef a, uint32_t which, bool mine) {
-  if (!a.gi.count_unbinned) return;
+  if (!a.stream.count_unbinned) return;
   const uint32_t n = (uint32_t)__popcll(__ballot(mine));
-  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&a.gi.unbinned[which], n);
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&a.stream.unbinned[which], n);
 }
 
 // final_gather.rgen:14-44 for every pixel of the band, 16 x 16 pixel tile by tile: the pixel's gather ray, binned
@@ -1065,8 +1065,8 @@ __global__ void __launch_bounds__(256) k_gather_rays(const FrameArgs) {
   V3 inval, loc, ad;
   const bool live = gather_ray(a, px, py, px < a.width && py < a.row_end, inval, loc, ad);
   u32x4 cand;
-  const bool walk = bin_ray(a, src, live, loc, ad, a.gi.ray_tmin, a.gi.ray_tmax, cand) != 0u;
-  const uint32_t at = blockIdx.x * 256u + group_reserve(a.gi.group_count + blockIdx.x, walk, false);
+  const bool walk = bin_ray(a, src, live, loc, ad, a.stream.ray_tmin, a.stream.ray_tmax, cand) != 0u;
+  const uint32_t at = blockIdx.x * 256u + group_reserve(a.stream.group_count + blockIdx.x, walk, false);
   if (walk) put_ray(a, at, loc, py * a.width + px, ad, 0u, cand);
   else if (live) put_miss(a, py * a.width + px);
   count_unbinned(a, 0, live && !walk);
@@ -1105,9 +1105,9 @@ __global__ void __launch_bounds__(256) k_surfel_rays(const FrameArgs) {
   const bool lit = live && r.lit;
   const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
   u32x4 cand_cos, cand_sun;
-  const bool walk_cos = bin_ray(a, src, live, r.org, r.cos_dir, a.gi.ray_tmin, a.gi.ray_tmax, cand_cos) != 0u;
-  const bool walk_sun = bin_ray(a, src, lit, r.org, sd, a.gi.ray_tmin, a.gi.ray_tmax, cand_sun) != 0u;
-  const uint32_t at = blockIdx.x * 512u + group_reserve(a.gi.group_count + blockIdx.x, walk_cos, walk_sun);
+  const bool walk_cos = bin_ray(a, src, live, r.org, r.cos_dir, a.stream.ray_tmin, a.stream.ray_tmax, cand_cos) != 0u;
+  const bool walk_sun = bin_ray(a, src, lit, r.org, sd, a.stream.ray_tmin, a.stream.ray_tmax, cand_sun) != 0u;
+  const uint32_t at = blockIdx.x * 512u + group_reserve(a.stream.group_count + blockIdx.x, walk_cos, walk_sun);
   if (walk_cos) put_ray(a, at, r.org, 2u * i, r.cos_dir, 0u, cand_cos);
   else if (live) put_miss(a, 2u * i);
   if (walk_sun) put_ray(a, at + (walk_cos ? 1u : 0u), r.org, 2u * i + 1u, sd, 1u, cand_sun);
@@ -1132,13 +1132,13 @@ __global__ void __launch_bounds__(256) k_surfel_shade(const FrameArgs) {
   repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
   if (live) {
     if (r.lit) {  // surfel/nee.rmiss:15-27
-      const u32x4 hs = reinterpret_cast<const u32x4*>(a.gi.ray_hits)[2u * i + 1u];
+      const u32x4 hs = reinterpret_cast<const u32x4*>(a.stream.ray_hits)[2u * i + 1u];
       if (hs.w == 0u) {
         const float dn = dot3(r.n, sd);
         pay.x = a.sun_term[0] * dn; pay.y = a.sun_term[1] * dn; pay.z = a.sun_term[2] * dn;
       }
     }
-    const u32x4 hc = reinterpret_cast<const u32x4*>(a.gi.ray_hits)[2u * i];
+    const u32x4 hc = reinterpret_cast<const u32x4*>(a.stream.ray_hits)[2u * i];
     Hit h;
     h.t = __uint_as_float(hc.x); h.inst = hc.y; h.block = hc.z; h.voxel = 0; h.found = hc.w != 0u;
     rq.kx = f2i_trunc(e.x / 4.0f); rq.ky = f2i_trunc(e.y / 4.0f); rq.kz = f2i_trunc(e.z / 4.0f);
@@ -1227,7 +1227,7 @@ hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_surfel_shade, dim3((a.gi.pool_size + 255u) / 256u), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-// rt 2: gather rays, 3: surfel rays; the stream is a.gi.rays / group_count, the hit records go to a.gi.ray_hits
+// rt 2: gather rays, 3: surfel rays; the stream is a.stream.rays / group_count, the hit records go to a.stream.ray_hits
 hipError_t launch_ray_walk(const FrameArgs& a_in, int rt, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = (size_t)a_in.n_lds_models * kN16LdsBytes + a_in.sl_walk.total;
   const FrameArgs a = with_schedule(a_in, grid, block);

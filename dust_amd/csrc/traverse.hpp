@@ -958,9 +958,24 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
       f32x4 blo, bhi;
       if (in_lds) { blo = lbox[ic * 2u]; bhi = lbox[ic * 2u + 1u]; }
       else { blo = *(DUST_RO(f32x4))(&a.boxes[ic].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ic].hi[0]); }
-      float t_lo;
-      const bool pass = test(blo, bhi, i < n_inst, t_lo);
-      append(pass, t_lo, i);
+      const float wlo[3] = {blo.x, blo.y, blo.z}, whi[3] = {bhi.x, bhi.y, bhi.z};
+      float t_lo = 0.0f, t_hi = tmax;
+      bool pass = i < n_inst;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float c1 = whi[k] - org.lo[k], c2 = wlo[k] - org.hi[k];
+        const float q1 = c1 * r1[k], q2 = c2 * r2[k];
+        t_hi = fminf(t_hi, fminf(up1[k] ? q1 : INFINITY, up2[k] ? q2 : INFINITY));
+        t_lo = fmaxf(t_lo, fmaxf(lo1[k] ? q1 : 0.0f, lo2[k] ? q2 : 0.0f));
+        pass = pass & !(z1[k] & (c1 < 0.0f)) & !(z2[k] & (c2 > 0.0f));
+      }
+      pass = pass & !(t_lo > t_hi * (1.0f + 1e-5f) + 1e-4f);
+      const uint64_t bal = __ballot(pass);
+      if (pass) {
+        const uint32_t pos = n + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < kMaxCand) cand[pos] = (__float_as_uint(t_lo) & 0xFFFF0000u) | (i & 0xFFFFu);
+      }
+      n += (uint32_t)__popcll(bal);
     }
   } else {
     // Thousands of instances (the reference's TLAS, accel_struct/tlas.rs:79-117, holds one entry per entity): a 64-wide hierarchy.
