@@ -158,7 +158,7 @@ __device__ __forceinline__ void gather_packet(ArgsRef a0, uint32_t px, uint32_t 
   }
 #endif
   Hit h;
-  const uint32_t ncand = cull_instances(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
+  const uint32_t ncand = cull_instances<MODE>(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
   trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
   ArgsRef b = reload_args(a0);
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(512, 4) k_final_gather_pool(const FrameArgs) {
       merge_range(dir, wave_range(live, d));
       any = any | (__any(live) != 0);
     }
-    const uint32_t ncand = cull_instances(a, any, org, dir, a.cam.far_, cand);
+    const uint32_t ncand = cull_instances<MODE>(a, any, org, dir, a.cam.far_, cand);
     if (ncand > kMaxCand || (a.debug & 12u)) {  // the list overflowed (or a debug order was asked for): packets, each with its own cull
       for (uint32_t j = begin; j < end; j += 64u) {
         uint32_t px = 0, py = 0;
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
     Hit h;
     {
       const Range3 orgs = wave_range(live, org);
-      const uint32_t ncand = cull_instances(a, __any(act), orgs, sun_item ? point_range(sd) : wave_range(live, dir), 10000.0f, cand);
+      const uint32_t ncand = cull_instances<MODE>(a, __any(act), orgs, sun_item ? point_range(sd) : wave_range(live, dir), 10000.0f, cand);
       LaneStats cur = {0, 0, 0, 0, 0, 0};
       trace_ray<3, MODE>(a, act, org, dir, 0.1f, 10000.0f, sun_item, cand, ncand, h, cur);
       if (COUNT) add_stats(sun_item ? st_sun : st_cos, cur);
@@ -1243,9 +1243,9 @@ hipError_t launch_ray_walk(const FrameArgs& a_in, int rt, uint32_t grid, uint32_
 }
 hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_kernels left after the build's static LDS)
   const void* fns[] = {
-      (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>,
-      (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>,
-      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>,
+      (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>, (const void*)k_final_gather<4>, (const void*)k_final_gather<5>, (const void*)k_final_gather<6>, (const void*)k_final_gather<7>,
+      (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>, (const void*)k_final_gather_pool<4>, (const void*)k_final_gather_pool<5>, (const void*)k_final_gather_pool<6>, (const void*)k_final_gather_pool<7>,
+      (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>, (const void*)k_surfel_trace<4>, (const void*)k_surfel_trace<5>, (const void*)k_surfel_trace<6>, (const void*)k_surfel_trace<7>,
       (const void*)k_ray_walk<2, 0>, (const void*)k_ray_walk<2, 1>, (const void*)k_ray_walk<2, 2>, (const void*)k_ray_walk<2, 3>,
       (const void*)k_ray_walk<3, 0>, (const void*)k_ray_walk<3, 1>, (const void*)k_ray_walk<3, 2>, (const void*)k_ray_walk<3, 3>,
       (const void*)k_gather_rays, (const void*)k_surfel_rays};

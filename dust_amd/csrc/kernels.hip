@@ -18,7 +18,7 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
   const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
   const V3 d = camera_ray_dir(a, p.px, p.py);
-  const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
+  const uint32_t ncand = (a.debug & 2u) ? 0u : cull_instances<MODE>(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
   Hit h;
   h.found = false;
   if (!(a.debug & 1u)) trace_ray<0, MODE>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
@@ -128,7 +128,7 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
     const bool act = k == 0 ? sun_live : live;
     const V3 dir = k == 0 ? sd : ad;
     const float tmax = k == 0 ? 10000.0f : 8.0f;
-    const uint32_t ncand = cull_instances(b, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
+    const uint32_t ncand = cull_instances<MODE>(b, __any(act), org, k == 0 ? point_range(sd) : wave_range(live, ad), tmax, cand);
     LaneStats cur = {0, 0, 0, 0, 0, 0};
     trace_ray<1, MODE>(b, act, loc, dir, 0.1f, tmax, k == 0, cand, ncand, h, cur);
     if (COUNT) add_stats(k == 0 ? st_sun : st_ao, cur);
@@ -688,9 +688,9 @@ hipError_t configure_kernels(size_t max_lds) {
   max_lds -= 1024;
 #endif
   const void* fns[] = {
-      (const void*)k_primary<0>, (const void*)k_primary<1>, (const void*)k_primary<2>, (const void*)k_primary<3>,
-      (const void*)k_ambient_occlusion<0>, (const void*)k_ambient_occlusion<1>, (const void*)k_ambient_occlusion<2>, (const void*)k_ambient_occlusion<3>,
-      (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>};
+      (const void*)k_primary<0>, (const void*)k_primary<1>, (const void*)k_primary<2>, (const void*)k_primary<3>, (const void*)k_primary<4>, (const void*)k_primary<5>, (const void*)k_primary<6>, (const void*)k_primary<7>,
+      (const void*)k_ambient_occlusion<0>, (const void*)k_ambient_occlusion<1>, (const void*)k_ambient_occlusion<2>, (const void*)k_ambient_occlusion<3>, (const void*)k_ambient_occlusion<4>, (const void*)k_ambient_occlusion<5>, (const void*)k_ambient_occlusion<6>, (const void*)k_ambient_occlusion<7>,
+      (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>, (const void*)k_primary_ao<4>, (const void*)k_primary_ao<5>, (const void*)k_primary_ao<6>, (const void*)k_primary_ao<7>};
   for (const void* f : fns) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;

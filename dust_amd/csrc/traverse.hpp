@@ -84,6 +84,8 @@ __shared__ unsigned long long g_dbg_mask[16];  // per wave: lanes being traced v
 // and the walk carries the 16-cell's child mask. Scenes without such a model run MODE 0 / 1: exactly the two-level code.
 #define COUNT ((MODE & 1) != 0)
 #define DEEP ((MODE & 2) != 0)
+#define LARGE ((MODE & 4) != 0)  // bit 2: a scene beyond kFlatCullMax instances -- the packet cull's 64-wide hierarchy is compiled into these variants only
+                                 // (in the others it cost the fused kernel 0.8 %: registers and code it never runs)
 enum { P_TOTAL = 0, P_GRAB, P_CULL, P_TRACE_RAY, P_INSTANCE, P_FIND, P_BRICK, P_SCREEN, P_ADVANCE, P_STAGE, P_SHADE,
        P_N_TRACES, P_N_CAND, P_N_CAND_ITER, P_N_VISITS, P_N_STEPS };
 enum { P_N_NEIGHBOUR_CALLS = 10 };  // (reuses the unused P_SHADE bucket)
@@ -905,6 +907,7 @@ __device__ __forceinline__ Range3 point_range(V3 v) {  // every ray shares v (th
 // Per axis:  exists o, d:  lo <= o + d t <= hi   <=>   org.lo + dir.lo t <= hi  and  org.hi + dir.hi t >= lo   (t >= 0).
 // The interval ends are the same in every lane, so each case split below is a select on precomputed per-packet
 // values (reciprocals included): no division and no branch inside the loop.
+template <int MODE>
 __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org, const Range3& dir, float tmax, uint32_t* cand) {
   PROF_ENTER(P_CULL);
   if (!any_active) { PROF_LEAVE(P_CULL); return 0; }
@@ -951,7 +954,7 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
     }
     n += (uint32_t)__popcll(bal);
   };
-  if (a.n_groups == 0u) {  // a few hundred instances at most: every box, 64 at a time
+  if (!LARGE) {  // a few hundred instances at most: every box, 64 at a time
     for (uint32_t base = 0; base < n_inst; base += 64) {
       const uint32_t i = base + lane;
       const uint32_t ic = i < n_inst ? i : n_inst - 1u;  // clamp instead of branching around the loads
@@ -1039,7 +1042,7 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
   PROF_COUNT(P_N_TRACES, 1);
   PROF_COUNT(P_N_CAND, ncand);
   const bool all = ncand > kMaxCand || (a_in.debug & 4u);  // debug bit 4: ignore the list, walk every instance in index order
-  const bool by_groups = ncand > kMaxCand && a_in.n_groups != 0u && !(a_in.debug & 4u);
+  const bool by_groups = LARGE && ncand > kMaxCand && !(a_in.debug & 4u);
   const uint32_t n = all ? a_in.n_instances : ncand;
   // world-space reciprocals feed only the conservative box tests below (1e-5 slack): v_rcp_f32's 1 ulp is enough.
   // (trace_instance keeps IEEE divisions: its reciprocals are the intersection shader's `1.0 / dir`.)
@@ -1878,15 +1881,19 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   if (a.static_rounds_request != 0xFFFFFFFFu) a.static_rounds = a.static_rounds_request;
   return a;
 }
-// kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model)
+// kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model), bit 2 = LARGE (more than kFlatCullMax instances)
 #define DUST_LAUNCH_MODE(kernel, count, a_in)                                                       \
   do {                                                                                              \
     const FrameArgs a = with_schedule(a_in, grid, block);                                           \
-    switch (((count) ? 1 : 0) | ((a).deep ? 2 : 0)) {                                               \
+    switch (((count) ? 1 : 0) | ((a).deep ? 2 : 0) | ((a).n_groups ? 4 : 0)) {                      \
       case 0: hipLaunchKernelGGL(kernel<0>, dim3(grid), dim3(block), lds, s, a); break;             \
       case 1: hipLaunchKernelGGL(kernel<1>, dim3(grid), dim3(block), lds, s, a); break;             \
       case 2: hipLaunchKernelGGL(kernel<2>, dim3(grid), dim3(block), lds, s, a); break;             \
-      default: hipLaunchKernelGGL(kernel<3>, dim3(grid), dim3(block), lds, s, a); break;            \
+      case 3: hipLaunchKernelGGL(kernel<3>, dim3(grid), dim3(block), lds, s, a); break;             \
+      case 4: hipLaunchKernelGGL(kernel<4>, dim3(grid), dim3(block), lds, s, a); break;             \
+      case 5: hipLaunchKernelGGL(kernel<5>, dim3(grid), dim3(block), lds, s, a); break;             \
+      case 6: hipLaunchKernelGGL(kernel<6>, dim3(grid), dim3(block), lds, s, a); break;             \
+      default: hipLaunchKernelGGL(kernel<7>, dim3(grid), dim3(block), lds, s, a); break;            \
     }                                                                                               \
   } while (0)
 static size_t lds_bytes(const FrameArgs& a, uint32_t block) {
