@@ -388,6 +388,7 @@ struct Tuning {
   uint32_t stream_refill = 16;  // DUST_HIP_STREAM_REFILL, DUST_HIP_STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
   uint32_t stream_top_iters = 8;
   bool no_stream_lds = false;   // DUST_HIP_NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
+  bool packet_only = false;     // DUST_HIP_PACKET_GI: the packet kernels even where the streams are the default (the final gather of a scene with a 4096^3 tree)
   bool packet_gi = true;        // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace); DUST_HIP_RAY_STREAM: as ray streams instead --
                                 // binned per ray over the top-level grid, then one ray per lane with lanes refilled (gi.hip): built and measured in round 5, slower on
                                 // every scene but the 4096^3 tree's gather (docs/EXPERIMENTS.md)
@@ -418,6 +419,7 @@ struct Tuning {
     t.stream_refill = std::min(64u, std::max(1u, num("DUST_HIP_STREAM_REFILL", 16)));
     t.stream_top_iters = std::max(1u, num("DUST_HIP_STREAM_TOP_ITERS", 8));
     t.packet_gi = std::getenv("DUST_HIP_RAY_STREAM") == nullptr;
+    t.packet_only = std::getenv("DUST_HIP_PACKET_GI") != nullptr;
     t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
     t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
     t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
@@ -1907,10 +1909,13 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       HIP_TRY(hipMemsetAsync(a.gi.touched + size_t(a.row_begin) * p->width, 0, size_t(a.row_end - a.row_begin) * p->width * 4, st));
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
-    if (!tune.packet_gi) {
-      // The pass as a ray stream (gi.hip): make the band's gather rays (a thread per pixel) -> trace them one per lane, lanes refilled
-      // (k_ray_stream) -> shade the hit records (a thread per pixel). Rays and hit records touch no GI state: the first two kernels may
-      // run beside the previous frame's surfel pass on the second stream; the shading waits for it (join_side).
+    // (a 4096^3 tree: long walks through one instance -- the one workload where a lane of its own per ray pays: 1.66 against 1.82 ms)
+    if (!tune.packet_gi || (a.deep && !tune.packet_only && !(tune.debug & 12u) && !tune.ray_lanes && !tune.no_gather_order && !tune.gather_split)) {
+      // The pass as a ray stream (gi.hip): make and bin the band's gather rays (a thread per pixel) -> walk them one per lane, lanes refilled
+      // (k_ray_walk) -> shade the hit records (a thread per pixel). Behind the previous frame's surfel pass, like the packet kernel: rays and
+      // hit records touch no GI state and COULD run beside that pass, but two persistent launches sharing the slots both get slower
+      // (the 4096^3 tree's GI frame: 5.40 ms beside it, 4.56 behind it).
+      HIP_TRY(join_side(ctx));
       dust::FrameArgs g = a;
       stream_args(p, 0, g, 8.0f, a.cam.far_);  // final_gather.rgen:47-50
       g.gi.fg_hits = g.stream.ray_hits;
@@ -1920,10 +1925,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));
       HIP_TRY(dust::launch_gather_rays(g, st));
       const uint32_t want = uint32_t((size_t(p->width) * (a.row_end - a.row_begin) + 1023u) / 1024u);
-      const uint32_t slots = ctx->side_busy ? frame_slots : resident;  // (a surfel pass beside it keeps its share)
+      const uint32_t slots = resident;
       const uint32_t ggrid = std::max(8u, std::min<uint32_t>((slots * block / 1024u) & ~7u, (want + 7u) & ~7u));
       HIP_TRY(dust::launch_ray_walk(g, 2, ggrid, 1024, count, st));
-      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool the shading reads
       dust::FrameArgs sh = a;   // (pixel order over the band)
       sh.gi.fg_hits = g.gi.fg_hits;
       HIP_TRY(dust::launch_final_gather_shade(sh, !sharded, st));
