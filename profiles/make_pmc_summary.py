@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel<MODE>: MODE 0 = the timed two-level build, 2 = the DEEP build (4096^3 scenes); 1 / 3 are the counting builds
 KEYS = {"k_primary_ao<0>": "primary_ao", "k_final_gather<0>": "final_gather", "k_surfel_trace<0>": "surfel_trace",
         "k_primary<0>": "primary", "k_ambient_occlusion<0>": "ambient_occlusion"}
-DEEP_KEYS = {"k_primary_ao<2>": "primary_ao", "k_final_gather<2>": "final_gather", "k_surfel_trace<2>": "surfel_trace"}
+DEEP_KEYS = {"k_primary_ao<2>": "primary_ao", "k_final_gather<2>": "final_gather", "k_ray_walk<2, 2>": "final_gather_walk", "k_surfel_trace<2>": "surfel_trace"}
 
 
 def parse(path, keys=None):

@@ -26,17 +26,25 @@ python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-bas
 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_RAY_LANES=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ray_lanes.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
+# round 5: thousands of instances (the packet cull's 64-wide hierarchy against every box for every packet), the GI passes as ray streams
+# (opt-in on the castle, the default for the deep tree's gather), N-rank denoise on one GPU
+python bench.py --props 4000 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_props.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_FLAT_CULL=1 python bench.py --props 4000 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_props_flat_cull.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_RAY_STREAM=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_stream_inplace.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_RAY_STREAM=1 python bench.py --workload deep --steps 30 --no-cpu-baseline > "$out/${tag}_bench_deep_stream.log" 2>> "$out/${tag}_bench.err"
+DUST_HIP_PACKET_GI=1 python bench.py --workload deep --steps 30 --no-cpu-baseline > "$out/${tag}_bench_deep_packet.log" 2>> "$out/${tag}_bench.err"
+python bench.py --denoise --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_denoise.log" 2>> "$out/${tag}_bench.err"
 # what ONE rank of an N-GPU row-band run does between collectives (four frames in flight, launches on a quarter of the slots each): every band of N = 2, 4, 8
 : > "$out/${tag}_bench_bands_emulated.log"
 for n in 2 4 8; do for r in $(seq 0 $((n - 1))); do
-  DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
+  DUST_HIP_RESERVE_BLOCKS=32 DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
     python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/$n', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight'], 'rays_per_step': j['config']['rays_per_step_all_gpus']}))" >> "$out/${tag}_bench_bands_emulated.log"
 done; done
 
 # a 1/8 band launched ALONE, one frame in flight: what single-frame strong scaling on 8 GPUs would get from the kernel
 : > "$out/${tag}_bench_band_alone.log"
 for r in 0 1 2 3 4 5 6 7; do
-  DUST_BENCH_EMULATE_BAND=$r/8 python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 1 2>> "$out/${tag}_bench.err" |
+  DUST_HIP_RESERVE_BLOCKS=32 DUST_BENCH_EMULATE_BAND=$r/8 python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 1 2>> "$out/${tag}_bench.err" |
     python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/8', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight']}))" >> "$out/${tag}_bench_band_alone.log"
 done
 
@@ -48,6 +56,10 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi -- \
     python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_deep -- \
     python "$R/bench.py" --workload deep --steps 10 --warmup 2 --no-cpu-baseline > "$out/${tag}_bench_deep_prof.log" 2>&1
+DUST_HIP_RAY_STREAM=1 DUST_HIP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi_stream -- \
+    python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_stream_prof.log" 2>&1
+python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_gi_stream_results.db') \
+    --json "$out/${tag}_kernel_stats_gi_stream.json" > "$out/${tag}_kernel_stats_gi_stream.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_deep_results.db') \
     --json "$out/${tag}_kernel_stats_deep.json" > "$out/${tag}_kernel_stats_deep.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_results.db') \
@@ -75,6 +87,22 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o denoise -- \
 { grep "GI frame" "$out/${tag}_denoise_timing.log"; python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'denoise_results.db') | grep -i "denoise\|kernel  "; } > "$out/${tag}_denoise_kernels.txt" 2>&1
 python "$R/tools/kernel_sections.py" > "$out/${tag}_sections.txt" 2>&1
 python "$R/tools/kernel_sections.py" --deep > "$out/${tag}_sections_deep.txt" 2>&1
+DUST_HIP_RAY_STREAM=1 python "$R/tools/kernel_sections.py" > "$out/${tag}_sections_stream.txt" 2>&1
+python "$R/tools/kernel_sections.py" --props 4000 > "$out/${tag}_sections_props.txt" 2>&1
+# SQ counters (instructions, lane activity, waits) of the stream and the packet GI kernels side by side
+for v in stream packet; do
+  if [ $v = stream ]; then export DUST_HIP_RAY_STREAM=1; else unset DUST_HIP_RAY_STREAM; fi
+  i=0
+  for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"; do
+    i=$((i + 1))
+    DUST_HIP_NO_SIDE_STREAM=1 rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$tag" -o sq_${v}_$i -- \
+        python "$R/bench.py" --workload gi --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_sq_${v}_$i.log" 2>&1
+  done
+  python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name "sq_${v}_*_results.db" | sort) | grep -E "k_ray_walk<., 0>|k_gather_rays|k_surfel_rays|k_final_gather<0>|k_surfel_trace<0>|k_primary_ao<0>" > "$out/${tag}_sq_$v.txt" 2>&1
+done
+unset DUST_HIP_RAY_STREAM
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times.txt" 2>&1
 DUST_HIP_EQUAL_BANDS=1 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times_equal_bands.txt" 2>&1
