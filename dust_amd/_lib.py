@@ -65,6 +65,11 @@ class Camera(C.Structure):
                 ("position", C.c_float * 3), ("tan_half_fov", C.c_float), ("far_", C.c_float), ("near_", C.c_float)]
 
 
+class TopLevelInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("dim", C.c_uint32 * 3), ("lo", C.c_float * 3), ("cell", C.c_float * 3),
+                ("n_cells", C.c_uint32), ("n_items", C.c_uint32), ("n_groups", C.c_uint32)]
+
+
 class Sky(C.Structure):
     _fields_ = [("state", C.c_float * 56)]
 
@@ -151,6 +156,7 @@ SYMBOLS = {
     "dust_hip_scene_add_instance": (C.c_int, [_P, _P, _f32p, _f32p, _u32p]),
     "dust_hip_scene_set_transform": (C.c_int, [_P, C.c_uint32, _f32p, _f32p]),
     "dust_hip_scene_commit": (C.c_int, [_P]),
+    "dust_hip_top_level_build": (C.c_int, [C.POINTER(C.c_float), C.c_uint32, _P, _u32p, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t, _u32p, _u32p]),
     "dust_hip_pipeline_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "dust_hip_pipeline_destroy": (None, [_P]),
     "dust_hip_pipeline_set_noise": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),

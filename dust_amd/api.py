@@ -358,6 +358,25 @@ class Scene:
         L.check(self._lib.dust_hip_scene_commit(self._h))
 
 
+def top_level_build(boxes):
+    """Host only: the grid and the slot order dust_hip_scene_commit builds over instance world boxes (n x 6: lo, hi) ->
+    dict(dim, lo, cell, cells, items, ranges, slot_order, n_groups). For tests and tools."""
+    lib = L.load()
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    n = len(b)
+    info = L.TopLevelInfo()
+    info.struct_size = C.sizeof(L.TopLevelInfo)
+    fp = b.ctypes.data_as(C.POINTER(C.c_float))
+    L.check(lib.dust_hip_top_level_build(fp, n, C.byref(info), None, 0, None, 0, None, None))
+    cells, items = np.zeros(info.n_cells, np.uint32), np.zeros(max(1, info.n_items), np.uint16)
+    ranges, order = np.zeros((n, 2), np.uint32), np.zeros(n, np.uint32)
+    L.check(lib.dust_hip_top_level_build(fp, n, C.byref(info), cells.ctypes.data_as(C.POINTER(C.c_uint32)), len(cells),
+                                     items.ctypes.data_as(C.POINTER(C.c_uint16)), len(items), ranges.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     order.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return {"dim": tuple(info.dim), "lo": np.array(info.lo[:], np.float32), "cell": np.array(info.cell[:], np.float32), "cells": cells,
+            "items": items[:info.n_items], "ranges": ranges, "slot_order": order, "n_groups": info.n_groups}
+
+
 def sky_struct(sky):
     """56 baked sky floats -> DustHipSky"""
     s = L.Sky()

@@ -1324,6 +1324,25 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
         for (uint32_t x = rl & 255u; x <= (rh & 255u); ++x) s->grid_items[at[(size_t(z) * g.dim[1] + y) * g.dim[0] + x]++] = uint16_t(i);
   }
 }
+// the instances in the order of a Morton curve through their boxes' centres (10 bits per axis over the scene's bounds): the packet
+// cull's groups are runs of 64 consecutive slots
+void order_slots(DustHipScene* s) {
+  const size_t n = s->world_boxes.size() / 6;
+  std::vector<std::pair<uint32_t, uint32_t>> keyed(n);
+  auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t c[3];
+    for (int a = 0; a < 3; ++a) {
+      const double span = std::max(1e-6, double(s->world_max[a]) - double(s->world_min[a]));
+      const double mid = 0.5 * (double(s->world_boxes[i * 6 + a]) + double(s->world_boxes[i * 6 + 3 + a]));
+      c[a] = uint32_t(std::min(1023.0, std::max(0.0, (mid - double(s->world_min[a])) / span * 1024.0)));
+    }
+    keyed[i] = {spread(c[0]) | (spread(c[1]) << 1) | (spread(c[2]) << 2), uint32_t(i)};
+  }
+  std::sort(keyed.begin(), keyed.end());
+  s->slot_order.resize(n);
+  for (size_t k = 0; k < n; ++k) s->slot_order[k] = keyed[k].second;
+}
 }  // namespace
 
 DustStatus dust_hip_scene_commit(DustHipScene* s) {
@@ -1423,20 +1442,7 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       s->n_groups = n > dust::kFlatCullMax && !std::getenv("DUST_HIP_FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
       if (s->n_groups) {
         if (full || s->slot_order.size() != n) {
-          std::vector<std::pair<uint32_t, uint32_t>> keyed(n);
-          auto spread = [](uint32_t v) { v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
-          for (size_t i = 0; i < n; ++i) {
-            uint32_t c[3];
-            for (int a = 0; a < 3; ++a) {
-              const double span = std::max(1e-6, double(s->world_max[a]) - double(s->world_min[a]));
-              const double mid = 0.5 * (double(s->world_boxes[i * 6 + a]) + double(s->world_boxes[i * 6 + 3 + a]));
-              c[a] = uint32_t(std::min(1023.0, std::max(0.0, (mid - double(s->world_min[a])) / span * 1024.0)));
-            }
-            keyed[i] = {spread(c[0]) | (spread(c[1]) << 1) | (spread(c[2]) << 2), uint32_t(i)};
-          }
-          std::sort(keyed.begin(), keyed.end());
-          s->slot_order.resize(n);
-          for (size_t k = 0; k < n; ++k) s->slot_order[k] = keyed[k].second;
+          order_slots(s);
         }
         dust::DevBox* sb = reinterpret_cast<dust::DevBox*>(img + s->layout.sboxes);
         dust::DevBox* gb = reinterpret_cast<dust::DevBox*>(img + s->layout.gboxes);
@@ -1471,6 +1477,34 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     ++s->revision;
     s->structure_dirty = false;
     s->committed = true;
+    return DUST_OK;
+  });
+}
+
+DustStatus dust_hip_top_level_build(const float* boxes, uint32_t n, DustTopLevelInfo* info, uint32_t* cells, size_t cells_capacity, uint16_t* items,
+                                size_t items_capacity, uint32_t* ranges, uint32_t* slot_order) {
+  if (!boxes || !info || n == 0 || n > 65535) return fail(DUST_ERR_INVALID_ARGUMENT, "bad top-level build arguments");
+  STRUCT_TRY(info, "DustTopLevelInfo");
+  return guarded([&]() -> DustStatus {
+    DustHipScene s;   // (a bare scene record: no context, no device: only what build_grid / order_slots read and write)
+    s.world_boxes.assign(boxes, boxes + size_t(n) * 6);
+    for (int a = 0; a < 3; ++a) { s.world_min[a] = 1e30f; s.world_max[a] = -1e30f; }
+    for (uint32_t i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) {
+        if (!(boxes[i * 6 + a] <= boxes[i * 6 + 3 + a])) return fail(DUST_ERR_INVALID_ARGUMENT, "a box with lo > hi (or NaN)");
+        s.world_min[a] = std::min(s.world_min[a], boxes[i * 6 + a]); s.world_max[a] = std::max(s.world_max[a], boxes[i * 6 + 3 + a]);
+      }
+    std::vector<uint32_t> rg;
+    build_grid(&s, s.world_boxes, rg);
+    order_slots(&s);
+    for (int a = 0; a < 3; ++a) { info->dim[a] = s.grid.dim[a]; info->lo[a] = s.grid.lo[a]; info->cell[a] = s.grid.cell[a]; }
+    info->n_cells = uint32_t(s.grid_cells.size());
+    info->n_items = uint32_t(s.grid_items.size());
+    info->n_groups = n > dust::kFlatCullMax ? (n + 63) / 64 : 0;
+    if (cells) { if (cells_capacity < s.grid_cells.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "cells buffer too small"); std::memcpy(cells, s.grid_cells.data(), s.grid_cells.size() * 4); }
+    if (items) { if (items_capacity < s.grid_items.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "items buffer too small"); std::memcpy(items, s.grid_items.data(), s.grid_items.size() * 2); }
+    if (ranges) std::memcpy(ranges, rg.data(), size_t(n) * 8);
+    if (slot_order) std::memcpy(slot_order, s.slot_order.data(), size_t(n) * 4);
     return DUST_OK;
   });
 }

@@ -225,6 +225,20 @@ DustStatus dust_hip_scene_set_transform(DustHipScene*, uint32_t instance_id, con
  * that changed are re-derived on the host and one stream-ordered copy from pinned memory carries them to the device behind
  * the frame in flight -- no allocation and no wait unless instances were added since the last commit. */
 DustStatus dust_hip_scene_commit(DustHipScene*);
+/* Host only (no device, no context): the two top-level structures dust_hip_scene_commit builds over the instances' world boxes --
+ * what the reference hands to the driver as a TLAS (accel_struct/tlas.rs:37-117). boxes: n x {lo[3], hi[3]}.
+ *   grid:  info->dim cells of info->cell from info->lo; cells[c] = first item | items << 20 for cell c = (z * dim[1] + y) * dim[0] + x;
+ *          items: instance ids; ranges[2 i], ranges[2 i + 1]: the block of cells instance i is listed in, x | y << 9 | z << 18;
+ *   slot_order: the instances along a Morton curve (the packet cull groups 64 consecutive ones when n > 256: info->n_groups).
+ * Any output pointer may be NULL (info alone gives the sizes). For tests and tools. */
+typedef struct DustTopLevelInfo {
+  uint32_t struct_size;
+  uint32_t dim[3];
+  float lo[3], cell[3];
+  uint32_t n_cells, n_items, n_groups;
+} DustTopLevelInfo;
+DustStatus dust_hip_top_level_build(const float* boxes, uint32_t n, DustTopLevelInfo* info, uint32_t* cells, size_t cells_capacity, uint16_t* items,
+                                size_t items_capacity, uint32_t* ranges, uint32_t* slot_order);
 
 /* the members of CameraSettings the shaders read (standard.rs:277-302,813-827; layout.playout:20-33) */
 typedef struct DustHipCamera {
