@@ -11,6 +11,9 @@ mkdir -p gpurun_out
   run() { local t0=$SECONDS; "$@" > gpurun_out/_stab.tmp 2>&1; local rc=$?; echo "rc $rc ${SECONDS}s+$((SECONDS - t0)): $* :: $(tail -1 gpurun_out/_stab.tmp | cut -c1-160)"; }
   run timeout 900 python3 tools/stress_parity.py 4000 41000
   STRESS_SWITCHES=1 run timeout 900 python3 tools/stress_parity.py 4000 45000
+  DUST_HIP_RAY_STREAM=1 run timeout 900 python3 tools/stress_parity.py 3000 61000
+  DUST_HIP_RAY_STREAM=1 STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 100 64000
+  DUST_HIP_RAY_STREAM=1 STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 800 65000
   STRESS_BIG=1 run timeout 900 python3 tools/stress_parity.py 600 49000
   STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 150 49600
   STRESS_FULL=1 run timeout 900 python3 tools/stress_parity.py 200 49800
