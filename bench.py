@@ -597,10 +597,15 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
         pipe.render(scene, cams[k], sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=1 + k, rand=synth.frame_rand(1, 1 + k))
     # untimed: the rays of exactly the frames that are timed below (they differ from frame to frame)
     rays = 0
+    algo = 0   # algorithmic bytes of the same frames: every frame of a moving view has its own counts
     for k in range(settle, n):
         frame(k, count=True)
         be.sync()
-        rays += sum(pipe.pass_stats(i).rays for i in range(3))
+        st = [pipe.pass_stats(i) for i in range(3)]
+        rays += sum(x.rays for x in st)
+        hit_px, miss_px = st[0].hits, st[0].rays - st[0].hits
+        algo += (algorithmic_bytes(st[0], hit_px * 32 + miss_px * 24) + algorithmic_bytes(st[1], 0) + algorithmic_bytes(st[2], 0)
+                 - (st[1].hits + st[2].hits) * 5 + hit_px * 24)
     pipe.clear()
     gc.collect()
     gc.disable()
@@ -628,9 +633,16 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
         be.sync()
         still_ms.append((time.perf_counter() - t1) / 40 * 1e3)
     speed = swing * 2.0 * math.pi / period
+    k_ms = lm[0] / ln[0] if ln[0] else None
+    achieved = (algo / steps) / (k_ms * 1e-3) / 1e9 if k_ms else None
     return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "rays_per_step": int(rays / steps), "settle_steps": settle,
-            "kernels_ms": {"k_primary_ao": round(lm[0] / ln[0], 4) if ln[0] else None},
+            "kernels_ms": {"k_primary_ao": round(k_ms, 4) if k_ms else None},
+            "roofline": {"bound": "hbm", "kernel": "k_primary_ao", "algorithmic_bytes_per_launch": int(algo / steps), "kernel_ms": round(k_ms, 4) if k_ms else None,
+                         "achieved": round(achieved, 3) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6) if achieved else None,
+                         "note": "mean algorithmic bytes of the timed frames (each counted in an untimed pass of its own) over the mean kernel time of the "
+                                 "launches that were bracketed by HIP events (every 4th frame)"},
             "still_same_views": {"ms_per_step": [round(v, 4) for v in still_ms], "mean_ms_per_step": round(sum(still_ms) / len(still_ms), 4),
                                  "moving_over_still": round((dt / steps * 1e3) / (sum(still_ms) / len(still_ms)), 4)},
             "camera": f"sway: eye on the circle of radius {radius:.1f} at height {eye0[1]:.1f} round the origin, {swing} rad either side of the reference's "

@@ -123,10 +123,12 @@ static int gpu_frame(int argc, char** argv) {
     auto pipe_of = [&](uint32_t r) -> dust::StandardPipeline& { return r == 0 ? pipeline : *ranks[r - 1]; };
     for (uint32_t r = 0; r < world; ++r)
       if (cuts[r] < cuts[r + 1]) EXPECT(pipe_of(r).render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242, cuts[r], cuts[r + 1]));
-    for (DustHipPlane plane : {DUST_PLANE_DEPTH, DUST_PLANE_ILLUMINANCE, DUST_PLANE_VOXEL_ID}) {
-      for (uint32_t r = 0; r < world; ++r) comms[r]->gather_bands(pipe_of(r), plane, cuts, 0);
-      comms[0]->wait();
-    }
+    // depth on its own (dust_hip_gather_bands), the other two planes in ONE collective (dust_hip_gather_planes: what a root that
+    // goes on to denoise the frame asks for)
+    for (uint32_t r = 0; r < world; ++r) comms[r]->gather_bands(pipe_of(r), DUST_PLANE_DEPTH, cuts, 0);
+    comms[0]->wait();
+    for (uint32_t r = 0; r < world; ++r) comms[r]->gather_planes(pipe_of(r), (1u << DUST_PLANE_ILLUMINANCE) | (1u << DUST_PLANE_VOXEL_ID), cuts, 0);
+    comms[0]->wait();
     comms[0]->sync();
   } else {
     const bool ok = pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242);
