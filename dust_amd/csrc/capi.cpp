@@ -327,6 +327,7 @@ struct DustHipScene : RefCounted {
   // the top-level grid over the instance boxes (dust_dev.h DevGrid; rebuilt by every commit): its header, and the two arrays
   // that are copied into the image
   dust::DevGrid grid{};
+  bool grid_valid = true;            // false: some cell would list more instances than a cell word counts (the ray streams then stay off)
   std::vector<uint32_t> grid_cells;
   std::vector<uint16_t> grid_items;
   std::vector<uint32_t> slot_order;  // large scenes: the instances along a space-filling curve (made by a structural commit; a moved instance keeps its slot)
@@ -1277,7 +1278,7 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
   const double density0 = density_env ? std::max(0.001, std::atof(density_env)) : 12.0;
   ranges.resize(n * 2);
   std::vector<uint32_t> count;
-  for (double density = density0;; density *= 0.5) {  // (coarser until a cell's list and the item array fit the packed cell word: never, for scenes of any sane shape)
+  for (double density = density0;; density *= 0.5) {
     const double target = std::min(262144.0, std::max(1.0, density * double(std::max<size_t>(n, 1))));
     const double edge = std::cbrt(ext[0] * ext[1] * ext[2] / target);
     for (int a = 0; a < 3; ++a) {
@@ -1304,7 +1305,10 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
           for (uint32_t x = lo[0]; x <= hi[0]; ++x) most = std::max(most, ++count[(size_t(z) * g.dim[1] + y) * g.dim[0] + x]);
       total += size_t(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
     }
-    if ((total < (size_t(1) << dust::kGridItemBits) && most <= dust::kGridMaxCellItems) || n_cells == 1) break;
+    // (coarser until the item array fits the packed cell word's 20 index bits: never, for scenes of any sane shape. More than 4095 boxes over
+    //  ONE cell cannot be listed at any resolution that helps: the grid is then marked unusable and the single-ray paths are not taken)
+    s->grid_valid = most <= dust::kGridMaxCellItems;
+    if (total < (size_t(1) << dust::kGridItemBits) || n_cells == 1) break;
   }
   const size_t n_cells = count.size();
   s->grid_cells.assign(n_cells, 0u);
@@ -1496,6 +1500,7 @@ DustStatus dust_hip_top_level_build(const float* boxes, uint32_t n, DustTopLevel
       }
     std::vector<uint32_t> rg;
     build_grid(&s, s.world_boxes, rg);
+    if (!s.grid_valid) return fail(DUST_ERR_UNSUPPORTED, "more than 4095 boxes over one grid cell: no grid lists them (a scene renders by the packet kernels then)");
     order_slots(&s);
     for (int a = 0; a < 3; ++a) { info->dim[a] = s.grid.dim[a]; info->lo[a] = s.grid.lo[a]; info->cell[a] = s.grid.cell[a]; }
     info->n_cells = uint32_t(s.grid_cells.size());
@@ -1683,7 +1688,7 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
       b.gi.perm = sv[in_b ? 1 : 0];
     }
-    if (tune.packet_gi) {
+    if (tune.packet_gi || !b.grid.cells) {
       take_counters(p, 3, b);
       { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
       const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
@@ -1764,8 +1769,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.boxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.boxes));
   a.visits = reinterpret_cast<const dust::DevVisit*>(s->dev(s->layout.visits));
   a.grid = s->grid;
-  a.grid.cells = reinterpret_cast<const uint32_t*>(s->dev(s->layout.grid_cells));
-  a.grid.items = reinterpret_cast<const uint16_t*>(s->dev(s->layout.grid_items));
+  // (a grid that could not list every box -- build_grid -- is not handed to the kernels at all: the packet kernels, which never read it, run instead)
+  a.grid.cells = s->grid_valid ? reinterpret_cast<const uint32_t*>(s->dev(s->layout.grid_cells)) : nullptr;
+  a.grid.items = s->grid_valid ? reinterpret_cast<const uint16_t*>(s->dev(s->layout.grid_items)) : nullptr;
   a.enters = reinterpret_cast<const dust::DevEnter*>(s->dev(s->layout.enters));
   a.gboxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.gboxes));
   a.sboxes = reinterpret_cast<const dust::DevBox*>(s->dev(s->layout.sboxes));
@@ -1944,7 +1950,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     // (a 4096^3 tree: long walks through one instance -- the one workload where a lane of its own per ray pays: 1.66 against 1.82 ms)
-    if (!tune.packet_gi || (a.deep && !tune.packet_only && !(tune.debug & 12u) && !tune.ray_lanes && !tune.no_gather_order && !tune.gather_split)) {
+    if (a.grid.cells && (!tune.packet_gi || (a.deep && !tune.packet_only && !(tune.debug & 12u) && !tune.ray_lanes && !tune.no_gather_order && !tune.gather_split))) {
       // The pass as a ray stream (gi.hip): make and bin the band's gather rays (a thread per pixel) -> walk them one per lane, lanes refilled
       // (k_ray_walk) -> shade the hit records (a thread per pixel). Behind the previous frame's surfel pass, like the packet kernel: rays and
       // hit records touch no GI state and COULD run beside that pass, but two persistent launches sharing the slots both get slower

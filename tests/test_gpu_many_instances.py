@@ -114,3 +114,29 @@ def test_moved_instances_keep_their_slots():
         cmp = P.compare_gbuffers(g, P.read_hip_gbuffer(pipe))
         for k in ("depth", "voxel_id", "normal", "albedo"):
             assert cmp[k] == 0, (step, cmp)
+
+
+def test_more_boxes_over_one_cell_than_a_cell_lists(monkeypatch):
+    """4200 instances stacked on (nearly) one spot: no grid resolution keeps a cell's list inside the 12 count bits of its cell word, so the
+    commit marks the grid unusable and a scene asked to render by ray streams renders by the packet kernels -- same results, nothing dropped."""
+    monkeypatch.setenv("DUST_HIP_RAY_STREAM", "1")
+    desc = scattered_scene(4200, seed=23, n_models=3, span=(6.0, 3.0, 6.0))
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    oscene = P.oracle_scene(desc)
+    sky, cam = P.sky_state(), P.camera_for((40.0, 25.0, 60.0))
+    w, h = 48, 32
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    pipe = api.StandardPipeline(ctx, w, h)
+    pipe.set_noise(0, n0)
+    pipe.set_noise(5, n5)
+    pipe.configure_gi(1 << 12, 512)
+    gi = O.GI(1 << 12, 512)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    for f in range(1, 3):
+        rnd = synth.frame_rand(4, f)
+        pipe.render(scene, cam, sky, passes, frame_index=f, rand=rnd)
+        g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f, gi_threads=8)
+        P.assert_parity(P.compare_gbuffers(g, P.read_hip_gbuffer(pipe)))
+        compare_gi(gi, pipe)
+    assert np.isfinite(P.read_hip_gbuffer(pipe)["depth"]).sum() > 50

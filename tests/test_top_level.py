@@ -124,3 +124,7 @@ def test_bad_arguments_are_refused():
     from dust_amd import _lib as L
     with pytest.raises(L.DustError):
         api.top_level_build(np.array([[1, 0, 0, 0, 1, 1]], np.float32))     # lo > hi
+    # more boxes over one cell than a cell word counts (12 bits): refused rather than listed short
+    stack = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (4200, 1))
+    with pytest.raises(L.DustError):
+        api.top_level_build(stack)
