@@ -140,3 +140,43 @@ def test_more_boxes_over_one_cell_than_a_cell_lists(monkeypatch):
         P.assert_parity(P.compare_gbuffers(g, P.read_hip_gbuffer(pipe)))
         compare_gi(gi, pipe)
     assert np.isfinite(P.read_hip_gbuffer(pipe)["depth"]).sum() > 50
+
+
+@pytest.mark.parametrize("n,stream", [(20000, False), (20000, True), (65535, False)])
+def test_as_many_instances_as_the_api_admits(monkeypatch, n, stream):
+    """The instance id is 16 bits wide (dust_hip_scene_add_instance refuses the 65 536th): 20 000 and 65 535 instances -- 313 and 1 024
+    groups, several 64-wide rounds of group boxes per cull, an overflowing list where the props bunch up -- against the oracle."""
+    if stream:
+        monkeypatch.setenv("DUST_HIP_RAY_STREAM", "1")
+    else:
+        monkeypatch.delenv("DUST_HIP_RAY_STREAM", raising=False)
+    desc = scattered_scene(n, seed=31, n_models=4, span=(1500.0, 60.0, 1500.0))
+    for k in range(0, 400):      # a heap in the middle: more than kMaxCand boxes over one packet
+        mid, t = desc.instances[k]
+        t = t.copy().reshape(3, 4)
+        t[:, 3] *= np.float32(0.02)
+        desc.instances[k] = (mid, t.reshape(12))
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    oscene = P.oracle_scene(desc)
+    sky = P.sky_state()
+    w, h = (96, 54) if n < 30000 else (64, 36)   # (the oracle tests every box for every ray)
+    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
+    pipe = api.StandardPipeline(ctx, w, h)
+    pipe.set_noise(0, n0)
+    pipe.set_noise(5, n5)
+    pipe.configure_gi(1 << 13, 1024)
+    gi = O.GI(1 << 13, 1024)
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
+    for f, eye in ((1, (60.0, 45.0, 90.0)), (2, (700.0, 200.0, 500.0))):
+        cam = P.camera_for(eye)
+        rnd = synth.frame_rand(6, f)
+        pipe.render(scene, cam, sky, passes, frame_index=f, rand=rnd)
+        g = P.render_oracle(oscene, cam, sky, w, h, passes, n5[f % 4], rnd, noise0=n0[f % 4], gi=gi, frame_index=f, gi_threads=8)
+        hip = P.read_hip_gbuffer(pipe)
+        P.assert_parity(P.compare_gbuffers(g, hip))
+        compare_gi(gi, pipe)
+        assert np.isfinite(hip["depth"]).sum() > 200
+    if n == 65535:
+        with pytest.raises(L.DustError):
+            scene.add_instance(scene._models[0], desc.instances[0][1])
