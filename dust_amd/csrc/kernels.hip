@@ -141,6 +141,62 @@ __device__ __forceinline__ void ao_packet(ArgsRef a, const Packet& p, uint32_t* 
   if (live) store_radiance(reload_args(a).g.illuminance, pix, payload, h.found ? h.t : 0.0f);
 }
 
+#ifdef DUST_WALK_PROBE
+// (never shipped: the walk-only kernel the round-4 review asked to have MEASURED -- make VARIANT=wp5 EXTRA="-DDUST_WALK_PROBE -DDUST_WP_T=640
+// -DDUST_WP_W=5 -DDUST_MAX_BLOCK=1024u", tools/diag/walk_probe.py. k_primary without its shading: cull + trace of the camera rays, a 16-byte hit
+// record per pixel into the accumulation plane (which a primary-only frame does not touch), at the launch bounds given; DUST_WALK_PROBE=2
+// adds k_shade_probe, a thread per pixel at full occupancy that turns the records into the G-buffer planes with primary_shade.)
+#ifndef DUST_WP_T
+#define DUST_WP_T 512
+#define DUST_WP_W 4
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(DUST_WP_T, DUST_WP_W) k_primary(const FrameArgs) {
+  ArgsRef a0 = launch_args();
+  stage_roots(a0);
+  uint32_t* cand = wave_cand_list(a0);
+  LaneStats st = {0, 0, 0, 0, 0, 0};
+  WorkCursor wc = cursor_begin();
+  Packet p;
+  while (next_packet(a0, wc, p)) {
+    ArgsRef a = reload_args(a0);
+    const V3 o = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
+    const V3 d = camera_ray_dir(a, p.px, p.py);
+    const uint32_t ncand = cull_instances<MODE>(a, __any(p.valid), point_range(o), wave_range(p.valid, d), a.cam.far_, cand);
+    Hit h;
+    h.found = false;
+    trace_ray<0, MODE>(a, p.valid, o, d, a.cam.near_, a.cam.far_, false, cand, ncand, h, st);
+    if (p.valid) {
+      ArgsRef b = reload_args(a0);
+      u32x4 r;
+      r.x = h.found ? __float_as_uint(h.t) : 0x7F800000u; r.y = h.inst | (h.voxel << 16); r.z = h.block; r.w = h.found ? 1u : 0u;
+      DUST_NT_STORE(r, (DUST_GLOBAL_AS u32x4*)b.g.accum + ((size_t)p.py * b.width + p.px));
+    }
+  }
+  prof_end();
+  flush_stats<MODE>(a0, 0, st);
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_shade_probe(const FrameArgs) {
+  ArgsRef a = launch_args();
+  // 8x8 pixel blocks per wave, like the packets (the hit-lane waterfall of primary_shade wants few distinct instances per wave)
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (wave >= a.tiles_x * a.tiles_y) return;
+  const uint32_t ty = wave / a.tiles_x, tx = wave - ty * a.tiles_x;
+  Packet p;
+  p.px = tx * kTileW + (lane % kTileW); p.py = a.row_begin + ty * kTileH + (lane / kTileW);
+  p.valid = p.px < a.width && p.py < a.row_end;
+  Hit h;
+  h.found = false; h.t = 0.0f; h.inst = 0; h.block = 0; h.voxel = 0;
+  if (p.valid) {
+    const u32x4 r = *((const DUST_GLOBAL_AS u32x4*)a.g.accum + ((size_t)p.py * a.width + p.px));
+    h.t = __uint_as_float(r.x); h.inst = r.y & 0xFFFFu; h.voxel = r.y >> 16; h.block = r.z; h.found = r.w != 0u;
+  }
+  float hitT;
+  uint32_t npk;
+  primary_shade<MODE>(a, p, mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]), camera_ray_dir(a, p.px, p.py), h, true, hitT, npk);
+}
+#else
 template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
   ArgsRef a0 = launch_args();
@@ -158,6 +214,7 @@ __global__ void __launch_bounds__(512, 4) k_primary(const FrameArgs) {
   prof_end();
   flush_stats<MODE>(a0, 0, st);
 }
+#endif
 
 template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_ambient_occlusion(const FrameArgs) {
@@ -662,6 +719,13 @@ hipError_t launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t* cu
 hipError_t launch_primary(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a_in, block);
   DUST_LAUNCH_MODE(k_primary, count, a_in);
+#if defined(DUST_WALK_PROBE) && DUST_WALK_PROBE >= 2
+  {
+    const uint32_t waves = a_in.tiles_x * a_in.tiles_y;
+    if (a_in.deep) hipLaunchKernelGGL(k_shade_probe<2>, dim3((waves + 3u) / 4u), dim3(256), 0, s, a_in);
+    else hipLaunchKernelGGL(k_shade_probe<0>, dim3((waves + 3u) / 4u), dim3(256), 0, s, a_in);
+  }
+#endif
   return hipGetLastError();
 }
 hipError_t launch_primary_ao(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
