@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -195,6 +196,10 @@ struct DustHipContext : RefCounted {
   bool side_busy = false;
   std::vector<hipStream_t> extra_streams;  // communicators' gather streams (comm.hip): they read pipelines' planes, so every wait for the context covers them
   hipStream_t copy = nullptr;  // scene commits upload on a stream of their own (the copy engine), beside the frame in flight -- never between two frames
+  // Which frames of the stream have STARTED (FrameArgs::started_word): a word of pinned host memory that the first traversal launch of
+  // every frame writes its sequence number into. `frame_seq` counts those launches as they are enqueued. 0 / null: not available.
+  volatile uint32_t* started = nullptr;
+  uint32_t frame_seq = 0;
 };
 // wait for everything enqueued on the context's stream (and remember that we did: scene commits recycle their pinned staging
 // slots by this, without an event per commit)
@@ -233,6 +238,7 @@ static void release(DustHipContext* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   c->srgb_lut.release();
+  if (c->started) (void)hipHostFree(const_cast<uint32_t*>(c->started));
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -317,6 +323,7 @@ struct DustHipScene : RefCounted {
     DeviceBuffer dev;
     void* host = nullptr;
     mutable uint64_t epoch = 0;  // the context's sync_epoch when a frame reading the slot was last enqueued
+    mutable uint32_t last_seq = 0;  // ... and that frame's start sequence number (DustHipContext::frame_seq), 0 = it has none (no traversal launch, or no word)
   } slots[kImages];
   int current = -1;           // the slot frames read
   uint32_t next_slot = 0;
@@ -337,12 +344,12 @@ struct DustHipScene : RefCounted {
   uint64_t revision = 0;  // bumped by every commit (what the cost-ordered hand-out keys its view on)
   bool committed = false;
   const uint8_t* dev(size_t off) const { return static_cast<const uint8_t*>(slots[current].dev.p) + off; }
-  void touch() const { slots[current].epoch = ctx->sync_epoch; }  // a frame reading the current slot is being enqueued
+  void touch() const { slots[current].epoch = ctx->sync_epoch; slots[current].last_seq = 0; }  // a frame reading the current slot is being enqueued
   void free_images() {  // (the caller has waited for the streams)
     for (Slot& sl : slots) {
       if (sl.host) { (void)hipHostFree(sl.host); sl.host = nullptr; }
       sl.dev.release();
-      sl.epoch = 0;
+      sl.epoch = 0; sl.last_seq = 0;
     }
     current = -1;
     image_capacity = 0;
@@ -872,6 +879,13 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   const size_t cap = c->max_lds > reserve ? c->max_lds - reserve : 0;
   if (c->lds_root_bytes > cap) c->lds_root_bytes = uint32_t(cap);
   HIP_TRY(dust::configure_kernels(c->max_lds));
+  {  // (a context without the word works as before: commits that find the host a ring ahead wait for the whole stream)
+    void* w = nullptr;
+    if (!std::getenv("DUST_HIP_NO_START_WORD") && hipHostMalloc(&w, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && w) {
+      std::memset(w, 0, 64);
+      c->started = static_cast<volatile uint32_t*>(w);
+    } else (void)hipGetLastError();
+  }
   *out = c.release();
   return DUST_OK;
 }
@@ -1472,7 +1486,22 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
     if (!s->ctx->copy) HIP_TRY(hipStreamCreateWithFlags(&s->ctx->copy, hipStreamNonBlocking));
     const int slot = int(s->next_slot++ % DustHipScene::kImages);
     DustHipScene::Slot& sl = s->slots[slot];
-    if (sl.epoch == s->ctx->sync_epoch) HIP_TRY(sync_stream(s->ctx));  // nobody has waited since a frame last read this slot: the host is a ring ahead
+    if (sl.epoch == s->ctx->sync_epoch) {  // nobody has waited since a frame last read this slot: the host is a ring ahead
+      // The frame AFTER that one has started => that one is done (one stream, launches in order; only the plain case: nothing outstanding on the
+      // side stream or on communicators' streams). The GPU keeps the rest of the ring to work on meanwhile:
+      // waiting for the whole stream instead left it idle for the ~50 us the host needs to enqueue again, every 8th frame (2 % of a moving view).
+      DustHipContext* c = s->ctx;
+      bool waited = false;
+      const uint32_t need = sl.last_seq + (c->side ? 2u : 1u);  // (a surfel pass on the side stream is joined in the course of the NEXT frame: one more)
+      if (c->started && sl.last_seq != 0 && !c->side_busy && c->extra_streams.empty() && int32_t(c->frame_seq - need) >= 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 0;; ++spin) {
+          if (int32_t(*c->started - need) >= 0) { waited = true; break; }
+          if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // (something else holds the queue: wait for all of it)
+        }
+      }
+      if (!waited) HIP_TRY(sync_stream(c));
+    }
     const size_t used = s->layout.grid_items + n_items * sizeof(uint16_t);  // (the sections' spare room is not sent)
     std::memcpy(sl.host, img, used);
     HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, used, hipMemcpyHostToDevice, s->ctx->copy));
@@ -1907,6 +1936,15 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // primary + AO in one launch unless told otherwise (DUST_HIP_NO_FUSE=1 keeps the reference's one-launch-per-pass shape)
   const bool fuse = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION) && !tune.no_fuse;
   p->fused_last = fuse;
+  // the frame's first traversal launch tells the host that the frame has started (DustHipContext::started; dust_hip_scene_commit)
+  bool start_said = false;
+  auto say_start = [&](dust::FrameArgs& x) {
+    if (start_said || !ctx->started) return;
+    start_said = true;
+    x.started_word = const_cast<uint32_t*>(ctx->started);
+    x.started_seq = ++ctx->frame_seq;
+    s->slots[s->current].last_seq = x.started_seq;
+  };
   if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p0, st));
   if (fuse) {
     take_counters(p, 0, a);
@@ -1922,7 +1960,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       fblock = 1024;
       fgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus), (total_tiles + 7) / 8));
     }
+    say_start(a);
     HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
+    a.started_word = nullptr;
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
@@ -1930,7 +1970,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
+    say_start(a);
     HIP_TRY(dust::launch_primary(a, grid, block, count, st));
+    a.started_word = nullptr;
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; }
   }
   if (!fuse && (fp->passes & DUST_PASS_AMBIENT_OCCLUSION)) {
@@ -1938,7 +1980,9 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     { DustStatus os = order_tiles(p, 1, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 1;
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(1), st));
+    say_start(a);
     HIP_TRY(dust::launch_ambient_occlusion(a, grid, block, count, st));
+    a.started_word = nullptr;
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(1), st)); p->ev_valid[1] = true; }
   }
   if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p1, st));

@@ -256,6 +256,12 @@ struct FrameArgs {
   uint32_t stream_top_iters;    // ... and the grid steps + box tests per phase of a lane that walks the grid itself (candidate overflow)
   DevGrid grid;               // top-level structure over the instances (per-ray walks of the GI passes)
   DevStream stream;           // the pass's ray stream (DUST_HIP_RAY_STREAM)
+  // A frame's FIRST traversal launch on the context's stream says that it has started: workgroup 0 writes `started_seq` into a word of
+  // pinned host memory (null: this launch says nothing). Launches of one stream run one after the other, so the host then knows that
+  // every earlier frame of the stream is done -- which is how dust_hip_scene_commit recycles a scene image without waiting for the
+  // whole queue when the host runs a ring of commits ahead (capi.cpp).
+  DUST_RW(uint32_t) started_word;
+  uint32_t started_seq;
 };
 
 }  // namespace dust

@@ -1627,6 +1627,8 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   if (threadIdx.x < 16) g_dbg_mask[threadIdx.x] = 0;
 #endif
   if (blockIdx.x == 0 && threadIdx.x < kRegions) a.next_work_counters[threadIdx.x * kCounterStride] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.started_word)  // (dust_dev.h: the frame's first launch tells the host it is running)
+    __hip_atomic_store((uint32_t*)a.started_word, a.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(block_queue(a))[threadIdx.x] = 0u;  // {next, end} = {0, 0}: empty; band_try = 0
   if (threadIdx.x < (blockDim.x >> 6) * 2u) reinterpret_cast<uint32_t*>(block_queue(a) + 2)[threadIdx.x] = 0xFFFFFFFFu;  // per-wave tile accounts: none open
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the

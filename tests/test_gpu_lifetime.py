@@ -137,6 +137,41 @@ def test_commit_between_frames_changes_nothing_and_does_not_wait():
     assert per < 500.0   # (ctypes + numpy marshalling dominate here; tools/commit_timing measures the C call alone)
 
 
+def test_host_a_ring_of_commits_ahead_of_the_gpu():
+    """A frame loop that never waits: set_transform + commit + render, 64 times over at a frame size the GPU needs longer for than
+    the host. The scene image lives in a ring of 8 copies; when the ring comes round the commit waits until the frame after the
+    slot's last reader has STARTED (the word its first launch writes, DustHipContext::started) -- not for the whole queue.
+    Every frame goes into the running mean (PASS_ACCUMULATE) and moves the instance by its own amount: a frame that saw a
+    recycled image too early, or too late, changes the mean. Equal, bit for bit, to the same loop with a wait after every frame;
+    and to the loop in a pipeline with GI passes on the side stream in between (the commit then takes the careful way)."""
+    cam, sky = P.camera_for((90.0, 60.0, -80.0)), P.sky_state()
+    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_ACCUMULATE
+
+    def loop(wait, gi_every=0):
+        ctx, desc, models, scene, pipe = _setup(w=1920, h=1080)
+        t0 = np.array(desc.instances[2][1], np.float32)
+        for f in range(1, 65):
+            moved = t0.copy()
+            moved[3] += 0.37 * f
+            moved[7] -= 0.11 * f
+            scene.set_transform(2, moved)
+            scene.commit()
+            extra = (L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED) if gi_every and f % gi_every == 0 else 0
+            pipe.render(scene, cam, sky, passes | extra, frame_index=f, rand=synth.frame_rand(11, f))
+            if wait:
+                ctx.sync()
+        return [pipe.read_plane(pl) for pl in (L.PLANE_ACCUM, L.PLANE_DEPTH, L.PLANE_VOXEL_ID, L.PLANE_MOTION)]
+    want = loop(True)
+    got = loop(False)
+    for x, y in zip(want, got):
+        assert np.array_equal(x, y)
+    want = loop(True, gi_every=3)
+    got = loop(False, gi_every=3)
+    for x, y in zip(want[1:], got[1:]):   # (the GI passes feed the illuminance the mean is taken of; their own order is fixed by GI_ORDERED)
+        assert np.array_equal(x, y)
+    assert np.array_equal(want[0], got[0])
+
+
 def test_gi_state_save_and_restore():
     """dust_hip_pipeline_read_gi / _write_gi: three frames, save, restore into a fresh pipeline, two more frames == five frames."""
     cam, sky = P.camera_for((90.0, 60.0, -80.0)), P.sky_state()
