@@ -9,21 +9,21 @@ mkdir -p gpurun_out
   echo "# HEAD ${HEAD_STAMP:-unknown}: randomised GPU-vs-oracle sweeps (tools/stress_*.py), native backtrace preload"
   export LD_PRELOAD=$PWD/tools/diag/libsegv_bt.so
   run() { local t0=$SECONDS; "$@" > gpurun_out/_stab.tmp 2>&1; local rc=$?; echo "rc $rc ${SECONDS}s+$((SECONDS - t0)): $* :: $(tail -1 gpurun_out/_stab.tmp | cut -c1-160)"; }
-  run timeout 900 python3 tools/stress_parity.py 4000 41000
-  STRESS_SWITCHES=1 run timeout 900 python3 tools/stress_parity.py 4000 45000
-  DUST_HIP_RAY_STREAM=1 run timeout 900 python3 tools/stress_parity.py 3000 61000
-  DUST_HIP_RAY_STREAM=1 STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 100 64000
-  DUST_HIP_RAY_STREAM=1 STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 800 65000
-  STRESS_BIG=1 run timeout 900 python3 tools/stress_parity.py 600 49000
-  STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 150 49600
-  STRESS_FULL=1 run timeout 900 python3 tools/stress_parity.py 200 49800
-  STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 1500 50000
-  STRESS_FULLGI=1 run timeout 1200 python3 tools/stress_parity.py 12 53000
-  run timeout 900 python3 tools/stress_sharded.py 300 51500
-  run timeout 900 python3 tools/stress_host.py bands 300 52000
-  run timeout 900 python3 tools/stress_host.py commits 300 52300
-  run timeout 900 python3 tools/stress_host.py threads 20 52600
-  run timeout 900 python3 tools/stress_host.py schedule 40 52700
+  run timeout 900 python3 tools/stress_parity.py 4000 71000
+  STRESS_SWITCHES=1 run timeout 900 python3 tools/stress_parity.py 4000 75000
+  DUST_HIP_RAY_STREAM=1 run timeout 900 python3 tools/stress_parity.py 3000 81000
+  DUST_HIP_RAY_STREAM=1 STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 100 84000
+  DUST_HIP_RAY_STREAM=1 STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 800 85000
+  STRESS_BIG=1 run timeout 900 python3 tools/stress_parity.py 600 79000
+  STRESS_MANY=1 run timeout 900 python3 tools/stress_parity.py 150 79600
+  STRESS_FULL=1 run timeout 900 python3 tools/stress_parity.py 200 79800
+  STRESS_DEEP=1 run timeout 900 python3 tools/stress_parity.py 1500 90000
+  STRESS_FULLGI=1 run timeout 1200 python3 tools/stress_parity.py 12 93000
+  run timeout 900 python3 tools/stress_sharded.py 300 91500
+  run timeout 900 python3 tools/stress_host.py bands 300 92000
+  run timeout 900 python3 tools/stress_host.py commits 600 92300
+  run timeout 900 python3 tools/stress_host.py threads 20 92600
+  run timeout 900 python3 tools/stress_host.py schedule 40 92700
   run timeout 600 python3 tools/stress_edits.py
   run timeout 600 python3 tools/stress_denoise.py
   run timeout 600 python3 tools/stress_tonemap.py
