@@ -1342,8 +1342,9 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
         for (uint32_t x = rl & 255u; x <= (rh & 255u); ++x) s->grid_items[at[(size_t(z) * g.dim[1] + y) * g.dim[0] + x]++] = uint16_t(i);
   }
 }
-// the instances in the order of a Morton curve through their boxes' centres (10 bits per axis over the scene's bounds): the packet
-// cull's groups are runs of 64 consecutive slots
+// the instances in the order of a Hilbert curve through their boxes' centres (10 bits per axis over the scene's bounds; Skilling's
+// transform): the packet cull's groups are runs of 64 consecutive slots, and consecutive cells of this curve are always neighbours
+// (along a Z-order a run that crosses a block boundary jumps across the scene, and the group's box with it)
 void order_slots(DustHipScene* s) {
   const size_t n = s->world_boxes.size() / 6;
   std::vector<std::pair<uint32_t, uint32_t>> keyed(n);
@@ -1355,7 +1356,19 @@ void order_slots(DustHipScene* s) {
       const double mid = 0.5 * (double(s->world_boxes[i * 6 + a]) + double(s->world_boxes[i * 6 + 3 + a]));
       c[a] = uint32_t(std::min(1023.0, std::max(0.0, (mid - double(s->world_min[a])) / span * 1024.0)));
     }
-    keyed[i] = {spread(c[0]) | (spread(c[1]) << 1) | (spread(c[2]) << 2), uint32_t(i)};
+    uint32_t X[3] = {c[0], c[1], c[2]};
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+      const uint32_t P = Q - 1u;
+      for (int a = 0; a < 3; ++a) {
+        if (X[a] & Q) X[0] ^= P;
+        else { const uint32_t t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+      }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1) if (X[2] & Q) t ^= Q - 1u;
+    for (uint32_t& x : X) x ^= t;
+    keyed[i] = {(spread(X[0]) << 2) | (spread(X[1]) << 1) | spread(X[2]), uint32_t(i)};
   }
   std::sort(keyed.begin(), keyed.end());
   s->slot_order.resize(n);
@@ -1711,7 +1724,7 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     b.gi.sort_keys = sk[0];
     b.gi.sort_vals = sv[0];
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(3), st));
-    if (!tune.no_surfel_sort) {  // phase 0: 16-bit Morton keys + radix sort -> gi.perm
+    if (!tune.no_surfel_sort) {  // phase 0: 16-bit space-filling-curve keys + radix sort -> gi.perm
       HIP_TRY(dust::launch_surfel_keys(b, st));
       bool in_b = false;
       HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
