@@ -39,6 +39,9 @@ __device__ __forceinline__ bool gather_ray(ArgsRef a, uint32_t px, uint32_t py, 
 // faster); 48 bins on 64x32 tiles 0.267, 64x64 0.256 (96 bins there: 0.250, frame 0.3 % faster), 128x64 0.255 (frame no faster): more rays per tile make a packet's 64
 // entries fall into fewer bins, until the spread of their origins costs as much.
 // Every pixel's ray, hit and stores are exactly what they were: only the lane a pixel rides in changes.
+// position of direction bin (octant * 6 + dominant axis * 2 + which of the other two is larger) along that path (k_gather_order)
+__constant__ uint8_t kBinPath[48] = {2, 1, 3, 4, 0, 5, 9, 10, 8, 7, 11, 6, 22, 21, 23, 18, 20, 19, 14, 13, 15, 16, 12, 17,
+                                     45, 46, 44, 43, 47, 42, 38, 37, 39, 40, 36, 41, 25, 26, 24, 29, 27, 28, 33, 34, 32, 31, 35, 30};
 constexpr uint32_t kOrderTile = 32, kOrderTileW = 64, kOrderTileH = 64, kOrderThreads = kOrderTile * kOrderTile, kOrderSlots = kOrderTileW * kOrderTileH;
 __global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs) {
   ArgsRef a = launch_args();
@@ -65,7 +68,13 @@ __global__ void __launch_bounds__(kOrderThreads) k_gather_order(const FrameArgs)
     const float ax = fabsf(ad.x), ay = fabsf(ad.y), az = fabsf(ad.z);
     const uint32_t dom = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
     const uint32_t sec = dom == 0u ? (ay >= az ? 0u : 1u) : (dom == 1u ? (ax >= az ? 0u : 1u) : (ax >= ay ? 0u : 1u));
-    const uint32_t key = live ? ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec : kBins;
+    // the bins in the order of a path over the sphere on which consecutive bins are neighbours: inside an octant the six orders of the
+    // components' magnitudes by adjacent swaps; from one octant to the next ONE sign flips, that of the smallest component (kBinPath).
+    // A packet that straddles two bins -- most do: 4096 entries over 48 bins -- then bounds two adjacent cones instead of two unrelated
+    // ones, whose direction intervals straddle zero on two or three axes and leave the packet's cull nothing to reject
+    // (k_final_gather 0.2356 -> 0.2274 ms)
+    const uint32_t raw = ((ad.x < 0.0f ? 1u : 0u) | (ad.y < 0.0f ? 2u : 0u) | (ad.z < 0.0f ? 4u : 0u)) * 6u + dom * 2u + sec;
+    const uint32_t key = live ? (uint32_t)kBinPath[raw] : kBins;
     uint64_t peers = ~0ull;
 #pragma unroll
     for (uint32_t bit = 0; bit < 6; ++bit) {
