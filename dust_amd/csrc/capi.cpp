@@ -1470,8 +1470,7 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       std::memcpy(img + s->layout.grid_cells, s->grid_cells.data(), s->grid_cells.size() * sizeof(uint32_t));
       // the packet cull's 64-wide hierarchy (kernels: cull_instances): slots along a Morton curve through the boxes' centres -- ordered
       // by structural commits, refitted by every commit --, a box per 64 consecutive slots
-      static const uint32_t flat_max = std::getenv("DUST_HIP_FLAT_CULL_MAX") ? uint32_t(std::atoi(std::getenv("DUST_HIP_FLAT_CULL_MAX"))) : dust::kFlatCullMax;  // (A/B runs)
-      s->n_groups = n > flat_max && !std::getenv("DUST_HIP_FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
+      s->n_groups = n > dust::kFlatCullMax && !std::getenv("DUST_HIP_FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
       if (s->n_groups) {
         if (full || s->slot_order.size() != n) {
           order_slots(s);
