@@ -114,7 +114,9 @@ def main():
         pipe.render(scene, cam, sky, passes, 5, synth.frame_rand(1, 5))
         ctx.sync()
         b = read(lib)
-        if b[23] and slot >= 3:
+        # (bucket 23 is the ray streams' trip counter AND the packet kernels' candidate-loop cycles: which kernels ran is known from the switches)
+        streamed = slot >= 3 and ("DUST_HIP_RAY_STREAM" in os.environ or ("--deep" in sys.argv and slot == 3 and "DUST_HIP_PACKET_GI" not in os.environ))
+        if streamed:
             report_stream(title + " -> k_ray_walk", b, pipe.pass_stats(slot).ms)
         else:
             report(title, b, pipe.pass_stats(slot).ms)
