@@ -41,10 +41,16 @@ __global__ void __launch_bounds__(kThreads) k_radix_histogram(PassArgs a) {
   for (uint32_t d = threadIdx.x; d < (1u << BITS); d += kThreads) bins[d] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kTile;
+  uint32_t key[kRounds];
+#pragma unroll
+  for (uint32_t r = 0; r < kRounds; ++r) {  // the loads in one batch, then the LDS atomics
+    const uint32_t i = base + r * kThreads + threadIdx.x;
+    key[r] = i < a.n ? a.keys_in[i] : 0u;
+  }
 #pragma unroll
   for (uint32_t r = 0; r < kRounds; ++r) {
     const uint32_t i = base + r * kThreads + threadIdx.x;
-    if (i < a.n) atomicAdd(&bins[(a.keys_in[i] >> a.shift) & ((1u << BITS) - 1u)], 1u);
+    if (i < a.n) atomicAdd(&bins[(key[r] >> a.shift) & ((1u << BITS) - 1u)], 1u);
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < (1u << BITS); d += kThreads) a.hist[(size_t)blockIdx.x * (1u << BITS) + d] = bins[d];
@@ -60,6 +66,7 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
   // (a) digit totals and the share of the tiles before this one
   for (uint32_t d = threadIdx.x; d < NB; d += kThreads) {
     uint32_t total = 0, before = 0;
+#pragma unroll 16  // sixteen independent loads per round trip (the rolled loop made one trip per two tiles: most of the kernel's time)
     for (uint32_t t = 0; t < a.n_tiles; ++t) {
       const uint32_t c = a.hist[(size_t)t * NB + d];
       total += c;
@@ -94,12 +101,19 @@ __global__ void __launch_bounds__(kThreads) k_radix_scatter(PassArgs a) {
   const uint32_t base = blockIdx.x * kTile + wave * (kRounds * 64u);  // a wave owns kRounds * 64 consecutive items
   const uint64_t lower = (1ull << lane) - 1ull;
   uint32_t key[kRounds], val[kRounds], rank[kRounds];
+  // every round's loads first, in one batch: the wave-level fences of the ranking loop keep the compiler from hoisting a round's loads over
+  // the round before it, and eight dependent round trips to memory were most of this kernel's 20 us
 #pragma unroll
   for (uint32_t r = 0; r < kRounds; ++r) {
     const uint32_t i = base + r * 64u + lane;
     const bool valid = i < a.n;
     key[r] = valid ? a.keys_in[i] : 0u;
     val[r] = valid ? a.vals_in[i] : 0u;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < kRounds; ++r) {
+    const uint32_t i = base + r * 64u + lane;
+    const bool valid = i < a.n;
     const uint32_t digit = (key[r] >> a.shift) & (NB - 1u);
     uint64_t peers = __ballot(valid);  // lanes holding the same digit as this one
 #pragma unroll
