@@ -453,7 +453,32 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
   // items), then the any-hit sun rays: with both rays of a group in one item the pool is only 1.3 items per resident wave and
   // the kernel lasts as long as the waves that drew two. What a lit surfel receives from the sun goes through its own array
   // and is added when the request is applied (surfel.rmiss:14-26 / surfel.rchit:35-102 add it to the same value there).
+#ifdef DUST_PROFILE
+  // profile builds, DUST_HIP_DEBUG = (cycles / 1024) << 12: only the work items that took at least that long stay in the section buckets
+  // (what is different about the items the kernel's length hangs on, tools/kernel_sections.py --heavy). Lane i keeps bucket i as it was
+  // when the item began and puts it back if the item turns out short; P_TOTAL then counts the kept items' cycles.
+  unsigned long long pf_snap = 0, pf_t0 = 0, pf_kept = 0;
+  bool pf_open = false;
+  const unsigned long long pf_min = (unsigned long long)(a0.debug >> 12) << 10;
+  auto pf_item = [&](bool last) {
+    if (pf_min == 0ull) return;
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (pf_open) {
+      if (now - pf_t0 < pf_min) { if (l < (uint32_t)kProfBuckets) g_prof[w][l] = pf_snap; }
+      else pf_kept += now - pf_t0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (last && l == 0u) g_prof[w][P_TOTAL] = pf_kept - now;  // (prof_end adds the clock: total = the kept items' cycles)
+    if (l < (uint32_t)kProfBuckets) pf_snap = g_prof[w][l];
+    pf_t0 = now; pf_open = true;
+  };
+#endif
   while (next_packet(a0, wc, p)) {  // tiles_x = 2 * ceil(pool_size / 64), tiles_y = 1
+#ifdef DUST_PROFILE
+    pf_item(false);
+#endif
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
     const uint32_t groups = (a.gi.pool_size + 63u) / 64u;
     const uint32_t item = p.px / kTileW;
@@ -539,6 +564,9 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
       ar.gi.replacement[i] = repl;
     }
   }
+#ifdef DUST_PROFILE
+  pf_item(true);
+#endif
   prof_end();
   flush_stats<MODE>(a0, 0, st_sun);
   flush_stats<MODE>(a0, 1, st_cos);

@@ -52,7 +52,7 @@ __device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, 
     if (h.inst != cur) continue;
     todo = false;
     InstanceRef in = a.instances[cur];
-    ModelRef m = a.models[in.model];
+    ModelRef m = a.visits[cur].m;  // the instance's model record by the instance's index (a.models[in.model] is a round trip behind `in`)
     const uint32_t block = resolve_block(m, h.block);
     const DustHipBlock b = load_block(m.blocks + block);
     const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);

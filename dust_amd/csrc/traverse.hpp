@@ -1772,9 +1772,19 @@ __device__ bool hash_get(const DUST_CONST_AS DevGI& gi, HashKey key, uint32_t fr
 // store). One body, so both forms take the same decisions in the same order.
 struct HashMemory {
   uint32_t* base;  // first entry of the window
-  __device__ __forceinline__ uint32_t claim(uint32_t i, uint32_t fp) { return atomicCAS(&base[i * 3], 0u, fp); }
-  __device__ __forceinline__ uint32_t meta(uint32_t i) const { return base[i * 3 + 2]; }
-  __device__ __forceinline__ uint32_t radiance(uint32_t i) const { return base[i * 3 + 1]; }
+  // the probe's radiance and meta words are requested WITH the compare-and-swap of its fingerprint, not behind it (three dependent round
+  // trips to a random place of a 384 MB table per probe -> one). As racy as the shader's reads after its atomicCompSwap
+  // (spatial_hash.glsl:147-195): another invocation may write the entry at any time either way.
+  uint32_t rad_c, meta_c;
+  __device__ __forceinline__ uint32_t claim(uint32_t i, uint32_t fp) {
+    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    const u32x2_a4 rm = *reinterpret_cast<const volatile u32x2_a4*>(&base[i * 3 + 1]);
+    const uint32_t old = atomicCAS(&base[i * 3], 0u, fp);
+    rad_c = rm.x; meta_c = rm.y;
+    return old;
+  }
+  __device__ __forceinline__ uint32_t meta(uint32_t) const { return meta_c; }
+  __device__ __forceinline__ uint32_t radiance(uint32_t) const { return rad_c; }
   __device__ __forceinline__ void set(uint32_t i, uint32_t rad, uint32_t meta_) { base[i * 3 + 1] = rad; base[i * 3 + 2] = meta_; }
   __device__ __forceinline__ void set_fingerprint(uint32_t i, uint32_t fp) { base[i * 3] = fp; }
 };
@@ -1851,7 +1861,7 @@ __device__ __forceinline__ V3 faceid2normal(uint32_t face) {  // normal.glsl:20-
 // world-space surfel (brick centre + face) and hash key of a rough hit: final_gather.rchit:35-45, surfel.rchit:35-45
 __device__ void brick_surfel(ArgsRef a, const Hit& h, V3 o, V3 d, HashKey& key, DevSurfel& sf, uint32_t& avg_albedo) {
   InstanceRef in = a.instances[h.inst];
-  ModelRef m = a.models[in.model];
+  ModelRef m = a.visits[h.inst].m;  // (by the instance's index: not a round trip behind `in`, as a.models[in.model] is)
   const DustHipBlock b = load_block(m.blocks + resolve_block(m, h.block));
   const V3 ctr = mk((float)b.x + 2.0f, (float)b.y + 2.0f, (float)b.z + 2.0f);
   const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-item cycle costs of the surfel trace (pass kind 3) on the bench scene: is the kernel as long as its work or as its longest items?
-(GPU box) usage: surfel_items.py [frames]"""
+(GPU box) usage: surfel_items.py [frames [sun azimuth in degrees]]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,6 +9,7 @@ from dust_amd import scenes as P
 from dust_amd import _lib as L, api, synth
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+azimuth = float(sys.argv[2]) if len(sys.argv) > 2 else None   # degrees (the default sun stands at 180: x == 0)
 os.environ.setdefault("DUST_HIP_NO_SIDE_STREAM", "1")
 W, H = 1920, 1080
 ctx = api.Context(device=0, timing=True)
@@ -21,6 +22,11 @@ pipe.set_noise(5, synth.stbn_unitvec3_cosine())
 eye = (122.0, 300.61, 54.45)
 cam = api.make_camera(eye, api.look_at_rotation(eye, (0, 0, 0)), api.PinholeProjection())
 sky = P.sky_state()
+if azimuth is not None:   # the default sun turned about the vertical: same elevation, same baked coefficients
+    h = float(np.hypot(sky[48], sky[50]))
+    sky = sky.copy()
+    sky[48], sky[50] = h * np.sin(np.deg2rad(azimuth)), h * np.cos(np.deg2rad(azimuth))
+    print("sun", sky[48:51])
 passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
 for f in range(1, frames + 1):
     pipe.render(scene, cam, sky, passes, f, synth.frame_rand(1, f))

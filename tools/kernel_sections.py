@@ -4,6 +4,9 @@
   python tools/kernel_sections.py --build      # here (cross-compiles dust_amd/libdust_hip_prof.so, which travels with gpurun)
   gpurun -- 'python tools/kernel_sections.py [--deep]'  # on the GPU box (--deep: the 4096^3 stress tree instead of the castle)
 
+  DUST_HIP_DEBUG=$(( (cycles / 1024) << 12 )) python tools/kernel_sections.py   # k_surfel_trace: only the work items that took at least
+                                                        # `cycles` (of this instrumented build) stay in the buckets: what the longest items are made of
+
 Buckets are INCLUSIVE wave cycles summed over all waves; the table prints exclusive shares. The timers themselves
 cost ~10 instructions per mark, so treat the shares as relative, not as absolute kernel time.
 """
