@@ -1,5 +1,5 @@
 #!/bin/bash
-# session-6 A/B: GI frame with library builds given as arguments; step times (side stream and in place) + rocprofv3 per-kernel averages in place
+# A/B of library builds on the GI frame (arguments: the builds); step times (side stream and in place) + rocprofv3 per-kernel averages in place
 R=$GRAFT_REPO_ROOT; cd $R; out=$R/gpurun_out
 export ROUNDS=${ROUNDS:-2} WORKLOADS=gi STEPS=60
 echo "== side stream"; bash tools/ab.sh "$@"
