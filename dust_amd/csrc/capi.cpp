@@ -512,7 +512,7 @@ struct DustHipPipeline {
   // GI frame runs its surfel pass in place and is timed (P: primary / AO kernels, Q: the pass); once those events have completed --
   // looked at without waiting, some frames later -- the pass's share is 100 Q / (Q + 1.05 P) - 3, which is where the measured optima
   // of three workloads lie (castle 1080p 50 %, 4K 20 %, the 4096^3 tree 25 %). Until then: a guess from the ray counts.
-  struct { hipEvent_t p0 = nullptr, p1 = nullptr, q0 = nullptr, q1 = nullptr; int state = 0; uint32_t share = 0, gi_frames = 0; } side_cal;
+  struct { hipEvent_t p0 = nullptr, p1 = nullptr, q0 = nullptr, q1 = nullptr; int state = 0; uint32_t share = 0; } side_cal;
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
@@ -1920,10 +1920,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     }
     (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
     const bool gi_frame = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_SURFEL);
-    // (the timed in-place frame is the pipeline's 9th GI frame, not its first: by then the hand-out orders exist -- the first frame's unordered
-    // surfel trace has a tail of its own, and the 4096^3 tree's share came out at 29 or 40 % from one run to the next)
-    calibrate = cal.state == 0 && gi_frame && !tune.no_side_stream && !count && !sharded && !(tune.debug & 16u) && cal.gi_frames++ >= 8u;
-    if (calibrate && ctx->side_busy) HIP_TRY(join_side(ctx));  // (this frame's kernels run alone: the previous frame's pass first)
+    calibrate = cal.state == 0 && gi_frame && !tune.no_side_stream && !count && !sharded && !ctx->side_busy && !(tune.debug & 16u);
     if (calibrate && !cal.p0)
       for (hipEvent_t* e : {&cal.p0, &cal.p1, &cal.q0, &cal.q1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
     if (cal.share) share = cal.share;
