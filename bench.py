@@ -92,7 +92,7 @@ def parse(argv=None):
                          "examples/castle.rs:287-291 swinging, set_transform + commit every frame); the default line carries it as curves.moving")
     ap.add_argument("--no-extra-curves", action="store_true",
                     help="one GPU, default workload: skip curves.moving / gi_1080p / primary_ao_4k / deep (short runs after the headline's timed region)")
-    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra curve")
+    ap.add_argument("--extra-steps", type=int, default=40, help="timed steps of each extra curve (40: a 10-step region of 0.7 ms GI frames is 7 ms, of which the two synchronisations around it are percents)")
     ap.add_argument("--extra-timeout", type=float, default=150.0, help="seconds the extra curves may take before the line is printed without them")
     ap.add_argument("--assets", default=None,
                     help="directory with the reference's LFS assets (castle.vox, teapot.vox, stbn_scalar_*.png, stbn_unitvec3_cosine_*.png): a file "
