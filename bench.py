@@ -71,9 +71,18 @@ def parse(argv=None):
                     help="frames of the sequence on the GPU at once, each on a stream, context and G-buffer of its own (0 = auto: 4 for "
                          "row bands on N > 1 GPUs, where a rank's launch is as long as its most expensive tile and most of the GPU would "
                          "idle behind it; 1 otherwise). GI workloads run one frame at a time (every frame reads the previous one's hash)")
+    ap.add_argument("--in-flight-slots", choices=["auto", "share", "all"], default="auto",
+                    help="with several frames in flight: share = every launch on 1/D of the workgroup slots (row bands: a band is as long as its "
+                         "heaviest tile, D of them side by side fill the device); all = every launch asks for ALL slots, so the next frame's workgroups "
+                         "start on the CUs the previous frame's last tiles have left (whole frames on one GPU); auto = share for row bands of an N > 1 "
+                         "job (or an emulated band), all otherwise (DustHipPipelineConfig.in_flight_slots)")
     ap.add_argument("--band-cuts", choices=["cost", "rows"], default="cost",
                     help="row bands of a non-GI workload: cost = bands of about equal measured cost (one untimed whole-frame launch records every "
                          "tile's cycles, rank 0's map decides); rows = equal row counts")
+    ap.add_argument("--band-rebalance", type=int, default=3,
+                    help="row bands at equal cost: rounds of proportional correction of the cuts from MEASURED band-step times (every rank times its "
+                         "own band under the run's frames in flight, without collectives; sharding.rebalance_cuts) before the timed region; 0 = the "
+                         "cuts of the one whole-frame tile-cost map (round 5)")
     ap.add_argument("--deep-occupancy", type=float, default=0.01, help="--workload deep: occupied share of the brick lattice")
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N > 1, row bands: native = the library's own RCCL path (dust_hip_comm_create / dust_hip_gather_bands / "
@@ -137,10 +146,9 @@ class HipBackend:
         # One explicit stream for everything: the library's launches, torch's own kernels, and the point RCCL orders its
         # collectives against (torch's "current stream"). torch's DEFAULT stream has the handle 0, which the library reads as
         # "no stream given" and would answer with a private non-blocking stream that nothing of torch's is ordered with.
-        if world > 1:
-            # leave 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the traversal
-            # kernels (which otherwise hold every VGPR of every SIMD) and frame k's gather really overlaps frame k+1
-            os.environ.setdefault("DUST_HIP_RESERVE_BLOCKS", "32")
+        # (world > 1: every pipeline leaves 32 of the 512 workgroup slots empty so that RCCL's send / receive kernels can run next to the
+        #  traversal kernels, which otherwise hold every VGPR of every SIMD -- DustHipPipelineConfig.reserve_blocks, set in open_lane; the
+        #  library does the same on its own once a pipeline has been through one of its collectives, DUST_RESERVE_AUTO)
         self.streams = []
         self.stream, self.ctx = self._stream_and_context()
         torch.cuda.set_stream(self.stream)
@@ -178,6 +186,8 @@ class HipBackend:
             lane.sc = dict(first)
             lane.sc["scene"] = self.P.hip_scene(lane.ctx, first["desc"])
         lane.pipe = self.api.StandardPipeline(lane.ctx, args.width, args.height)
+        if self.world > 1 or os.environ.get("DUST_BENCH_EMULATE_BAND"):
+            lane.pipe.configure(reserve_blocks=32)
         lane.enter = lambda: self.torch.cuda.stream(lane.stream)
         return lane
 
@@ -325,28 +335,90 @@ def measure_curve(be, dist, args, lanes, shard):
     per_rows, rows, send = sharding.band_layout(rank, world, H) if bands else (H, (0, H), (0, H))
     emulate = os.environ.get("DUST_BENCH_EMULATE_BAND")  # "r/N" on ONE GPU: this rank renders band r of N, nothing is gathered --
     emulate = emulate if (emulate and bands and world == 1) else None   # what a rank of an N-GPU strong-scaling run does between collectives
-    er, en = (int(v) for v in emulate.split("/")) if emulate else (rank, world)
+    # ("all/N": every band of N is timed while the cuts are balanced, and the timed region then runs the SLOWEST one -- the frame is done when it is)
+    er_all = bool(emulate) and emulate.split("/")[0] == "all"
+    er, en = ((0 if er_all else int(emulate.split("/")[0])), int(emulate.split("/")[1])) if emulate else (rank, world)
     if emulate:
         per_rows, rows, send = sharding.band_layout(er, en, H)
         send = (send[0], en * per_rows)  # (sizes the padded render target as the N-rank run would)
-    band_cuts = None
+    D = len(lanes)
+    slots_mode = getattr(args, "in_flight_slots", "auto")
+    if slots_mode == "auto":
+        slots_mode = "share" if (bands and (world > 1 or emulate)) else "all"
+    for lane in lanes:
+        if hasattr(lane.pipe, "configure"):
+            lane.pipe.configure(frames_in_flight=D, in_flight_slots=slots_mode)  # D launches side by side on 1/D of the workgroup slots each, or one behind the other's tail
+        else:
+            lane.pipe.set_frames_in_flight(D)
+    band_cuts, balance_log, band_steps_ms = None, [], None
     if bands and not gi_mode and en > 1 and args.band_cuts == "cost":
         # Bands of equal COST instead of equal rows (a frame is done when its slowest band is: the castle's top half takes 0.122 ms,
         # its bottom half 0.096). One untimed whole-frame launch records every tile's cycles; rank 0's map decides the cuts for all.
         pipe.render(sc["scene"], cam, sky, passes, frame_index=1, rand=synth.frame_rand(1, 1))
         be.sync()
         costs = pipe.tile_costs(0)
-        band_cuts = sharding.balanced_cuts(None if costs is None else costs.sum(axis=1), en, H)
+        strip_cost = None if costs is None else costs.sum(axis=1)
+        band_cuts = sharding.balanced_cuts(strip_cost, en, H)
         if world > 1:
             agreed = torch.tensor(band_cuts, dtype=torch.int64, device=be.device)
             dist.broadcast(agreed, src=0)
             band_cuts = [int(v) for v in agreed.tolist()]
+        # ... and that map, taken under ONE launch that had the device to itself, mispredicts a band's step under D frames in flight by +-15 %
+        # (round 5: seven bands of eight at 0.032-0.034 ms, one at 0.0425): a few rounds of proportional correction from measured band-step
+        # times. Every rank times ITS band -- frames in flight as in the timed region, no collective inside -- and the times are shared.
+        BAL_WARM, BAL_STEPS = 48, 96
+
+        def band_step_ms(r, cuts):
+            _, rws, _ = sharding.layout_from_cuts(r, cuts, H)
+            if rws[0] >= rws[1]:
+                return 0.0
+            for phase in (BAL_WARM, BAL_STEPS):
+                be.sync()
+                t0 = time.perf_counter()
+                for k in range(phase):
+                    ln = lanes[k % D]
+                    ln.pipe.render(ln.sc["scene"], cam, sky, passes, frame_index=1 + k, rand=synth.frame_rand(1, 1 + k), rows=rws)
+                be.sync()
+            return (time.perf_counter() - t0) / BAL_STEPS * 1e3
+
+        def all_band_ms(cuts):
+            if world > 1:
+                mine = torch.tensor([band_step_ms(rank, cuts)], dtype=torch.float64, device=be.device)
+                every = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                return [float(v.item()) for v in every]
+            return [band_step_ms(r, cuts) for r in range(en)] if (er_all or getattr(args, "band_rebalance", 0)) else None
+        rounds = int(getattr(args, "band_rebalance", 0)) if hasattr(lanes[0].pipe, "configure") else 0
+        best = None
+        for rd in range(rounds + 1):
+            ms_now = all_band_ms(band_cuts) if (rounds or er_all) else None
+            if ms_now is None:
+                break
+            balance_log.append({"cuts": list(band_cuts), "band_ms": [round(v, 4) for v in ms_now]})
+            if best is None or max(ms_now) < max(best[1]):
+                best = (list(band_cuts), ms_now)
+            if rd == rounds:
+                break
+            band_cuts, strip_cost = sharding.rebalance_cuts(strip_cost, band_cuts, ms_now, en, H)
+        if best is not None:
+            band_cuts, band_steps_ms = best   # (the best set seen: a correction may overshoot)
+            if er_all:
+                er = max(range(en), key=lambda r: band_steps_ms[r])
         per_rows, rows, send = sharding.layout_from_cuts(er, band_cuts, H)
     have_rows = rows[0] < rows[1]                                        # a rank past the end of the frame renders no pixels
     gi_bands = gi_mode and bands and world > 1   # (one GPU: the band is the frame, nothing to exchange, the racy apply is fine)
-    if gi_bands:  # one frame, row bands, replicated surfel pass (SURVEY 8e option i)
+    # DUST_BENCH_EMULATE_BAND=r/N on a GI workload (one GPU): what rank r of an N-rank GI job does between collectives -- its band's pixel
+    # passes, the exchange's export / import on its own band, 1/N of the surfel trace (slots [r S, (r + 1) S) of the ordered pool), the
+    # replicated ordering and ordered apply. The other ranks' records in the staging arrays are those of the last FULL trace (the first
+    # EMULATE_FULL_STEPS steps trace the whole pool), so the apply does a frame's worth of inserts and the hash stays a converged one.
+    gi_emulate = gi_mode and bool(emulate)
+    EMULATE_FULL_STEPS = 24
+    if gi_bands:  # one frame, row bands; the surfel TRACE sharded over the ranks too (native communicator), ordering + apply replicated
         ex = pipe.gi_exchange(world * per_rows)
         ex_owner, ex_touched, ex_merged = be.alias_exchange(ex)
+    if gi_emulate:
+        pipe.gi_exchange(en * per_rows)
+        emu_comm = be.api.Comm.local(lanes[0].ctx, 1)[0]   # a loopback group of one: export + import, no reduction
 
     # Framebuffer gather: two illuminance targets in torch tensors, bound to the pipeline in turn (dust_hip_pipeline_bind_plane),
     # so RCCL moves frame k straight out of its render target while frame k+1 renders into the other one -- no staging copy.
@@ -361,10 +433,7 @@ def measure_curve(be, dist, args, lanes, shard):
     # Slots: step k renders into target k % S on lane (k % S) % D -- two targets per pipeline at least, so that a gather never
     # reads what the next frame of the same pipeline writes; with D > 1 frames in flight every lane has its own stream, and a
     # rank whose launch is held up by one expensive tile fills the rest of the GPU with the next frames' tiles.
-    D = len(lanes)
     S = max(2, D)
-    for lane in lanes:
-        lane.pipe.set_frames_in_flight(D)  # D launches side by side, each on 1/D of the workgroup slots
     fixed_targets = S == D  # every lane renders into one target of its own: bound once, not per step
     targets = [torch.zeros((tgt_rows, W, 4), dtype=torch.float16, device=be.device) for _ in range(S)]
     if slices:
@@ -408,7 +477,7 @@ def measure_curve(be, dist, args, lanes, shard):
         gather.wait_slot(k % S)  # the gather that last read this target is done
         if not fixed_targets:
             be.bind_target(pipe, targets[k % S])
-        if gi_bands:
+        if gi_bands or gi_emulate:
             frame_index = 1 + k  # every rank works on the same frame
             rnd = synth.frame_rand(1, frame_index)
             pix = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_GI_SHARDED
@@ -417,7 +486,9 @@ def measure_curve(be, dist, args, lanes, shard):
             if count:  # the second call restarts the counters: keep the pixel passes' now
                 be.sync()
                 pix_stats[:] = [pipe.pass_stats(i) for i in range(4)] if have_rows else []
-            if native:   # the same five steps inside the library, on the context's stream
+            if gi_emulate:
+                emu_comm.gi_exchange(pipe, rows[0] if have_rows else H, rows[1] if have_rows else H, en * per_rows, frame_index)
+            elif native:   # the same five steps inside the library, on the context's stream
                 lanes[0].comm.gi_exchange(pipe, rows[0] if have_rows else H, rows[1] if have_rows else H, per_rows, frame_index)
             else:
                 sharding.gi_exchange_step(dist, rank, world, ex_owner, ex_touched, ex_merged, per_rows * W,
@@ -426,7 +497,17 @@ def measure_curve(be, dist, args, lanes, shard):
                                           (lambda: pipe.gi_import(H, H, frame_index)))  # empty own range: every stamp is another band's
             # the replicated surfel pass must leave the SAME hash on every GPU: deterministic apply, not the racy one
             sp = L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED | cs | (L.PASS_ACCUMULATE if have_rows else 0)
-            pipe.render(scene, cam, sky, sp, frame_index=frame_index, rand=rnd, rows=rows if have_rows else (0, 0))
+            # the surfel pass: its TRACE sharded over the ranks where the library's communicator carries the records (an all-gather of 64 B per
+            # slot), its ordering and ordered apply replicated; through torch.distributed: the whole pass replicated (round 5's shape)
+            shard = ((er, en) if k >= EMULATE_FULL_STEPS else (0, 1)) if gi_emulate else ((rank, world) if native else (0, 0))
+            if shard[1]:
+                pipe.render(scene, cam, sky, sp, frame_index=frame_index, rand=rnd, rows=rows if have_rows else (0, 0), surfel_shard=shard)
+                if gi_emulate:
+                    pipe.gi_surfel_finish(frame_index)
+                else:
+                    lanes[0].comm.gi_surfel_exchange(pipe, frame_index)
+            else:
+                pipe.render(scene, cam, sky, sp, frame_index=frame_index, rand=rnd, rows=rows if have_rows else (0, 0))
         elif bands:
             frame_index = 1 + k
             if have_rows:
@@ -453,7 +534,7 @@ def measure_curve(be, dist, args, lanes, shard):
     barrier()
     n_classes = 6 if gi_mode else 3
     st = [pipe.pass_stats(i) for i in range(n_classes)]
-    if gi_bands:
+    if gi_bands or gi_emulate:
         st[:4] = pix_stats if pix_stats else [L.PassStats() for _ in range(4)]
     if bands and not have_rows:
         st[:min(4, n_classes)] = [L.PassStats() for _ in range(min(4, n_classes))]
@@ -521,8 +602,9 @@ def measure_curve(be, dist, args, lanes, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "band_cuts": band_cuts,
-            "comm": "native" if native else "torch", "denoise": denoise}
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "in_flight_slots": slots_mode if D > 1 else None, "band_cuts": band_cuts,
+            "comm": "native" if native else "torch", "denoise": denoise, "band_balance": balance_log or None,
+            "band_steps_ms": [round(v, 4) for v in band_steps_ms] if band_steps_ms else None, "emulated_band": (f"{er}/{en}" if emulate else None)}
 
 
 def compact(curve, gi_mode):
@@ -609,12 +691,13 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
     pipe.clear()
     gc.collect()
     gc.disable()
-    # The stretch is timed twice (settle frames, then the timed ones, each time) and the faster pass is reported: a frame loop that commits
-    # every frame can be at most a ring of 8 scene images (under 2 ms of GPU work) ahead of the GPU, so ONE multi-millisecond stall of the
-    # host process -- seen on these boxes about once in ten runs -- drains the queue and shows up in a 5 ms timed region as a several
-    # times slower step. Both passes are listed in `passes_ms_per_step`.
+    # The stretch is timed three times (settle frames, then the timed ones, each time) and the MEDIAN pass is reported: a frame loop that
+    # commits every frame can be at most a ring of 8 scene images (under 2 ms of GPU work) ahead of the GPU, so ONE multi-millisecond stall
+    # of the host process -- seen on these boxes about once in ten runs -- drains the queue and shows up in a 5 ms timed region as a several
+    # times slower step; the median of three drops such a pass without favouring the fastest (round 5 took the faster of two: a bias the
+    # other curves, single passes, do not have). All passes are listed in `passes_ms_per_step`.
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         for k in range(settle):
             frame(k)
         be.sync()
@@ -626,7 +709,7 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
         dt_i = time.perf_counter() - t0
         runs.append((dt_i,) + tuple(pipe.kernel_times(mark=True)))
     gc.enable()
-    dt, lm, ln = min(runs, key=lambda r: r[0])
+    dt, lm, ln = sorted(runs, key=lambda r: r[0])[1]
     # the same views standing still: three cameras of the timed stretch (first, middle, last), the teapot where it was, 40 + 40 frames each
     still_ms = []
     for k in (settle, settle + steps // 2, n - 1):
@@ -702,6 +785,31 @@ def extra_curves(args, be, noise0, noise5, base):
         rec = curve("primary_ao", args.width, args.height, sc)
         rec["scene"] = f"the castle + 4000 scattered props: {sc['info']['n_instances']} instances of {sc['info']['n_models']} models"
         return rec
+    def pipelined(depth):
+        """The headline's frames, `depth` of them in flight on streams, contexts and G-buffers of their own, every launch asking for all
+        workgroup slots (the reference's host keeps up to three frames in flight, rhyolite_bevy/src/lib.rs:58): the next frame's workgroups
+        become resident on the CUs the previous frame's last tiles have left, so a step no longer pays its launch's tail, staging and gap.
+        Per-kernel HIP-event times are inflated by the overlap: the roofline here is algorithmic bytes per STEP over ms_per_step."""
+        a = argparse.Namespace(**vars(args))
+        a.steps, a.warmup, a.in_flight_slots = max(args.extra_steps, 60), 0, "all"
+        lanes = []
+        for i in range(depth):
+            lane = be.open_lane(a, base.sc)
+            lane.pipe.set_noise(5, noise5)
+            lanes.append(lane)
+        c = measure_curve(be, None, a, lanes, "bands")
+        acct = account(c, False)
+        step_bytes = acct["bytes_primary"] + acct["bytes_ao"]
+        achieved = step_bytes / (c["ms_per_step"] * 1e-3) / 1e9
+        return {"value": round(c["mrays"], 2), "unit": "Mrays/s", "ms_per_step": round(c["ms_per_step"], 4), "steps": a.steps, "frames_in_flight": depth,
+                "in_flight_slots": c["in_flight_slots"], "rays_per_step": int(c["rays_per_step"]), "settle_steps": c["settle"],
+                "kernels_ms": {"k_primary_ao": round(c["ms"][0], 4)},
+                "roofline": {"bound": "hbm", "kernel": "k_primary_ao", "algorithmic_bytes_per_step": int(step_bytes), "achieved": round(achieved, 3), "unit": "GB/s",
+                             "peak": HBM_PEAK_GBPS, "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                             "note": "bytes per step / ms_per_step (whole-step rate): with launches overlapping, the HIP-event duration of one launch "
+                                     "(kernels_ms) includes the time it shares the device with its neighbours' and is not what a step costs"}}
+    run("pipelined", lambda: pipelined(2))
+    run("pipelined_3", lambda: pipelined(3))
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
     run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
     run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))
@@ -828,7 +936,8 @@ def run_rank(args, be, dist):
             return ((f"bands x{world}: one frame in {world} row bands of about equal measured cost, cut at rows {c['band_cuts']}" if c.get("band_cuts") else
                      f"bands x{world}: one frame in {world} row bands of {c['per_rows']} rows")
                     + (", identical hash + surfel pool on every GPU (all-reduce MAX of slot owners, all-gather of hash stamps, all-reduce SUM of "
-                       "winning surfels, deterministic apply), surfel pass replicated" if gi_mode and world > 1 else "")
+                       "winning surfels, deterministic apply), " + ("surfel TRACE sharded by pool slots with an all-gather of its records, ordering + apply replicated"
+                                                                    if c.get("comm") == "native" else "surfel pass replicated") if gi_mode and world > 1 else "")
                     + (", RCCL gather of the (equal-size, padded) bands to rank " + root_txt if world > 1 else ""))
         return (f"spp x{world}: one {W}x{H} sample per GPU, " +
                 ("RCCL all-to-all of the RGBA16F frames by row slices (rank j assembles slice j of every sample)" if c["slices"] or world == 1
@@ -846,7 +955,9 @@ def run_rank(args, be, dist):
                    "frame": [W, H], "spp_per_step": 1 if bands_main else world, "parallelism": parallelism(main_curve),
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": sc["n_bricks"], "scene_build_s": round(sc["t_load"], 3), "untimed_steps_before_timing": main_curve["settle"],
-                   "frames_in_flight": main_curve["frames_in_flight"], "denoise": bool(main_curve.get("denoise")),
+                   "frames_in_flight": main_curve["frames_in_flight"], "in_flight_slots": main_curve.get("in_flight_slots"), "denoise": bool(main_curve.get("denoise")),
+                   **({"emulated_band": main_curve["emulated_band"]} if main_curve.get("emulated_band") else {}),
+                   **({"band_steps_ms": main_curve["band_steps_ms"], "band_balance": main_curve["band_balance"]} if main_curve.get("band_steps_ms") else {}),
                    "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(main_curve["rays_per_step"])},
         "ranks_seen": main_curve["ranks_seen"],
         "curves": {c["scaling"]: {"shard": c["shard"], "value": round(c["mrays"], 2), "ms_per_step": round(c["ms_per_step"], 4),

@@ -29,6 +29,10 @@ PASS_DENOISE = 1 << 5
 PASS_COUNT_STATS = 1 << 16
 PASS_GI_ORDERED = 1 << 17
 PASS_GI_SHARDED = 1 << 18
+GI_PATH_AUTO, GI_PATH_PACKETS, GI_PATH_STREAMS = 0, 1, 2
+SIDE_STREAM_AUTO, SIDE_STREAM_OFF = 0, 1
+IN_FLIGHT_SHARE, IN_FLIGHT_ALL = 0, 1
+RESERVE_AUTO = 0xFFFFFFFF
 CONTEXT_TIMING = 1
 CONTEXT_TIMING_SPARSE = 2
 
@@ -76,7 +80,7 @@ class Sky(C.Structure):
 
 class FrameParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("passes", C.c_uint32), ("frame_index", C.c_uint32),
-                ("rand", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
+                ("rand", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("surfel_rank", C.c_uint32), ("surfel_world", C.c_uint32)]
 
 
 class ToneMapParams(C.Structure):
@@ -87,6 +91,11 @@ class ToneMapParams(C.Structure):
 class DenoiseParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_accumulated_frames", C.c_uint32), ("disocclusion_threshold", C.c_float),
                 ("antilag_sigma_scale", C.c_float), ("antilag_power", C.c_float), ("max_blur_radius", C.c_float)]
+
+
+class PipelineConfig(C.Structure):  # DustHipPipelineConfig
+    _fields_ = [("struct_size", C.c_uint32), ("reserve_blocks", C.c_uint32), ("gi_path", C.c_uint32), ("side_stream", C.c_uint32),
+                ("side_share", C.c_uint32), ("frames_in_flight", C.c_uint32), ("in_flight_slots", C.c_uint32)]
 
 
 class GiExchange(C.Structure):
@@ -177,6 +186,8 @@ SYMBOLS = {
     "dust_hip_pipeline_exposure": (C.c_int, [_P, _f32p, _f32p]),
     "dust_hip_pipeline_clear": (C.c_int, [_P]),
     "dust_hip_pipeline_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
+    "dust_hip_pipeline_configure": (C.c_int, [_P, C.POINTER(PipelineConfig)]),
+    "dust_hip_pipeline_get_config": (C.c_int, [_P, C.POINTER(PipelineConfig)]),
     "dust_hip_pipeline_set_denoiser": (C.c_int, [_P, C.POINTER(DenoiseParams)]),
     "dust_hip_pipeline_restart_denoiser": (C.c_int, [_P]),
     "dust_hip_device_eval": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32]),
@@ -191,6 +202,7 @@ SYMBOLS = {
     "dust_hip_comm_wait": (C.c_int, [_P, C.c_uint64]),
     "dust_hip_comm_sync": (C.c_int, [_P]),
     "dust_hip_gi_exchange_run": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "dust_hip_gi_surfel_exchange_run": (C.c_int, [_P, _P, C.c_uint32]),
 }
 
 _lib = None

@@ -384,6 +384,23 @@ def sky_struct(sky):
     return s
 
 
+def _config_from_environment():
+    """the production knobs of DustHipPipelineConfig as A/B scripts and the stress drivers spell them (read HERE, not by the library)"""
+    import os
+    e, cfg = os.environ, {}
+    if "DUST_HIP_RAY_STREAM" in e:
+        cfg["gi_path"] = "streams"
+    elif "DUST_HIP_PACKET_GI" in e:
+        cfg["gi_path"] = "packets"
+    if "DUST_HIP_NO_SIDE_STREAM" in e:
+        cfg["side_stream"] = "off"
+    if e.get("DUST_HIP_SIDE_SHARE") and int(e["DUST_HIP_SIDE_SHARE"]) > 0:   # (0: calibrated, the default)
+        cfg["side_share"] = min(90, max(5, int(e["DUST_HIP_SIDE_SHARE"])))
+    if e.get("DUST_HIP_RESERVE_BLOCKS"):
+        cfg["reserve_blocks"] = int(e["DUST_HIP_RESERVE_BLOCKS"])
+    return cfg
+
+
 class StandardPipeline:
     """StandardPipeline (crates/render/src/pipeline/standard.rs:51-60, :222-240) + its GBuffer (:881-917)."""
 
@@ -392,12 +409,45 @@ class StandardPipeline:
     FINAL_GATHER_RAYTYPE = 2
     SURFEL_RAYTYPE = 3
 
-    def __init__(self, ctx, width, height):
+    def __init__(self, ctx, width, height, **config):
+        """config: DustHipPipelineConfig fields (see configure). A/B runs and the stress drivers may also name them in the environment
+        of THIS shim -- DUST_HIP_RAY_STREAM / DUST_HIP_PACKET_GI (gi_path), DUST_HIP_NO_SIDE_STREAM, DUST_HIP_SIDE_SHARE,
+        DUST_HIP_RESERVE_BLOCKS --: the library itself reads no production knob from the environment."""
         self._ctx = ctx
         self._lib = ctx._lib
         self.width, self.height = width, height
         self._h = C.c_void_p()
         L.check(self._lib.dust_hip_pipeline_create(ctx._h, width, height, C.byref(self._h)))
+        cfg = _config_from_environment()
+        cfg.update(config)
+        if cfg:
+            self.configure(**cfg)
+
+    def configure(self, reserve_blocks=None, gi_path=None, side_stream=None, side_share=None, frames_in_flight=None, in_flight_slots=None):
+        """dust_hip_pipeline_configure: the fields given replace the pipeline's current ones.
+        gi_path: "auto" | "packets" | "streams"; side_stream: "auto" | "off"; in_flight_slots: "share" | "all"; reserve_blocks: int or "auto"."""
+        c = self.get_config(raw=True)
+        if reserve_blocks is not None:
+            c.reserve_blocks = L.RESERVE_AUTO if reserve_blocks == "auto" else int(reserve_blocks)
+        if gi_path is not None:
+            c.gi_path = {"auto": L.GI_PATH_AUTO, "packets": L.GI_PATH_PACKETS, "streams": L.GI_PATH_STREAMS}.get(gi_path, gi_path)
+        if side_stream is not None:
+            c.side_stream = {"auto": L.SIDE_STREAM_AUTO, "off": L.SIDE_STREAM_OFF}.get(side_stream, side_stream)
+        if side_share is not None:
+            c.side_share = int(side_share)
+        if in_flight_slots is not None:
+            c.in_flight_slots = {"share": L.IN_FLIGHT_SHARE, "all": L.IN_FLIGHT_ALL}.get(in_flight_slots, in_flight_slots)
+        c.frames_in_flight = int(frames_in_flight) if frames_in_flight is not None else 0
+        L.check(self._lib.dust_hip_pipeline_configure(self._h, C.byref(c)))
+
+    def get_config(self, raw=False):
+        c = L.PipelineConfig(C.sizeof(L.PipelineConfig))
+        L.check(self._lib.dust_hip_pipeline_get_config(self._h, C.byref(c)))
+        if raw:
+            return c
+        return {"reserve_blocks": "auto" if c.reserve_blocks == L.RESERVE_AUTO else c.reserve_blocks,
+                "gi_path": ("auto", "packets", "streams")[c.gi_path], "side_stream": ("auto", "off")[c.side_stream], "side_share": c.side_share,
+                "frames_in_flight": c.frames_in_flight, "in_flight_slots": ("share", "all")[c.in_flight_slots]}
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -409,10 +459,11 @@ class StandardPipeline:
         layers = t.size // (128 * 128 * (1 if texture == 0 else 4))
         L.check(self._lib.dust_hip_pipeline_set_noise(self._h, texture, _ptr(t), layers))
 
-    def render(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
-        """sky: 56 floats, or a DustHipSky made once with api.sky_struct() (a frame loop: the conversion is most of this call's host time)"""
+    def render(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0), surfel_shard=(0, 0)):
+        """sky: 56 floats, or a DustHipSky made once with api.sky_struct() (a frame loop: the conversion is most of this call's host time).
+        surfel_shard: (rank, world) -- with PASS_SURFEL | PASS_GI_SHARDED the pass only traces rank's share of the ordered pool (Comm.gi_surfel_exchange completes it)"""
         s = sky if isinstance(sky, L.Sky) else sky_struct(sky)
-        fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1])
+        fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1], surfel_shard[0], surfel_shard[1])
         L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
 
     def pass_stats(self, index):
@@ -507,6 +558,11 @@ class StandardPipeline:
     def gi_import(self, row_begin, row_end, frame_index):
         L.check(self._lib.dust_hip_gi_import(self._h, row_begin, row_end, frame_index))
 
+    def gi_surfel_finish(self, frame_index):
+        """completes a sharded surfel trace WITHOUT an exchange (dust_hip_gi_surfel_exchange_run with no communicator): a world of one, or
+        one emulated rank of N -- the other ranks' records are whatever the staging arrays hold"""
+        L.check(self._lib.dust_hip_gi_surfel_exchange_run(self._h, None, frame_index))
+
     def read_gi(self):
         """(hash entries as uint32[capacity+2, 3], surfel pool as structured array)"""
         cap, pool = getattr(self, "_gi", None) or (32 * 1024 * 1024, 720 * 480)  # the defaults of an implicit configuration
@@ -564,16 +620,23 @@ class Comm:
         L.check(self._lib.dust_hip_comm_info(self._h, C.byref(r), C.byref(w), C.byref(l)))
         return r.value, w.value, bool(l.value)
 
+    def _cuts(self, cuts):
+        """world + 1 row indices as the C array the library reads cuts[0..world] of (a shorter list would be an out-of-bounds host read)"""
+        world = self.info()[1]
+        if len(cuts) != world + 1:
+            raise ValueError(f"band cuts: {len(cuts)} entries for a communicator of {world} ranks (want world + 1)")
+        return cuts if isinstance(cuts, C.Array) else (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+
     def gather_bands(self, pipe, plane, cuts, root=0, dst_ptr=None, dst_bytes=0):
         """-> the gather's ticket (wait(ticket) before its source target or destination is used again)"""
-        c = cuts if isinstance(cuts, C.Array) else (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        c = self._cuts(cuts)
         t = C.c_uint64()
         L.check(self._lib.dust_hip_gather_bands(pipe._h, self._h, plane, c, root, C.c_void_p(dst_ptr) if dst_ptr else None, dst_bytes, C.byref(t)))
         return t.value
 
     def gather_planes(self, pipe, planes, cuts, root=0):
         """several planes (an iterable of DUST_PLANE_* indices) in one collective, each into the root pipeline's own plane -> ticket"""
-        c = cuts if isinstance(cuts, C.Array) else (C.c_uint32 * len(cuts))(*[int(v) for v in cuts])
+        c = self._cuts(cuts)
         mask = 0
         for pl in planes:
             mask |= 1 << int(pl)
@@ -583,6 +646,10 @@ class Comm:
 
     def gi_exchange(self, pipe, row_begin, row_end, band_rows, frame_index):
         L.check(self._lib.dust_hip_gi_exchange_run(pipe._h, self._h, row_begin, row_end, band_rows, frame_index))
+
+    def gi_surfel_exchange(self, pipe, frame_index):
+        """completes a surfel pass whose trace was sharded (render(..., surfel_shard=(rank, world))): all-gather of the records, stamps, ordered apply"""
+        L.check(self._lib.dust_hip_gi_surfel_exchange_run(pipe._h, self._h, frame_index))
 
     def wait(self, ticket=0):
         L.check(self._lib.dust_hip_comm_wait(self._h, ticket))

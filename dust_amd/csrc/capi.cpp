@@ -28,9 +28,8 @@ namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t);
+hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
 hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t);
-uint32_t final_gather_pool_group();
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
 hipError_t launch_gi_export(const FrameArgs& a, hipStream_t);
 hipError_t launch_gi_import(const FrameArgs& a, hipStream_t);
@@ -40,6 +39,7 @@ hipError_t radix_sort_pairs(void* scratch, uint32_t* keys_a, uint32_t* vals_a, u
                             uint32_t key_bits, bool* in_b, hipStream_t s);
 hipError_t launch_surfel_trace(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t);
+hipError_t launch_surfel_unstage(const FrameArgs& a, hipStream_t);
 hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_rays(const FrameArgs& a, hipStream_t);
 hipError_t launch_surfel_shade(const FrameArgs& a, hipStream_t);
@@ -367,82 +367,74 @@ static void release(const DustHipScene* cs) {
   release(c);
 }
 
-// DUST_HIP_* diagnostic switches, read ONCE when a pipeline is created (not per frame: a frame is ~0.3 ms of GPU time)
+// What decides which kernels a pipeline's frames run. Two kinds, kept apart:
+//  * PRODUCTION knobs arrive through the C ABI (DustHipPipelineConfig, dust_hip_pipeline_configure): slots left free for other queues'
+//    kernels, which form the GI passes take, the surfel pass's second stream and its share, how several frames in flight split the slots;
+//  * DIAGNOSTIC switches (ablations, A/B runs, the stress drivers' random draws) come from the environment, read ONCE when a pipeline
+//    is created through the one lookup below. None of them is needed for any production frame; DESIGN.md section 9 lists them.
+static const char* diag_env(const char* name) {   // "NO_FUSE" -> $DUST_HIP_NO_FUSE (the library's only environment lookup besides DUST_HIP_DEBUG-class reads here)
+  char full[64];
+  std::snprintf(full, sizeof full, "DUST_HIP_%s", name);
+  return std::getenv(full);
+}
 struct Tuning {
-  uint32_t debug = 0;           // DUST_HIP_DEBUG ablation bits (FrameArgs::debug)
-  uint32_t block = 512;         // DUST_HIP_BLOCK: threads per workgroup, whole wavefronts, <= the kernels' launch bounds
-  uint32_t blocks_per_cu = 2;   // DUST_HIP_BLOCKS_PER_CU
-  uint32_t reserve_blocks = 0;  // DUST_HIP_RESERVE_BLOCKS: workgroup slots left free for another queue's kernels
-  bool no_fuse = false;         // DUST_HIP_NO_FUSE: primary and AO passes as two launches (the reference's shape)
-  bool no_gather_order = false; // DUST_HIP_NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
-  bool no_surfel_sort = false;  // DUST_HIP_NO_SURFEL_SORT: trace the surfel pool in pool order
-  bool no_tile_order = false;   // DUST_HIP_NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
-  bool equal_bands = false;     // DUST_HIP_EQUAL_BANDS: bands of equal tile count (round 3) instead of equal measured cost
-  bool no_lds_boxes = false;    // DUST_HIP_NO_LDS_BOXES: the packet cull reads the instance boxes from memory
-  bool no_side_stream = false;  // DUST_HIP_NO_SIDE_STREAM: the surfel pass on the main stream, in place
-  uint32_t side_share = 0;      // DUST_HIP_SIDE_SHARE: percent of the workgroup slots the surfel pass takes on the second stream (0: by ray counts)
-  uint32_t static_rounds = 0xFFFFFFFFu;  // DUST_HIP_STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
-  uint32_t still_refresh_max = 64;  // DUST_HIP_STILL_REFRESH_MAX: cap of the launches between two re-measurements of a view that stands still
-  uint32_t cost_keep_shift = 1; // DUST_HIP_COST_KEEP_SHIFT k: a tile's cost estimate moves 1 / 2^k of the way to each new measurement (0: takes it as it is)
-  bool gather_join_first = false;  // DUST_HIP_GATHER_JOIN_FIRST: split gather, but the trace too waits for the surfel pass (experiment)
-  bool gather_split = false;    // DUST_HIP_GATHER_SPLIT: the final gather as a trace kernel + a shading pass over hit records (measured slower, see render_frame)
-  bool wide_fused = true;       // DUST_HIP_NO_WIDE_FUSED: the fused kernel always as two 512-thread workgroups per CU
-  bool dilate_still = false;    // DUST_HIP_DILATE_STILL: ... of a still view as well (experiment)
-  bool dilate = true;           // DUST_HIP_NO_DILATE: a moving view's order from the tiles' own costs only
-  bool force_moving = false;    // DUST_HIP_FORCE_MOVING: treat every view as a moving one (diagnostic)
-  uint32_t cuts_reuse = 4;      // DUST_HIP_CUTS_REUSE: re-orderings of a moving view that keep one set of band cuts
-  uint32_t moving_refresh = 4;  // DUST_HIP_MOVING_REFRESH: launches between two re-orderings of a view that moves (order_tiles)
-  uint32_t side_prio = 3;       // DUST_HIP_SIDE_PRIO: issue priority floor of the surfel pass on the second stream
-  uint32_t stream_refill = 16;  // DUST_HIP_STREAM_REFILL, DUST_HIP_STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
+  // ---- production (DustHipPipelineConfig)
+  uint32_t reserve_blocks = 0xFFFFFFFFu;  // workgroup slots left free for another queue's kernels; 0xFFFFFFFF = auto (32 once the pipeline has taken part in a collective of world > 1)
+  uint32_t gi_path = DUST_GI_PATH_AUTO;   // packets / ray streams (auto: packets, except the final gather of a scene with a 4096^3 tree)
+  bool no_side_stream = false;            // the surfel pass on the main stream, in place
+  uint32_t side_share = 0;                // percent of the workgroup slots the surfel pass takes on the second stream (0: calibrated)
+  uint32_t in_flight_slots = DUST_IN_FLIGHT_SHARE;  // frames in flight: every launch on 1/n of the slots, or every launch asking for all of them
+  // ---- diagnostics (environment)
+  uint32_t debug = 0;           // DEBUG ablation bits (FrameArgs::debug)
+  uint32_t block = 512;         // BLOCK: threads per workgroup, whole wavefronts, <= the kernels' launch bounds
+  uint32_t blocks_per_cu = 2;   // BLOCKS_PER_CU
+  bool no_fuse = false;         // NO_FUSE: primary and AO passes as two launches (the reference's shape)
+  bool no_gather_order = false; // NO_GATHER_ORDER: plain 8x8 pixel packets in the final gather
+  bool no_surfel_sort = false;  // NO_SURFEL_SORT: trace the surfel pool in pool order
+  bool no_tile_order = false;   // NO_TILE_ORDER: hand tiles out in screen order, not most expensive first
+  bool equal_bands = false;     // EQUAL_BANDS: bands of equal tile count (round 3) instead of equal measured cost
+  bool no_lds_boxes = false;    // NO_LDS_BOXES: the packet cull reads the instance boxes from memory
+  uint32_t static_rounds = 0xFFFFFFFFu;  // STATIC_ROUNDS: dealt rounds of the hand-out (default: one, kernels.hip with_schedule)
+  uint32_t still_refresh_max = 64;  // cap of the launches between two re-measurements of a view that stands still
+  uint32_t cost_keep_shift = 1; // a tile's cost estimate moves 1 / 2^k of the way to each new measurement
+  bool wide_fused = true;       // NO_WIDE_FUSED: the fused kernel always as two 512-thread workgroups per CU
+  bool dilate = true;           // NO_DILATE: a moving view's order from the tiles' own costs only
+  bool force_moving = false;    // FORCE_MOVING: treat every view as a moving one
+  uint32_t cuts_reuse = 4;      // re-orderings of a moving view that keep one set of band cuts
+  uint32_t moving_refresh = 4;  // launches between two re-orderings of a view that moves (order_tiles)
+  uint32_t side_prio = 3;       // issue priority floor of the surfel pass on the second stream
+  uint32_t stream_refill = 16;  // STREAM_REFILL, STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
   uint32_t stream_top_iters = 8;
-  bool no_stream_lds = false;   // DUST_HIP_NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
-  bool packet_only = false;     // DUST_HIP_PACKET_GI: the packet kernels even where the streams are the default (the final gather of a scene with a 4096^3 tree)
-  bool packet_gi = true;        // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace); DUST_HIP_RAY_STREAM: as ray streams instead --
-                                // binned per ray over the top-level grid, then one ray per lane with lanes refilled (gi.hip): built and measured in round 5, slower on
-                                // every scene but the 4096^3 tree's gather (docs/EXPERIMENTS.md)
-  bool ray_lanes = false;       // DUST_HIP_RAY_LANES: gather rays as refilled ray lanes (k_final_gather_pool) instead of a packet at a time:
-                                // the wavefront compaction north_star names, built and measured in round 3 -- slower at this problem size, see DESIGN Appendix B
+  bool no_stream_lds = false;   // NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
+  bool packet_gi() const { return gi_path != DUST_GI_PATH_STREAMS; }    // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace)
+  bool packet_only() const { return gi_path == DUST_GI_PATH_PACKETS; }  // ... even where the streams are the default
   static uint32_t num(const char* name, uint32_t dflt) {
-    const char* e = std::getenv(name);
+    const char* e = diag_env(name);
     return e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
   }
+  static bool flag(const char* name) { return diag_env(name) != nullptr; }
   static Tuning from_environment() {
     Tuning t;
-    t.debug = num("DUST_HIP_DEBUG", 0);
+    t.debug = num("DEBUG", 0);
 #ifndef DUST_MAX_BLOCK
 #define DUST_MAX_BLOCK 512u   // the kernels' launch bounds (an experiment build may raise both)
 #endif
-    t.block = std::min(DUST_MAX_BLOCK, std::max(128u, num("DUST_HIP_BLOCK", 512) & ~127u));  // <= the kernels' launch bounds (512); an even number of
+    t.block = std::min(DUST_MAX_BLOCK, std::max(128u, num("BLOCK", 512) & ~127u));  // <= the kernels' launch bounds (512); an even number of
                                                                                     // waves keeps the LDS areas behind the per-wave lists 16-byte aligned
-    t.blocks_per_cu = std::max(1u, num("DUST_HIP_BLOCKS_PER_CU", 2));
-    t.reserve_blocks = num("DUST_HIP_RESERVE_BLOCKS", 0) & ~7u;  // whole rounds over the 8 XCDs
-    t.no_fuse = std::getenv("DUST_HIP_NO_FUSE") != nullptr;
-    t.no_gather_order = std::getenv("DUST_HIP_NO_GATHER_ORDER") != nullptr;
-    t.no_surfel_sort = std::getenv("DUST_HIP_NO_SURFEL_SORT") != nullptr;
-    t.no_tile_order = std::getenv("DUST_HIP_NO_TILE_ORDER") != nullptr;
-    t.equal_bands = std::getenv("DUST_HIP_EQUAL_BANDS") != nullptr;
-    t.no_lds_boxes = std::getenv("DUST_HIP_NO_LDS_BOXES") != nullptr;
-    t.ray_lanes = std::getenv("DUST_HIP_RAY_LANES") != nullptr;
-    t.no_stream_lds = std::getenv("DUST_HIP_NO_STREAM_LDS") != nullptr;
-    t.stream_refill = std::min(64u, std::max(1u, num("DUST_HIP_STREAM_REFILL", 16)));
-    t.stream_top_iters = std::max(1u, num("DUST_HIP_STREAM_TOP_ITERS", 8));
-    t.packet_gi = std::getenv("DUST_HIP_RAY_STREAM") == nullptr;
-    t.packet_only = std::getenv("DUST_HIP_PACKET_GI") != nullptr;
-    t.no_side_stream = std::getenv("DUST_HIP_NO_SIDE_STREAM") != nullptr;
-    t.side_share = num("DUST_HIP_SIDE_SHARE", 0);
-    t.static_rounds = num("DUST_HIP_STATIC_ROUNDS", 0xFFFFFFFFu);
-    t.side_prio = std::min(3u, num("DUST_HIP_SIDE_PRIO", 3));
-    t.moving_refresh = std::max(1u, num("DUST_HIP_MOVING_REFRESH", 4));
-    t.cost_keep_shift = std::min(4u, num("DUST_HIP_COST_KEEP_SHIFT", 1));
-    t.dilate = std::getenv("DUST_HIP_NO_DILATE") == nullptr;
-    t.gather_join_first = std::getenv("DUST_HIP_GATHER_JOIN_FIRST") != nullptr;
-    t.gather_split = std::getenv("DUST_HIP_GATHER_SPLIT") != nullptr;
-    t.wide_fused = std::getenv("DUST_HIP_NO_WIDE_FUSED") == nullptr && std::getenv("DUST_HIP_BLOCK") == nullptr;
-    t.dilate_still = std::getenv("DUST_HIP_DILATE_STILL") != nullptr;
-    t.force_moving = std::getenv("DUST_HIP_FORCE_MOVING") != nullptr;
-    t.cuts_reuse = std::max(1u, num("DUST_HIP_CUTS_REUSE", 4));
-    t.still_refresh_max = std::max(1u, num("DUST_HIP_STILL_REFRESH_MAX", 64));
-    if (t.side_share) t.side_share = std::min(90u, std::max(5u, t.side_share));
+    t.blocks_per_cu = std::max(1u, num("BLOCKS_PER_CU", 2));
+    t.no_fuse = flag("NO_FUSE");
+    t.no_gather_order = flag("NO_GATHER_ORDER");
+    t.no_surfel_sort = flag("NO_SURFEL_SORT");
+    t.no_tile_order = flag("NO_TILE_ORDER");
+    t.equal_bands = flag("EQUAL_BANDS");
+    t.no_lds_boxes = flag("NO_LDS_BOXES");
+    t.no_stream_lds = flag("NO_STREAM_LDS");
+    t.stream_refill = std::min(64u, std::max(1u, num("STREAM_REFILL", 16)));
+    t.stream_top_iters = std::max(1u, num("STREAM_TOP_ITERS", 8));
+    t.static_rounds = num("STATIC_ROUNDS", 0xFFFFFFFFu);
+    t.dilate = !flag("NO_DILATE");
+    t.wide_fused = !flag("NO_WIDE_FUSED") && !flag("BLOCK");
+    t.force_moving = flag("FORCE_MOVING");
     return t;
   }
 };
@@ -451,6 +443,7 @@ struct DustHipPipeline {
   DustHipContext* ctx = nullptr;  // retained
   Tuning tune;
   uint32_t frames_in_flight = 1;  // dust_hip_pipeline_set_frames_in_flight
+  bool in_collective = false;     // the pipeline has taken part in a collective of a communicator with world > 1 (comm.hip): DUST_RESERVE_AUTO then leaves 32 slots free
   uint32_t width = 0, height = 0;
   DeviceBuffer planes[DUST_PLANE_COUNT];
   void* bound[DUST_PLANE_COUNT] = {};  // caller-owned storage a plane was redirected to (dust_hip_pipeline_bind_plane), or null
@@ -483,6 +476,10 @@ struct DustHipPipeline {
   DeviceBuffer gi_rays_fg, gi_rays_sf, gi_hits_sf, gi_groups_fg, gi_groups_sf, gi_unbinned;
   DeviceBuffer gi_order, gi_order_count;  // final gather: live pixels of each 64x64 tile grouped by ray direction bin
   DeviceBuffer gi_touched, gi_merged;  // multi-GPU exchange buffers (dust_hip_pipeline_gi_exchange)
+  // sharded surfel trace (DustHipFrameParams::surfel_world >= 1): the records in slot order (made on first use), and what the pending
+  // pass's second half (dust_hip_gi_surfel_exchange_run) needs of its first
+  DeviceBuffer gi_stage_req, gi_stage_repl, gi_stage_sun;
+  struct { bool pending = false; const uint32_t* perm = nullptr; uint32_t rank = 0, world = 0, slots_per_rank = 0; } sf_shard;
   uint32_t gi_touched_rows = 0;
   uint32_t gi_capacity = 0, gi_pool_size = 0;
   uint32_t noise0_layers = 0, noise5_layers = 0;
@@ -872,7 +869,7 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_lds = (prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024) - 256;  // dynamic LDS a launch may ask for: the kernels hold 128 bytes of static LDS (earned priorities)
-  if (const char* env = std::getenv("DUST_HIP_LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));
+  if (const char* env = diag_env("LDS_ROOT_BYTES")) c->lds_root_bytes = uint32_t(std::strtoul(env, nullptr, 10));  // (diagnostic: DustHipConfig::lds_root_bytes is the knob)
   // what a 512-thread workgroup needs besides the staged roots: 8 candidate lists, the tile queue, and the static
   // buckets of the profiling / debug builds (kernels.hip lds_bytes(), configure_kernels())
   const size_t reserve = size_t(8) * (dust::kMaxCand * 8 + 8) + 16 + 4096;
@@ -881,7 +878,7 @@ DustStatus dust_hip_context_create(const DustHipConfig* cfg, DustHipContext** ou
   HIP_TRY(dust::configure_kernels(c->max_lds));
   {  // (a context without the word works as before: commits that find the host a ring ahead wait for the whole stream)
     void* w = nullptr;
-    if (!std::getenv("DUST_HIP_NO_START_WORD") && hipHostMalloc(&w, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && w) {
+    if (!diag_env("NO_START_WORD") && hipHostMalloc(&w, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess && w) {
       std::memset(w, 0, 64);
       c->started = static_cast<volatile uint32_t*>(w);
     } else (void)hipGetLastError();
@@ -1288,15 +1285,17 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
     g.lo[a] = float(double(s->world_min[a]) - 2.0 * margin);
     ext[a] = std::max(double(s->world_max[a]) + 2.0 * margin - double(g.lo[a]), 1e-3 * big + 1.0);
   }
-  const char* density_env = std::getenv("DUST_HIP_GRID_DENSITY");  // (per commit: ~100 ns, and tests vary it)
+  const char* density_env = diag_env("GRID_DENSITY");  // (per commit: ~100 ns, and tests vary it)
   const double density0 = density_env ? std::max(0.001, std::atof(density_env)) : 12.0;
   ranges.resize(n * 2);
   std::vector<uint32_t> count;
+  uint32_t last_dim[3] = {0, 0, 0}, halvings = 0;
+  bool force_one = false;
   for (double density = density0;; density *= 0.5) {
     const double target = std::min(262144.0, std::max(1.0, density * double(std::max<size_t>(n, 1))));
     const double edge = std::cbrt(ext[0] * ext[1] * ext[2] / target);
     for (int a = 0; a < 3; ++a) {
-      g.dim[a] = uint32_t(std::min(256.0, std::max(1.0, std::floor(ext[a] / edge + 0.5))));
+      g.dim[a] = force_one ? 1u : uint32_t(std::min(256.0, std::max(1.0, std::floor(ext[a] / edge + 0.5))));
       g.cell[a] = float(ext[a] / double(g.dim[a]));
       g.inv_cell[a] = float(double(g.dim[a]) / ext[a]);
       g.hi[a] = float(double(g.lo[a]) + ext[a]);
@@ -1323,6 +1322,13 @@ void build_grid(DustHipScene* s, const std::vector<float>& boxes, std::vector<ui
     //  ONE cell cannot be listed at any resolution that helps: the grid is then marked unusable and the single-ray paths are not taken)
     s->grid_valid = most <= dust::kGridMaxCellItems;
     if (total < (size_t(1) << dust::kGridItemBits) || n_cells == 1) break;
+    // (a fuse: an elongated scene whose rounded dims stop shrinking -- density x n <= 1 clamps the target to one cell, which ext / cbrt(V)
+    //  never reaches for aspects above ~2 -- or 40 halvings: ONE cell then; should even that list 2^20 items or more -- 2^20 boxes do not
+    //  exist, 65 535 instances at most --, the grid is marked unusable like a cell of more than 4095)
+    const bool stuck = g.dim[0] == last_dim[0] && g.dim[1] == last_dim[1] && g.dim[2] == last_dim[2];
+    for (int a = 0; a < 3; ++a) last_dim[a] = g.dim[a];
+    if (force_one) { s->grid_valid = false; break; }
+    if (stuck || ++halvings >= 40) force_one = true;
   }
   const size_t n_cells = count.size();
   s->grid_cells.assign(n_cells, 0u);
@@ -1470,7 +1476,7 @@ DustStatus dust_hip_scene_commit(DustHipScene* s) {
       std::memcpy(img + s->layout.grid_cells, s->grid_cells.data(), s->grid_cells.size() * sizeof(uint32_t));
       // the packet cull's 64-wide hierarchy (kernels: cull_instances): slots along a Morton curve through the boxes' centres -- ordered
       // by structural commits, refitted by every commit --, a box per 64 consecutive slots
-      s->n_groups = n > dust::kFlatCullMax && !std::getenv("DUST_HIP_FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
+      s->n_groups = n > dust::kFlatCullMax && !diag_env("FLAT_CULL") ? uint32_t((n + 63) / 64) : 0u;  // (DUST_HIP_FLAT_CULL: every box for every packet, for A/B runs)
       if (s->n_groups) {
         if (full || s->slot_order.size() != n) {
           order_slots(s);
@@ -1653,7 +1659,7 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     // (the cost-balanced cuts drift slowly: a view that moves keeps them for kCutsReuse re-orderings -- the scan for them is the longer half of the sorter)
     const bool reuse = h.ordered && h.cuts_age + 1 < p->tune.cuts_reuse && h.moving;
     HIP_TRY(dust::launch_cost_blend(static_cast<const uint32_t*>(h.cost.p), static_cast<uint32_t*>(h.smooth.p), total, p->tune.cost_keep_shift, st));
-    const bool spread = (h.moving || p->tune.dilate_still) && p->tune.dilate && a.tiles_y > 1u;
+    const bool spread = h.moving && p->tune.dilate && a.tiles_y > 1u;
     if (spread) HIP_TRY(dust::launch_cost_dilate(static_cast<const uint32_t*>(h.smooth.p), static_cast<uint32_t*>(h.spread.p), a.tiles_x, a.tiles_y, st));
     HIP_TRY(dust::launch_tile_order(static_cast<const uint32_t*>(spread ? h.spread.p : h.smooth.p), static_cast<uint32_t*>(h.order.p),
                                     p->tune.equal_bands ? nullptr : static_cast<uint32_t*>(h.cuts.p), reuse, total, per_band, st));
@@ -1678,7 +1684,8 @@ static DustStatus order_tiles(DustHipPipeline* p, uint32_t kind, dust::FrameArgs
     h.recorded = true; h.measured = true;
     if (still) h.refresh = std::min(kOrderRefreshMax, h.refresh * 2u);
   }
-  h.moving = !still && h.view != p->view_key && h.measured && h.view != 0;  // (the first launch of a view that stands still is not a moving one)
+  h.moving = !still && h.measured && h.view != 0 && (h.view != p->view_key || p->tune.force_moving);  // (the first launch of a view that stands still is not a moving one;
+                                                                                                     //  DUST_HIP_FORCE_MOVING: a still view on a moving view's schedule)
   h.view = p->view_key;
   return DUST_OK;
 }
@@ -1708,8 +1715,54 @@ static void stream_args(DustHipPipeline* p, int kind, dust::FrameArgs& a, float 
   a.tile_order = nullptr; a.tile_cost = nullptr; a.band_cuts = nullptr;  // (the stream hands out rays, not tiles)
   a.tiles_x = a.tiles_y = 1;
 }
+// The ray streams' buffers (gi.hip), made when a frame first takes a stream path -- the packet kernels, the default everywhere but the
+// final gather of a scene with a 4096^3 tree, never read them (130 MB at 1080p, 530 MB at 4K): a ray per pixel / two per surfel at most,
+// the hit records, the group counters. Waits for the streams once (an allocation is not stream-ordered).
+static DustStatus ensure_stream_buffers(DustHipPipeline* p, bool gather, bool surfel) {
+  const bool need_fg = gather && !p->gi_rays_fg.p, need_sf = surfel && !p->gi_rays_sf.p;
+  if (!need_fg && !need_sf && p->gi_unbinned.p) return DUST_OK;
+  HIP_TRY(sync_stream(p->ctx));
+  if (!p->gi_unbinned.p) {
+    HIP_TRY(p->gi_unbinned.alloc(4 * 4));
+    HIP_TRY(hipMemsetAsync(p->gi_unbinned.p, 0, 4 * 4, p->ctx->stream));
+  }
+  if (need_fg) {
+    const size_t tiles = size_t((p->width + 15) / 16) * ((p->height + 15) / 16);
+    HIP_TRY(p->gi_rays_fg.alloc(tiles * 256 * sizeof(dust::DevRay)));
+    HIP_TRY(p->gi_groups_fg.alloc(tiles * 4));
+    HIP_TRY(p->gi_fg_hits.alloc(size_t(p->width) * p->height * sizeof(dust::DevGatherHit)));
+  }
+  if (need_sf) {
+    const size_t runs = (size_t(p->gi_pool_size) + 255) / 256;
+    HIP_TRY(p->gi_rays_sf.alloc(runs * 512 * sizeof(dust::DevRay)));
+    HIP_TRY(p->gi_groups_sf.alloc(runs * 4));
+    HIP_TRY(p->gi_hits_sf.alloc(size_t(p->gi_pool_size) * 2 * sizeof(dust::DevGatherHit)));
+  }
+  return DUST_OK;
+}
 // The surfel pass of one frame (surfel.rgen + the spatial hash update) on stream `st`, on at most `resident` workgroup slots.
-static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, uint32_t passes, bool count, hipStream_t st, uint32_t resident) {
+// the recorded hash inserts, applied in surfel-index order (DUST_PASS_GI_ORDERED): in parallel over independent probe-window clusters (the serial
+// one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
+static DustStatus apply_ordered(DustHipPipeline* p, dust::FrameArgs& b, hipStream_t st) {
+  uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
+  uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
+  if (p->tune.debug & 16u) { HIP_TRY(dust::launch_surfel_apply(b, 1, st)); return DUST_OK; }
+  b.gi.sort_keys = sk[0];
+  b.gi.sort_vals = sv[0];
+  HIP_TRY(dust::launch_surfel_apply(b, 2, st));
+  uint32_t bits = 1;
+  while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
+  bool in_b = false;
+  HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
+  b.gi.apply_keys = sk[in_b ? 1 : 0];
+  b.gi.apply_vals = sv[in_b ? 1 : 0];
+  HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+  return DUST_OK;
+}
+// shard_world >= 1: the trace of rank shard_rank's share of the ordered pool only, records staged in slot order, nothing applied
+// (dust_hip_gi_surfel_exchange_run completes the pass)
+static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, uint32_t passes, bool count, hipStream_t st, uint32_t resident,
+                                  uint32_t shard_rank = 0, uint32_t shard_world = 0) {
   DustHipContext* ctx = p->ctx;
   const Tuning& tune = p->tune;
   const uint32_t block = tune.block;
@@ -1730,11 +1783,35 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, 16, &in_b, st));
       b.gi.perm = sv[in_b ? 1 : 0];
     }
-    if (tune.packet_gi || !b.grid.cells) {
-      take_counters(p, 3, b);
-      { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
-      const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
-      HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+    const bool staged = shard_world >= 1;
+    if (staged) {
+      const uint32_t groups = (p->gi_pool_size + 63u) / 64u, per = (groups + shard_world - 1u) / shard_world;
+      if (!p->gi_stage_req.p) {   // room for any world up to 64: a rank's share ends on a group boundary
+        const size_t cap = size_t(groups + 64u) * 64u;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(p->gi_stage_req.alloc(cap * sizeof(dust::DevHashRequest)));
+        HIP_TRY(p->gi_stage_repl.alloc(cap * 16));
+        HIP_TRY(p->gi_stage_sun.alloc(cap * 16));
+        HIP_TRY(hipMemsetAsync(p->gi_stage_req.p, 0, cap * sizeof(dust::DevHashRequest), st));
+        HIP_TRY(hipMemsetAsync(p->gi_stage_repl.p, 0xFF, cap * 16, st));   // direction 0xFFFFFFFF: "keep"
+        HIP_TRY(hipMemsetAsync(p->gi_stage_sun.p, 0, cap * 16, st));
+      }
+      b.sf_stage_req = static_cast<dust::DevHashRequest*>(p->gi_stage_req.p);
+      b.sf_stage_repl = static_cast<dust::DevSurfel*>(p->gi_stage_repl.p);
+      b.sf_stage_sun = static_cast<float*>(p->gi_stage_sun.p);
+      b.sf_group_begin = std::min(groups, shard_rank * per);
+      b.sf_group_count = std::min(per, groups - b.sf_group_begin);
+      b.tiles_x = 2 * b.sf_group_count;   // (a rank past the end of the pool traces nothing)
+      p->sf_shard.pending = true; p->sf_shard.perm = b.gi.perm; p->sf_shard.rank = shard_rank; p->sf_shard.world = shard_world;
+      p->sf_shard.slots_per_rank = per * 64u;
+    }
+    if (tune.packet_gi() || !b.grid.cells || staged) {   // (a sharded trace runs as packets: the stream's shading kernel writes by surfel index)
+      if (b.tiles_x) {   // (a rank past the end of the pool traces nothing)
+        take_counters(p, 3, b);
+        { DustStatus os = order_tiles(p, 3, b, st); if (os != DUST_OK) return os; }
+        const uint32_t sgrid = std::max(8u, std::min<uint32_t>(resident, (b.tiles_x + 7) / 8));
+        HIP_TRY(dust::launch_surfel_trace(b, sgrid, block, count, st));
+      }
     } else {
       // phase 1 as a ray stream (gi.hip): the pool's rays, compacted -> one ray per lane, lanes refilled -> the hash lookups over the hit records
       stream_args(p, 1, b, 0.1f, 10000.0f);  // surfel.rgen:33-62
@@ -1749,29 +1826,25 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
       HIP_TRY(dust::launch_surfel_shade(b, st));
     }
     // phase 2: apply the recorded inserts. Default: concurrently, like the reference's shaders. DUST_PASS_GI_ORDERED: the
-    // result of applying them in surfel-index order -- in parallel over independent probe-window clusters (the serial
-    // one-wavefront loop it is checked against stays reachable through DUST_HIP_DEBUG bit 16)
-    if (!(passes & DUST_PASS_GI_ORDERED)) {
+    // result of applying them in surfel-index order (apply_ordered). A sharded trace stops here: its records are not complete yet.
+    if (staged) {
+    } else if (!(passes & DUST_PASS_GI_ORDERED)) {
       HIP_TRY(dust::launch_surfel_apply(b, 0, st));
-    } else if (tune.debug & 16u) {
-      HIP_TRY(dust::launch_surfel_apply(b, 1, st));
     } else {
-      HIP_TRY(dust::launch_surfel_apply(b, 2, st));
-      uint32_t bits = 1;
-      while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
-      bool in_b = false;
-      HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
-      b.gi.apply_keys = sk[in_b ? 1 : 0];
-      b.gi.apply_vals = sv[in_b ? 1 : 0];
-      HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+      DustStatus as = apply_ordered(p, b, st);
+      if (as != DUST_OK) return as;
     }
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   return DUST_OK;
 }
 DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
-                                 const DustHipSky* sky, const DustHipFrameParams* fp) {
-  if (!p || !s || !cam || !sky || !fp) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
-  STRUCT_TRY(fp, "DustHipFrameParams");
+                                 const DustHipSky* sky, const DustHipFrameParams* fp_in) {
+  if (!p || !s || !cam || !sky || !fp_in) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  // (round 6 appended surfel_rank / surfel_world: a caller compiled against the struct that ends at row_end gets zeroes for them)
+  if (fp_in->struct_size < offsetof(DustHipFrameParams, surfel_rank)) return fail(DUST_ERR_INVALID_ARGUMENT, "DustHipFrameParams.struct_size is smaller than this library's DustHipFrameParams");
+  DustHipFrameParams fp_copy{};
+  std::memcpy(&fp_copy, fp_in, std::min<size_t>(fp_in->struct_size, sizeof fp_copy));
+  const DustHipFrameParams* fp = &fp_copy;
   if (p->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "pipeline and scene belong to different contexts");
   if (!s->committed) return fail(DUST_ERR_NOT_READY, "scene has uncommitted changes (call dust_hip_scene_commit)");
   for (size_t i = 0; i < s->models.size(); ++i)
@@ -1792,6 +1865,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     return fail(DUST_ERR_UNSUPPORTED, "a GI pass on a row band needs DUST_PASS_GI_SHARDED and the exchange of dust_hip_pipeline_gi_exchange");
   if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && (fp->passes & DUST_PASS_SURFEL))
     return fail(DUST_ERR_INVALID_ARGUMENT, "DUST_PASS_GI_SHARDED: the surfel pass runs after the exchange, in its own call");
+  if (fp->surfel_world != 0 && (fp->passes & DUST_PASS_SURFEL) && (!sharded || fp->surfel_world > 64 || fp->surfel_rank >= fp->surfel_world))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "a sharded surfel trace wants DUST_PASS_GI_SHARDED, surfel_world <= 64 and surfel_rank < surfel_world");
+  if (p->sf_shard.pending && (fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)))
+    return fail(DUST_ERR_NOT_READY, "a sharded surfel trace is pending on this pipeline: dust_hip_gi_surfel_exchange_run completes it before the next GI pass");
   if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && !p->gi_touched.p)
     return fail(DUST_ERR_NOT_READY, "DUST_PASS_GI_SHARDED: call dust_hip_pipeline_gi_exchange first");
   if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->gi_hash.p) {
@@ -1872,6 +1949,12 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   a.debug = tune.debug;
   a.static_rounds_request = tune.static_rounds;
   for (const DustHipModel* m : s->models) a.deep |= m->dev.n_levels == 3 ? 1u : 0u;
+  {  // which GI passes of this frame run as ray streams (decided once, here: the launches below ask the same questions)
+    const bool fg_stream = (fp->passes & DUST_PASS_FINAL_GATHER) && a.grid.cells &&
+                           (!tune.packet_gi() || (a.deep && !tune.packet_only() && !(tune.debug & 12u) && !tune.no_gather_order));
+    const bool sf_stream = (fp->passes & DUST_PASS_SURFEL) && a.grid.cells && !tune.packet_gi();
+    if (fg_stream || sf_stream) { DustStatus es = ensure_stream_buffers(p, fg_stream, sf_stream); if (es != DUST_OK) return es; }
+  }
   const bool count = fp->passes & DUST_PASS_COUNT_STATS;
   const uint32_t block = tune.block;
   uint32_t bpc = tune.blocks_per_cu;
@@ -1890,7 +1973,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // kernels hold all VGPRs of the SIMDs they run on, so a kernel of another queue (an RCCL send/receive moving the previous
   // frame to another GPU) can only become resident next to them where a workgroup slot was left empty.
   uint32_t resident = uint32_t(ctx->num_cus) * bpc;
-  if (tune.reserve_blocks && tune.reserve_blocks + 8u <= resident) resident -= tune.reserve_blocks;
+  // (DUST_RESERVE_AUTO: nothing until the pipeline has been seen in a collective of world > 1 -- comm.hip says so --, 32 from then on: without
+  //  them RCCL's kernels wait 36 us - 0.2 ms behind a persistent launch, with them under 10 us; they cost the traversal 5 %)
+  const uint32_t reserve_blocks = (tune.reserve_blocks == DUST_RESERVE_AUTO ? (p->in_collective ? 32u : 0u) : tune.reserve_blocks) & ~7u;
+  if (reserve_blocks && reserve_blocks + 8u <= resident) resident -= reserve_blocks;
   hipStream_t st = ctx->stream;
   p->stats_valid = false;
   // An event pair around a launch costs the stream ~6 us per record (a marker packet the next dispatch waits behind): 5 % of a
@@ -1933,7 +2019,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   const uint32_t main_resident = std::max(8u, resident - std::min(resident - 8u, side_slots));
   // (a caller with several frames in flight, each on a pipeline of its own: this launch takes its share of the slots -- whole
   // rounds over the 8 XCDs -- and leaves the rest to the others, dust_hip_pipeline_set_frames_in_flight)
-  const uint32_t frame_slots = p->frames_in_flight > 1 ? std::max(8u, (main_resident / p->frames_in_flight) & ~7u) : main_resident;
+  // (DUST_IN_FLIGHT_ALL: every launch asks for all of them -- whole frames one behind the other on two or three streams: the next frame's
+  //  workgroups become resident on the CUs the previous frame's last tiles have left)
+  const bool share_slots = p->frames_in_flight > 1 && tune.in_flight_slots == DUST_IN_FLIGHT_SHARE;
+  const uint32_t frame_slots = share_slots ? std::max(8u, (main_resident / p->frames_in_flight) & ~7u) : main_resident;
   const uint32_t grid = std::max(8u, std::min<uint32_t>(frame_slots, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
@@ -1974,7 +2063,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     // no slots reserved, the default block size): the roots are staged once per CU and sixteen waves share a tile queue
     uint32_t fblock = block, fgrid = grid;
     const size_t lds_wide = size_t(a.n_lds_models) * dust::kN16LdsBytes + 16u * (dust::kMaxCand * 8 + 8) + 16 + size_t(a.n_lds_boxes) * 32;
-    if (tune.wide_fused && block == 512 && bpc == 2 && !ctx->side_busy && p->frames_in_flight <= 1 && !tune.reserve_blocks && lds_wide <= ctx->max_lds &&
+    if (tune.wide_fused && block == 512 && bpc == 2 && !ctx->side_busy && !share_slots && !reserve_blocks && lds_wide <= ctx->max_lds &&
         grid == resident) {
       fblock = 1024;
       fgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus), (total_tiles + 7) / 8));
@@ -2013,7 +2102,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     }
     a.stats = static_cast<dust::DevStats*>(p->stats.p) + 3;
     // (a 4096^3 tree: long walks through one instance -- the one workload where a lane of its own per ray pays: 1.66 against 1.82 ms)
-    if (a.grid.cells && (!tune.packet_gi || (a.deep && !tune.packet_only && !(tune.debug & 12u) && !tune.ray_lanes && !tune.no_gather_order && !tune.gather_split))) {
+    if (a.grid.cells && (!tune.packet_gi() || (a.deep && !tune.packet_only() && !(tune.debug & 12u) && !tune.no_gather_order))) {
       // The pass as a ray stream (gi.hip): make and bin the band's gather rays (a thread per pixel) -> walk them one per lane, lanes refilled
       // (k_ray_walk) -> shade the hit records (a thread per pixel). Behind the previous frame's surfel pass, like the packet kernel: rays and
       // hit records touch no GI state and COULD run beside that pass, but two persistent launches sharing the slots both get slower
@@ -2038,47 +2127,25 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     } else {
     dust::FrameArgs g = a;
     uint32_t ggrid = std::max(8u, std::min<uint32_t>(resident, (total_tiles + 7) / 8));
-    bool pool = false;
     if (!tune.no_gather_order) {  // pre-pass: regroup the band's live pixels by ray-direction octant
       const uint32_t otx = (p->width + 63) / 64, oty = (a.row_end - a.row_begin + 63) / 64;
       g.gi.order = static_cast<uint32_t*>(p->gi_order.p);
       g.gi.order_count = static_cast<uint32_t*>(p->gi_order_count.p);
       g.gi.order_tiles_x = otx;
       HIP_TRY(dust::launch_gather_order(g, otx * oty, st));
-      pool = tune.ray_lanes;
-      // work items: 64 packets of 64 per tile -- or, as ray lanes, 4096 / group items of `group` entries --, the empty ones skipped by the kernel
-      g.tiles_x = otx * oty * (pool ? 4096u / dust::final_gather_pool_group() : 64u);
+      // work items: 64 packets of 64 per tile, the empty ones skipped by the kernel
+      g.tiles_x = otx * oty * 64u;
       g.tiles_y = 1;
       ggrid = std::max(8u, std::min<uint32_t>(resident, (g.tiles_x + 7) / 8));
     }
-    // DUST_HIP_GATHER_SPLIT (opt-in, round 4): trace, then shade. The gather RAYS touch no GI state: traced by a kernel of their own
-    // (hit records in gi_fg_hits) they can run beside the previous frame's surfel pass like the primary / AO kernel before them, on the
-    // same share of the slots; only the shading -- hash lookups and stamps, surfel enqueues, the radiance texels -- waits for that pass
-    // (join_side), as a full-occupancy pass over the records in pixel order. Built as the round-3 review proposed, and measured: the
-    // trace-only kernel is 0.190 ms against 0.233 fused, but the shading pass exposes the hash's random HBM traffic that the fused
-    // kernel hides under tracing (GI frame 0.747 ms with the join first, 0.84 beside the surfel pass at its usual share, 0.719 with the
-    // share cut to 22 %, against 0.730 fused): not the default.
-    const bool split = !pool && tune.gather_split;
-    if (split) {
-      const size_t need = size_t(p->width) * p->height * sizeof(dust::DevGatherHit);
-      if (p->gi_fg_hits.bytes < need) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(p->gi_fg_hits.alloc(need)); }
-      g.gi.fg_hits = static_cast<dust::DevGatherHit*>(p->gi_fg_hits.p);
-      if (tune.gather_join_first) HIP_TRY(join_side(ctx));
-      if (ctx->side_busy) ggrid = std::max(8u, std::min<uint32_t>(frame_slots, ggrid));  // (the pass beside it keeps its share)
-    } else {
-      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
-    }
+    // (Round 4 also built the gather as a trace-only kernel beside the previous frame's surfel pass + a shading pass over hit records, and
+    //  round 3 as refilled ray lanes inside the packet kernel: both measured slower and were removed in round 6 -- docs/EXPERIMENTS.md.)
+    HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool this gather reads
     take_counters(p, 2, g);
     { DustStatus os = order_tiles(p, 2, g, st); if (os != DUST_OK) return os; }
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(2), st));  // (behind the regrouping pre-pass: the gather kernel)
-    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded && !split, pool, st));
+    HIP_TRY(dust::launch_final_gather(g, ggrid, block, count, !sharded, st));
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(2), st)); p->ev_valid[2] = true; }
-    if (split) {
-      HIP_TRY(join_side(ctx));  // the previous frame's surfel pass has written the hash and the pool the shading reads
-      dust::FrameArgs sh = a;   // (pixel order over the band: no regrouping, no work counters)
-      sh.gi.fg_hits = g.gi.fg_hits;
-      HIP_TRY(dust::launch_final_gather_shade(sh, !sharded, st));
-    }
       }
   }
   if (fp->passes & DUST_PASS_SURFEL) {
@@ -2091,7 +2158,7 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     // beside the next frame's kernels it takes a share of the workgroup slots (both are persistent launches: with all slots
     // taken by the first, the second would simply run after it)
     const uint32_t side_resident = std::max(8u, (resident * share / 100u) & ~7u);
-    DustStatus rs = run_surfel_pass(p, a, fp->passes, count, aside ? ctx->side : st, aside ? side_resident : resident);
+    DustStatus rs = run_surfel_pass(p, a, fp->passes, count, aside ? ctx->side : st, aside ? side_resident : resident, fp->surfel_rank, fp->surfel_world);
     // (whatever of the pass was enqueued -- all of it, or what came before a failed launch -- is waited for by the next user of the GI state)
     if (aside) { ctx->side_busy = true; const hipError_t re = hipEventRecord(ctx->ev_side_done, ctx->side); if (rs == DUST_OK && re != hipSuccess) rs = hip_fail(re, "hipEventRecord(ev_side_done)"); }
     if (rs != DUST_OK) return rs;
@@ -2241,18 +2308,8 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys[0], &p->gi_sort_keys[1], &p->gi_sort_vals[0], &p->gi_sort_vals[1]}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
   HIP_TRY(p->gi_sort_scratch.alloc(dust::radix_sort_scratch_bytes(surfel_pool_size)));
-  // ray streams: a ray per pixel / two per surfel at most, the surfel rays' hit records, the gather rays' (per pixel), the counters
-  {
-    const size_t tiles = size_t((p->width + 15) / 16) * ((p->height + 15) / 16), runs = (size_t(surfel_pool_size) + 255) / 256;
-    HIP_TRY(p->gi_rays_fg.alloc(tiles * 256 * sizeof(dust::DevRay)));
-    HIP_TRY(p->gi_groups_fg.alloc(tiles * 4));
-    HIP_TRY(p->gi_fg_hits.alloc(size_t(p->width) * p->height * sizeof(dust::DevGatherHit)));
-    HIP_TRY(p->gi_rays_sf.alloc(runs * 512 * sizeof(dust::DevRay)));
-    HIP_TRY(p->gi_groups_sf.alloc(runs * 4));
-    HIP_TRY(p->gi_unbinned.alloc(4 * 4));
-    HIP_TRY(hipMemsetAsync(p->gi_unbinned.p, 0, 4 * 4, p->ctx->stream));
-    HIP_TRY(p->gi_hits_sf.alloc(size_t(surfel_pool_size) * 2 * sizeof(dust::DevGatherHit)));
-  }
+  // (the ray streams' buffers -- 48 B per pixel and more -- are made by the first frame that takes a stream path: ensure_stream_buffers)
+  for (DeviceBuffer* b : {&p->gi_rays_fg, &p->gi_groups_fg, &p->gi_fg_hits, &p->gi_rays_sf, &p->gi_groups_sf, &p->gi_unbinned, &p->gi_hits_sf}) b->release();
   p->gi_capacity = hash_capacity;
   p->gi_pool_size = surfel_pool_size;
   p->gi_touched_rows = 0;  // the exchange buffers follow the pool size: dust_hip_pipeline_gi_exchange re-creates them
@@ -2439,6 +2496,33 @@ DustStatus dust_hip_pipeline_set_frames_in_flight(DustHipPipeline* p, uint32_t n
   p->frames_in_flight = n;
   return DUST_OK;
 }
+DustStatus dust_hip_pipeline_configure(DustHipPipeline* p, const DustHipPipelineConfig* cfg) {
+  if (!p || !cfg) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  STRUCT_TRY(cfg, "DustHipPipelineConfig");
+  if (cfg->gi_path > DUST_GI_PATH_STREAMS || cfg->side_stream > DUST_SIDE_STREAM_OFF || cfg->in_flight_slots > DUST_IN_FLIGHT_ALL ||
+      cfg->frames_in_flight > 16 || (cfg->side_share != 0 && (cfg->side_share < 5 || cfg->side_share > 90)))
+    return fail(DUST_ERR_INVALID_ARGUMENT, "DustHipPipelineConfig: a field is out of range");
+  Tuning& t = p->tune;
+  t.reserve_blocks = cfg->reserve_blocks == DUST_RESERVE_AUTO ? DUST_RESERVE_AUTO : (cfg->reserve_blocks & ~7u);  // whole rounds over the 8 XCDs
+  t.gi_path = cfg->gi_path;
+  t.no_side_stream = cfg->side_stream == DUST_SIDE_STREAM_OFF;
+  t.side_share = cfg->side_share;
+  t.in_flight_slots = cfg->in_flight_slots;
+  if (cfg->frames_in_flight) p->frames_in_flight = cfg->frames_in_flight;
+  return DUST_OK;
+}
+DustStatus dust_hip_pipeline_get_config(const DustHipPipeline* p, DustHipPipelineConfig* out) {
+  if (!p || !out) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  STRUCT_TRY(out, "DustHipPipelineConfig");
+  const Tuning& t = p->tune;
+  out->reserve_blocks = t.reserve_blocks;
+  out->gi_path = t.gi_path;
+  out->side_stream = t.no_side_stream ? DUST_SIDE_STREAM_OFF : DUST_SIDE_STREAM_AUTO;
+  out->side_share = t.side_share;
+  out->frames_in_flight = p->frames_in_flight;
+  out->in_flight_slots = t.in_flight_slots;
+  return DUST_OK;
+}
 DustStatus dust_hip_pipeline_clear(DustHipPipeline* p) {
   if (!p) return fail(DUST_ERR_INVALID_ARGUMENT, "null pipeline");
   HIP_TRY(hipSetDevice(p->ctx->device));
@@ -2470,6 +2554,35 @@ DustStatus gi_exchange_view(DustHipPipeline* p, uint32_t padded_rows, DustHipGiE
   out->touched = p->gi_touched.p;
   out->merged = p->gi_merged.p;
   return DUST_OK;
+}
+void pipeline_note_collective(DustHipPipeline* p) { p->in_collective = true; }
+DustStatus surfel_stage_view(DustHipPipeline* p, uint32_t world, SurfelStage* out) {
+  if (!p->sf_shard.pending || !p->gi_stage_req.p) return fail(DUST_ERR_NOT_READY, "no sharded surfel trace is pending on this pipeline (dust_hip_render_frame with surfel_world >= 1 first)");
+  if (world != 0 && p->sf_shard.world != world) return fail(DUST_ERR_INVALID_ARGUMENT, "the pending surfel trace was sharded for another world size than the communicator's");
+  out->req = p->gi_stage_req.p; out->repl = p->gi_stage_repl.p; out->sun = p->gi_stage_sun.p;
+  out->slots_per_rank = p->sf_shard.slots_per_rank; out->rank = p->sf_shard.rank; out->pool_size = p->gi_pool_size;
+  return DUST_OK;
+}
+// the second half of a sharded surfel pass, on the context's stream behind the all-gather: records to their surfels + the trace's hash stamps, ordered apply
+DustStatus surfel_finish(DustHipPipeline* p, uint32_t frame_index) {
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  dust::FrameArgs a{};
+  a.frame_index = frame_index;
+  a.gi.hash = static_cast<uint32_t*>(p->gi_hash.p);
+  a.gi.hash_capacity = p->gi_capacity;
+  a.gi.pool = static_cast<dust::DevSurfel*>(p->gi_pool.p);
+  a.gi.pool_size = p->gi_pool_size;
+  a.gi.requests = static_cast<dust::DevHashRequest*>(p->gi_requests.p);
+  a.gi.replacement = static_cast<dust::DevSurfel*>(p->gi_replacement.p);
+  a.gi.sun_payload = static_cast<float*>(p->gi_sun_payload.p);
+  a.gi.perm = p->sf_shard.perm;
+  a.sf_stage_req = static_cast<dust::DevHashRequest*>(p->gi_stage_req.p);
+  a.sf_stage_repl = static_cast<dust::DevSurfel*>(p->gi_stage_repl.p);
+  a.sf_stage_sun = static_cast<float*>(p->gi_stage_sun.p);
+  const hipStream_t st = p->ctx->stream;
+  HIP_TRY(dust::launch_surfel_unstage(a, st));
+  p->sf_shard.pending = false;
+  return apply_ordered(p, a, st);
 }
 void context_add_stream(DustHipContext* c, hipStream_t s) { c->extra_streams.push_back(s); }
 void context_remove_stream(DustHipContext* c, hipStream_t s) {

@@ -92,7 +92,7 @@ constexpr uint32_t kMaxWorld = 64;
 
 // what one rank of a loopback group has asked for; the group runs the collective when its last rank has
 struct LocalCall {
-  int op = 0;  // 0 none, 1 gather_bands, 2 gi_exchange
+  int op = 0;  // 0 none, 1 gather_bands, 2 gi_exchange, 3 surfel exchange (the sharded trace's records)
   DustHipPipeline* pipe = nullptr;
   uint32_t planes = 0;  // bit i: plane i travels
   std::vector<uint32_t> cuts;
@@ -216,6 +216,31 @@ DustStatus run_local_gi(LocalGroup& g, hipStream_t st) {
   if (status == DUST_OK && e != hipSuccess) status = hip_fail(e, "loopback GI exchange");
   return status;
 }
+// the sharded surfel trace's second half on a loopback group: rank r's run of each staging array into every other rank's copy, then every
+// rank's own completion (records to their surfels, stamps, ordered apply) -- what three all-gathers and the same kernels do on N devices
+DustStatus run_local_surfel(LocalGroup& g, hipStream_t st) {
+  const uint32_t W = g.world;
+  std::vector<dust_internal::SurfelStage> sv(W);
+  for (uint32_t r = 0; r < W; ++r) {
+    if (g.calls[r].frame_index != g.calls[0].frame_index) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks of a surfel exchange disagree about the frame");
+    DUST_TRY(dust_internal::surfel_stage_view(g.calls[r].pipe, W, &sv[r]));
+    if (sv[r].rank != r) return set_error(DUST_ERR_INVALID_ARGUMENT, "a rank's pending surfel trace was made for another rank of the group");
+    if (sv[r].slots_per_rank != sv[0].slots_per_rank || sv[r].pool_size != sv[0].pool_size) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' surfel pools differ in size");
+  }
+  const size_t S = sv[0].slots_per_rank;
+  for (uint32_t r = 0; r < W; ++r)
+    for (uint32_t q = 0; q < W; ++q)
+      if (q != r) {
+        const size_t widths[3] = {32, 16, 16};
+        void* src[3] = {sv[r].req, sv[r].repl, sv[r].sun};
+        void* dst[3] = {sv[q].req, sv[q].repl, sv[q].sun};
+        for (int k = 0; k < 3; ++k)
+          HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(dst[k]) + size_t(r) * S * widths[k], static_cast<uint8_t*>(src[k]) + size_t(r) * S * widths[k], S * widths[k],
+                                 hipMemcpyDeviceToDevice, st));
+      }
+  for (uint32_t r = 0; r < W; ++r) DUST_TRY(dust_internal::surfel_finish(g.calls[r].pipe, g.calls[0].frame_index));
+  return DUST_OK;
+}
 // rank `c`'s part of a collective on a loopback group: remember it; the call that completes the group runs it for everyone
 DustStatus local_call(DustHipComm* c, LocalCall&& call) {
   LocalGroup& g = *c->local;
@@ -232,7 +257,7 @@ DustStatus local_call(DustHipComm* c, LocalCall&& call) {
   g.calls[c->rank] = std::move(call);
   if (++g.pending < g.world) return DUST_OK;
   const hipStream_t st = dust_internal::context_stream(c->ctx);
-  const DustStatus s = op == 1 ? run_local_gather(g, st) : run_local_gi(g, st);
+  const DustStatus s = op == 1 ? run_local_gather(g, st) : (op == 2 ? run_local_gi(g, st) : run_local_surfel(g, st));
   for (LocalCall& lc : g.calls) lc = LocalCall();
   g.pending = 0;
   return s;
@@ -346,6 +371,7 @@ static DustStatus gather_planes(DustHipPipeline* p, DustHipComm* c, uint32_t pla
   dust_internal::pipeline_size(p, &width, &height);
   DUST_TRY(check_cuts(cuts, c->world, height));
   HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
+  if (c->world > 1 && !c->local) dust_internal::pipeline_note_collective(p);  // (RCCL's kernels will want workgroup slots beside this pipeline's launches)
   if (c->local) {
     LocalCall call;
     call.op = 1; call.pipe = p; call.planes = planes; call.cuts.assign(cuts, cuts + c->world + 1); call.root = root; call.dst = dst; call.dst_bytes = dst_bytes;
@@ -430,6 +456,7 @@ DustStatus dust_hip_gi_exchange_run(DustHipPipeline* p, DustHipComm* c, uint32_t
   if (!p || !c || band_rows == 0 || row_begin > row_end) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad GI exchange arguments");
   if (dust_internal::pipeline_context(p) != c->ctx) return set_error(DUST_ERR_INVALID_ARGUMENT, "pipeline and communicator belong to different contexts");
   HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
+  if (c->world > 1 && !c->local) dust_internal::pipeline_note_collective(p);
   if (c->local) {
     LocalCall call;
     call.op = 2; call.pipe = p; call.row_begin = row_begin; call.row_end = row_end; call.band_rows = band_rows; call.frame_index = frame_index;
@@ -455,6 +482,45 @@ DustStatus dust_hip_gi_exchange_run(DustHipPipeline* p, DustHipComm* c, uint32_t
 #else
   return no_rccl();
 #endif
+}
+
+DustStatus dust_hip_gi_surfel_exchange_run(DustHipPipeline* p, DustHipComm* c, uint32_t frame_index) {
+  if (!p) return set_error(DUST_ERR_INVALID_ARGUMENT, "bad surfel exchange arguments");
+  if (!c) {   // no communicator: nothing travels (a world of one; one emulated rank of N, whose peers' records are what the staging arrays hold)
+    dust_internal::SurfelStage sv;
+    DUST_TRY(dust_internal::surfel_stage_view(p, 0, &sv));
+    return dust_internal::surfel_finish(p, frame_index);
+  }
+  if (dust_internal::pipeline_context(p) != c->ctx) return set_error(DUST_ERR_INVALID_ARGUMENT, "pipeline and communicator belong to different contexts");
+  HIP_TRY(hipSetDevice(dust_internal::context_device(c->ctx)));
+  if (c->world > 1 && !c->local) dust_internal::pipeline_note_collective(p);
+  if (c->local) {
+    LocalCall call;
+    call.op = 3; call.pipe = p; call.frame_index = frame_index;
+    return local_call(c, std::move(call));
+  }
+  dust_internal::SurfelStage sv;
+  DUST_TRY(dust_internal::surfel_stage_view(p, c->world, &sv));
+  if (sv.rank != c->rank) return set_error(DUST_ERR_INVALID_ARGUMENT, "the pending surfel trace was made for another rank than the communicator's");
+  if (c->world > 1) {
+#if DUST_HAVE_RCCL
+    Rccl* r = rccl();
+    if (!r) return no_rccl();
+    const hipStream_t st = dust_internal::context_stream(c->ctx);
+    const size_t S = sv.slots_per_rank;
+    // in place: rank r's run stands at r * S of each array. One group: the three all-gathers share their rounds over the links.
+    NCCL_TRY(r->GroupStart());
+    ncclResult_t ne = r->AllGather(static_cast<uint8_t*>(sv.req) + size_t(c->rank) * S * 32, sv.req, S * 32, ncclChar, c->nccl, st);
+    if (ne == ncclSuccess) ne = r->AllGather(static_cast<uint8_t*>(sv.repl) + size_t(c->rank) * S * 16, sv.repl, S * 16, ncclChar, c->nccl, st);
+    if (ne == ncclSuccess) ne = r->AllGather(static_cast<uint8_t*>(sv.sun) + size_t(c->rank) * S * 16, sv.sun, S * 16, ncclChar, c->nccl, st);
+    const ncclResult_t ge = r->GroupEnd();
+    if (ne != ncclSuccess) return nccl_fail(ne, "ncclAllGather");
+    if (ge != ncclSuccess) return nccl_fail(ge, "ncclGroupEnd");
+#else
+    return no_rccl();
+#endif
+  }
+  return dust_internal::surfel_finish(p, frame_index);
 }
 
 }  // extern "C"

@@ -161,7 +161,8 @@ struct DevHashRequest {  // one SpatialHashInsert call recorded by the surfel pa
   int32_t kx, ky, kz;
   uint32_t dir_flags;    // bits 0-7 face id, bit 8: insert valid
   float vx, vy, vz;
-  uint32_t pad;
+  uint32_t stamped;      // 1 + index of the hash entry the surfel's SpatialHashGet found and stamped (surfel.rchit:47), 0 = none: what the other
+                         // ranks of a sharded trace repeat (k_surfel_unstage) so that every rank's hash stays the single-GPU one
 };
 struct DevGatherHit { float t; uint32_t inst, block, found; };  // what a gather ray found: the hit record the shading kernel takes up
 struct DevGI {
@@ -262,6 +263,15 @@ struct FrameArgs {
   // whole queue when the host runs a ring of commits ahead (capi.cpp).
   DUST_RW(uint32_t) started_word;
   uint32_t started_seq;
+  // ---- round 6, appended: the surfel TRACE sharded over the ranks of an N-GPU job (DustHipFrameParams::surfel_rank / surfel_world).
+  // A rank traces the groups [sf_group_begin, sf_group_begin + sf_group_count) of the position-ordered pool (64 slots each) and leaves its
+  // records in SLOT order in three staging arrays -- contiguous per rank, so one all-gather per array completes them on every rank --;
+  // k_surfel_unstage then moves them to where the apply reads them (by surfel index) and repeats the trace's hash stamps.
+  // sf_stage_req null: the unsharded pass (records go straight to gi.requests / replacement / sun_payload, by surfel index).
+  DevHashRequest* sf_stage_req;
+  DevSurfel* sf_stage_repl;
+  float* sf_stage_sun;
+  uint32_t sf_group_begin, sf_group_count;
 };
 
 }  // namespace dust

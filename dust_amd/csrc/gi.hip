@@ -199,16 +199,7 @@ __device__ __forceinline__ void gather_packet(ArgsRef a0, uint32_t px, uint32_t 
   const uint32_t ncand = cull_instances<MODE>(a, __any(live), wave_range(live, loc), wave_range(live, ad), a.cam.far_, cand);
   trace_ray<2, MODE>(a, live, loc, ad, 8.0f, a.cam.far_, false, cand, ncand, h, st);
   __builtin_amdgcn_wave_barrier();
-  ArgsRef b = reload_args(a0);
-  if (b.gi.fg_hits) {  // tracing only: the ray touches no GI state, so this kernel may run while the previous frame's surfel pass still writes it
-    if (live) {
-      u32x4 rec;
-      rec.x = __float_as_uint(h.t); rec.y = h.inst; rec.z = h.block; rec.w = h.found ? 1u : 0u;
-      *reinterpret_cast<u32x4*>(&b.gi.fg_hits[(size_t)py * b.width + px]) = rec;
-    }
-  } else if (live) {
-    gather_shade(b, px, py, inval, loc, ad, h);
-  }
+  if (live) gather_shade(reload_args(a0), px, py, inval, loc, ad, h);
 }
 
 // final_gather.rgen:14-52 + rough.rint + final_gather.rchit:35-91 + final_gather.rmiss:12-24, a packet at a time
@@ -237,12 +228,10 @@ __global__ void __launch_bounds__(512, 4) k_final_gather(const FrameArgs) {
   flush_stats<MODE>(a0, 0, st);
 }
 
-// final_gather.rchit:35-91 / final_gather.rmiss:12-24 as a pass of its own over the hit records k_final_gather left (DevGI::fg_hits): a
-// pixel per thread in pixel order -- the radiance texels and the per-pixel surfels go out as whole lines instead of 8- and 16-byte pieces
-// scattered by the regrouping --, at full occupancy (the hash probe is a dependent chain instance -> block -> 36 random bytes of a 384 MB
-// table: latency that many resident waves hide and four persistent ones per SIMD did not). It is also what lets the TRACE run beside the
-// previous frame's surfel pass: only this kernel reads and stamps the hash. A pixel is live exactly when the trace found it live
-// (gather_ray reads the same G-buffer texels: nothing has written them in between).
+// final_gather.rchit:35-91 / final_gather.rmiss:12-24 as a pass of its own over the hit records k_ray_walk<2> left (DevGI::fg_hits): a
+// pixel per thread in pixel order, at full occupancy (the hash probe is a dependent chain instance -> block -> 36 random bytes of a 384 MB
+// table). A pixel is live exactly when the ray-making kernel found it live (gather_ray reads the same G-buffer texels: nothing has written
+// them in between).
 __global__ void __launch_bounds__(256) k_final_gather_shade(const FrameArgs) {
   ArgsRef a = launch_args();
   const uint32_t rows = a.row_end - a.row_begin;
@@ -256,85 +245,6 @@ __global__ void __launch_bounds__(256) k_final_gather_shade(const FrameArgs) {
     h.t = __uint_as_float(rec.x); h.inst = rec.y; h.block = rec.z; h.voxel = 0; h.found = rec.w != 0u;
     gather_shade(a, px, py, inval, loc, ad, h);
   }
-}
-
-// The same pass over ray lanes (trace_pool): a work item is kPoolGroup consecutive entries of a tile's direction-ordered list --
-// several packets' worth of rays that share one cull and are streamed through the wave's 64 lanes.
-#ifndef DUST_POOL_GROUP
-#define DUST_POOL_GROUP 256  // entries per work item of the ray-lane kernels (k_final_gather_pool, k_surfel_trace_pool)
-#endif
-constexpr uint32_t kPoolGroup = DUST_POOL_GROUP;
-struct GatherSource {
-  uint32_t tile;
-  __device__ __forceinline__ void pixel_of(ArgsRef a, uint32_t idx, uint32_t& px, uint32_t& py) const {
-    const uint32_t pixel = a.gi.order[(size_t)tile * kOrderSlots + idx];
-    py = pixel / a.width;
-    px = pixel - py * a.width;
-  }
-  __device__ __forceinline__ bool fetch(ArgsRef a, uint32_t idx, V3& o, V3& d) const {
-    uint32_t px, py;
-    pixel_of(a, idx, px, py);
-    V3 inval;
-    return gather_ray(a, px, py, true, inval, o, d);
-  }
-  __device__ __forceinline__ void skip(ArgsRef, uint32_t) const {}
-  __device__ __forceinline__ void shade(ArgsRef a, uint32_t idx, V3 o, V3 d, const Hit& h) const {
-    uint32_t px, py;
-    pixel_of(a, idx, px, py);
-    float w;
-    const V3 inval = load_radiance(a.g.illuminance, (size_t)py * a.width + px, w);  // (what gather_ray read when the ray was made)
-    gather_shade(a, px, py, inval, o, d, h);
-  }
-};
-__device__ __forceinline__ void merge_range(Range3& r, const Range3& q) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(r.lo[k], q.lo[k]); r.hi[k] = fmaxf(r.hi[k], q.hi[k]); }
-}
-template <int MODE>
-__global__ void __launch_bounds__(512, 4) k_final_gather_pool(const FrameArgs) {
-  ArgsRef a0 = launch_args();
-  stage_roots(a0);
-  uint32_t* cand = wave_cand_list(a0);
-  LaneStats st = {0, 0, 0, 0, 0, 0};
-  WorkCursor wc = cursor_begin();
-  Packet p;
-  const uint32_t lane = threadIdx.x & 63u;
-  while (next_packet(a0, wc, p)) {
-    ArgsRef a = reload_args(a0);
-    constexpr uint32_t kGroups = kOrderSlots / kPoolGroup;
-    const uint32_t id = p.px / kTileW, tile = id / kGroups, begin = (id % kGroups) * kPoolGroup;
-    const uint32_t n = a.gi.order_count[tile];
-    if (begin >= n) continue;  // this tile has fewer live pixels
-    const uint32_t end = n < begin + kPoolGroup ? n : begin + kPoolGroup;
-    GatherSource src;
-    src.tile = tile;
-    // the item's ray bundle: one pass over its entries, a packet at a time (the rays themselves are made again when a lane
-    // takes them: six floats apiece are cheaper to recompute than to park)
-    Range3 org, dir;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { org.lo[k] = dir.lo[k] = INFINITY; org.hi[k] = dir.hi[k] = -INFINITY; }
-    bool any = false;
-    for (uint32_t j = begin; j < end; j += 64u) {
-      V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-      const bool live = j + lane < end && src.fetch(a, j + lane, o, d);
-      merge_range(org, wave_range(live, o));
-      merge_range(dir, wave_range(live, d));
-      any = any | (__any(live) != 0);
-    }
-    const uint32_t ncand = cull_instances<MODE>(a, any, org, dir, a.cam.far_, cand);
-    if (ncand > kMaxCand || (a.debug & 12u)) {  // the list overflowed (or a debug order was asked for): packets, each with its own cull
-      for (uint32_t j = begin; j < end; j += 64u) {
-        uint32_t px = 0, py = 0;
-        const bool valid = j + lane < end;
-        if (valid) src.pixel_of(a, j + lane, px, py);
-        gather_packet<MODE>(a0, px, py, valid, cand, st);
-      }
-      continue;
-    }
-    trace_pool<2, MODE>(a, src, begin, end, cand, ncand, 8.0f, a.cam.far_, false, st);
-  }
-  prof_end();
-  flush_stats<MODE>(a0, 0, st);
 }
 
 // the surfel each slot's winning pixel enqueued -> surfel pool; clears the owner table for the next frame
@@ -480,10 +390,11 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
     pf_item(false);
 #endif
     ArgsRef a = reload_args(a0);  // per packet: nothing of the descriptor rides in SGPRs from one packet to the next
-    const uint32_t groups = (a.gi.pool_size + 63u) / 64u;
+    // (a rank of a sharded trace owns the groups [sf_group_begin, + sf_group_count) of the ordered pool; unsharded: all of them)
+    const uint32_t groups = a.sf_stage_req ? a.sf_group_count : (a.gi.pool_size + 63u) / 64u;
     const uint32_t item = p.px / kTileW;
     const bool sun_item = item >= groups;
-    const uint32_t slot = (sun_item ? item - groups : item) * 64u + (threadIdx.x & 63u);
+    const uint32_t slot = ((a.sf_stage_req ? a.sf_group_begin : 0u) + (sun_item ? item - groups : item)) * 64u + (threadIdx.x & 63u);
     const uint32_t i = (a.gi.perm && slot < a.gi.pool_size) ? a.gi.perm[slot] : slot;  // position order, or pool order
     const bool in_range = i < a.gi.pool_size;
     DevSurfel e;
@@ -525,12 +436,13 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
         const float dn = dot3(n, sd);
         pay.x = ar.sun_term[0] * dn; pay.y = ar.sun_term[1] * dn; pay.z = ar.sun_term[2] * dn;
       }
-      if (in_range) reinterpret_cast<f32x4*>(ar.gi.sun_payload)[i] = pay;
+      if (ar.sf_stage_req) { if (slot < ar.gi.pool_size) reinterpret_cast<f32x4*>(ar.sf_stage_sun)[slot] = pay; }
+      else if (in_range) reinterpret_cast<f32x4*>(ar.gi.sun_payload)[i] = pay;
       continue;
     }
     const V3 cd = dir;
     DevHashRequest rq;
-    rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
+    rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.stamped = 0;
     DevSurfel repl;
     repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
     if (live) {
@@ -549,6 +461,7 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
         uint32_t count = 0;
         uint32_t entry;
         const bool found = hash_get(ar.gi, key, ar.frame_index, rad, count, entry);
+        rq.stamped = entry;
         const float rnd0 = div_const((float)ar.noise0[((ny0 + 40u + ar.rand) % 128u) * 128u + ((nx0 + 114u + ar.rand) % 128u)], 255.0f);
         if (found) {
           rad = modulate_by_avg_albedo(rad, alb);
@@ -559,7 +472,9 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
         }
       }
     }
-    if (in_range) {
+    if (ar.sf_stage_req) {   // slot order: a rank's records are one contiguous run (dead and out-of-range slots carry "nothing to do")
+      if (slot < ar.gi.pool_size) { ar.sf_stage_req[slot] = rq; ar.sf_stage_repl[slot] = repl; }
+    } else if (in_range) {
       ar.gi.requests[i] = rq;
       ar.gi.replacement[i] = repl;
     }
@@ -570,6 +485,24 @@ __global__ void __launch_bounds__(512, 4) k_surfel_trace(const FrameArgs) {
   prof_end();
   flush_stats<MODE>(a0, 0, st_sun);
   flush_stats<MODE>(a0, 1, st_cos);
+}
+
+// ==================================================================== surfel pass, sharded trace: slot-ordered staging -> the apply's arrays
+// After the all-gather every rank holds every rank's records in SLOT order (FrameArgs::sf_stage_*). One thread per slot moves its three
+// records to the surfel's own index -- where the unsharded trace puts them and the apply kernels read them -- and repeats the hash stamp
+// the surfel's SpatialHashGet made on the rank that traced it (`stamped`; surfel.rchit:47 -> spatial_hash.glsl:200-219: the low half of
+// the entry's third word = frame_index): a 16-bit store of a value every rank agrees on, complete before the apply reads any entry.
+__global__ void k_surfel_unstage(const FrameArgs) {
+  ArgsRef a = launch_args();
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.gi.pool_size; slot += gridDim.x * blockDim.x) {
+    const uint32_t i = a.gi.perm ? a.gi.perm[slot] : slot;
+    if (i >= a.gi.pool_size) continue;
+    const DevHashRequest rq = a.sf_stage_req[slot];
+    a.gi.requests[i] = rq;
+    a.gi.replacement[i] = a.sf_stage_repl[slot];
+    reinterpret_cast<f32x4*>(a.gi.sun_payload)[i] = reinterpret_cast<const f32x4*>(a.sf_stage_sun)[slot];
+    if (rq.stamped != 0u) reinterpret_cast<uint16_t*>(a.gi.hash + (size_t)(rq.stamped - 1u) * 3)[4] = (uint16_t)a.frame_index;
+  }
 }
 
 // ==================================================================== surfel pass, phase 2: apply in surfel order
@@ -1211,7 +1144,7 @@ __global__ void __launch_bounds__(256) k_surfel_shade(const FrameArgs) {
   const V3 sd = mk(a.sun_dir[0], a.sun_dir[1], a.sun_dir[2]);
   f32x4 pay = {0.0f, 0.0f, 0.0f, 0.0f};
   DevHashRequest rq;
-  rq.kx = rq.ky = rq.kz = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.pad = 0;
+  rq.kx = rq.kz = rq.ky = 0; rq.dir_flags = 0; rq.vx = rq.vy = rq.vz = 0.0f; rq.stamped = 0;
   DevSurfel repl;
   repl.x = repl.y = repl.z = 0.0f; repl.direction = 0xFFFFFFFFu;
   if (live) {
@@ -1239,6 +1172,7 @@ __global__ void __launch_bounds__(256) k_surfel_shade(const FrameArgs) {
       V3 rad;
       uint32_t count = 0, entry;
       const bool found = hash_get(a.gi, key, a.frame_index, rad, count, entry);
+      rq.stamped = entry;
       const uint32_t ny0 = i / 128u, nx0 = i - ny0 * 128u;
       const float rnd0 = div_const((float)a.noise0[((ny0 + 40u + a.rand) % 128u) * 128u + ((nx0 + 114u + a.rand) % 128u)], 255.0f);
       if (found) {
@@ -1274,11 +1208,9 @@ hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t
   hipLaunchKernelGGL(k_gather_order, dim3(n_tiles), dim3(kOrderThreads), 0, s, a);
   return hipGetLastError();
 }
-uint32_t final_gather_pool_group() { return kPoolGroup; }
-hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, bool pool, hipStream_t s) {
+hipError_t launch_final_gather(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t s) {
   const size_t lds = lds_bytes(a_in, block);
-  if (pool) DUST_LAUNCH_MODE(k_final_gather_pool, count, a_in);
-  else DUST_LAUNCH_MODE(k_final_gather, count, a_in);
+  DUST_LAUNCH_MODE(k_final_gather, count, a_in);
   if (commit) hipLaunchKernelGGL(k_surfel_commit, dim3(pool_grid(a_in)), dim3(256), 0, s, a_in);
   return hipGetLastError();
 }
@@ -1303,6 +1235,10 @@ hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
   else if (mode == 1) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
   else if (mode == 2) hipLaunchKernelGGL(k_surfel_apply_keys, dim3(pool_grid(a)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_surfel_apply_clusters, dim3(1024), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_surfel_unstage(const FrameArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_surfel_unstage, dim3(pool_grid(a)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_rays(const FrameArgs& a, hipStream_t s) {
@@ -1335,7 +1271,6 @@ hipError_t launch_ray_walk(const FrameArgs& a_in, int rt, uint32_t grid, uint32_
 hipError_t configure_gi_kernels(size_t max_lds) {  // (max_lds: what configure_kernels left after the build's static LDS)
   const void* fns[] = {
       (const void*)k_final_gather<0>, (const void*)k_final_gather<1>, (const void*)k_final_gather<2>, (const void*)k_final_gather<3>, (const void*)k_final_gather<4>, (const void*)k_final_gather<5>, (const void*)k_final_gather<6>, (const void*)k_final_gather<7>,
-      (const void*)k_final_gather_pool<0>, (const void*)k_final_gather_pool<1>, (const void*)k_final_gather_pool<2>, (const void*)k_final_gather_pool<3>, (const void*)k_final_gather_pool<4>, (const void*)k_final_gather_pool<5>, (const void*)k_final_gather_pool<6>, (const void*)k_final_gather_pool<7>,
       (const void*)k_surfel_trace<0>, (const void*)k_surfel_trace<1>, (const void*)k_surfel_trace<2>, (const void*)k_surfel_trace<3>, (const void*)k_surfel_trace<4>, (const void*)k_surfel_trace<5>, (const void*)k_surfel_trace<6>, (const void*)k_surfel_trace<7>,
       (const void*)k_ray_walk<2, 0>, (const void*)k_ray_walk<2, 1>, (const void*)k_ray_walk<2, 2>, (const void*)k_ray_walk<2, 3>,
       (const void*)k_ray_walk<3, 0>, (const void*)k_ray_walk<3, 1>, (const void*)k_ray_walk<3, 2>, (const void*)k_ray_walk<3, 3>,

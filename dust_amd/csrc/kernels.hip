@@ -764,15 +764,6 @@ hipError_t configure_kernels(size_t max_lds) {
 
 }  // namespace dust
 
-#ifdef DUST_POOL_STATS
-extern "C" int dust_hip_pool_stats(unsigned long long* out) {
-  unsigned long long h[16] = {};
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dust::g_pool_stats), sizeof h) != hipSuccess) return -1;
-  for (int i = 0; i < 16; ++i) out[i] = h[i];
-  unsigned long long z[16] = {};
-  return hipMemcpyToSymbol(HIP_SYMBOL(dust::g_pool_stats), z, sizeof z) == hipSuccess ? 0 : -1;
-}
-#endif
 #ifdef DUST_WAVE_TIMES
 extern "C" int dust_hip_launch_clocks(unsigned long long* out) {  // 256 x 3
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dust::g_launch_clock), sizeof(unsigned long long) * 256 * 3) == hipSuccess ? 0 : -1;

@@ -440,6 +440,9 @@ __device__ __forceinline__ bool n16_child(DUST_RO(uint8_t) node, int lds_slot, u
   return true;
 }
 
+#ifndef DUST_TRANSPOSE_RAYS
+#define DUST_TRANSPOSE_RAYS 32   // rays of an incoherent packet still wanting a candidate batch at or below which the box scan runs lane = box (trace_ray); 0: never
+#endif
 constexpr uint32_t kDirectCell = 0x100u;  // find_brick's cell_log2 flag: a 16-cell whose bricks the walk tests one by one
 #ifndef DUST_DIRECT_BRICKS
 #define DUST_DIRECT_BRICKS 4
@@ -662,6 +665,27 @@ __device__ __attribute__((noinline)) u32x8 visit_neighbours(const DUST_CONST_AS 
   return out;
 }
 
+// A ray with a direction component that is exactly zero whose origin lies exactly ON a brick plane of that axis (o_a a multiple of 4 in
+// object space) hits NOTHING in the instance: for every brick the local coordinate o_a - b_a is 0, 4 or outside [0, 4], and the
+// intersection shaders' slab arithmetic (hit.rint:20-28, intersect_aabb04) then yields {NaN, +-inf} or two infinities of one sign for that
+// axis -- minNum / maxNum drop the NaN, t_min = +inf or t_max = -inf, and `t_min >= t_max` rejects the brick (the oracle's brute force over
+// every brick runs the same arithmetic and finds the same nothing). Only a ray STRICTLY inside a slab it never leaves can hit a brick of it.
+// The case is not exotic: the reference's default sun has x == 0 exactly (pipeline/sky.rs:20), a surfel's sun ray starts at its brick's
+// centre + 2.01 n (surfel.rgen:27), and an instance whose lattice is offset by 2 (mod 4) from the surfel's own has a brick plane exactly
+// there: the conservative walk then called visit_neighbours on 55-89 % of its trips -- for bricks on either side that cannot be hit --,
+// and those sun items were the surfel trace's longest (docs/EXPERIMENTS.md, rounds 5 and 6). The incoherent ray types only: a camera or
+// AO ray's origin is not on the lattice.
+template <int RT>
+__device__ __forceinline__ bool in_brick_plane(V3 o, V3 d) {
+#ifdef DUST_NO_PLANE_EXIT
+  return false;
+#else
+  if (RT < 2) return false;
+  const float qx = o.x * 0.25f, qy = o.y * 0.25f, qz = o.z * 0.25f;  // (exact: a power of two)
+  return (d.x == 0.0f && qx == rintf(qx)) || (d.y == 0.0f && qy == rintf(qy)) || (d.z == 0.0f && qz == rintf(qz));
+#endif
+}
+
 // Hierarchical traversal of one instance in object space. Visits, front to back, a SUPERSET of the
 // bricks whose intersection routine can report an accepted hit: exit planes are recomputed from
 // integer cell coordinates at every step (no accumulated error), and whenever the walk passes within
@@ -677,6 +701,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   const bool in_bounds = slab_box(o, d, inv_d, m.bmin, m.bmax, te, tx);
   PROF_LEAVE(P_SETUP);
   if (!in_bounds) return;
+  if (in_brick_plane<RT>(o, d)) return;
   PROF_ENTER(P_CAND);
   const int E = (int)m.extent;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, inv[3] = {inv_d.x, inv_d.y, inv_d.z};
@@ -1065,13 +1090,52 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
     for (uint32_t base = 0; base < n; base += 32u) {
       const uint32_t cnt = n - base < 32u ? n - base : 32u;
       ArgsRef a = reload_args(a_in);
+      uint64_t need;  // the rays this batch can still matter to
       {
         const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[base]);
         const float t_lo = __uint_as_float(c0 & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
         const bool settled = !active || (best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo;
-        if (__all(settled)) break;  // sorted by earliest entry: no later candidate matters either
+        need = __ballot(!settled);
+        if (need == 0ull) break;  // sorted by earliest entry: no later candidate matters either
       }
       uint32_t mask = 0;
+#if DUST_TRANSPOSE_RAYS > 0
+      // The scan below costs one trip per CANDIDATE whatever the number of rays that still want the batch -- and from the second batch on most
+      // rays of a packet are settled (a whole-sphere packet of cosine rays keeps 128 of the castle's 157 boxes: four batches, 121 trips for
+      // 3.7 visits per ray; a sun item has a third of its lanes active to begin with). With few rays left the scan is turned round: a lane
+      // holds a BOX (lane k and lane 32 + k: candidate k of the batch), the rays are taken two at a time -- lanes 0-31 test the first, lanes
+      // 32-63 the second: six cross-lane reads bring the ray over --, and one ballot is the two rays' masks. One trip per two rays.
+      // (settled rays get no mask: the pop loop below would drop theirs at its first candidate anyway)
+      if ((uint32_t)__popcll(need) <= (uint32_t)DUST_TRANSPOSE_RAYS) {
+        PROF_COUNT(P_N_CAND_ITER, (__popcll(need) + 1) >> 1);
+        const uint32_t lane = threadIdx.x & 63u, k = lane & 31u, half = lane >> 5;
+        const bool have = k < cnt;
+        const uint32_t ii = cand[base + (have ? k : 0u)] & 0xFFFFu;
+        f32x4 blo, bhi;
+        if (!LARGE && a.n_lds_boxes != 0) {  // (a large scene's LDS holds its group boxes)
+          const f32x4* lbox = reinterpret_cast<const f32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
+          blo = lbox[ii * 2u]; bhi = lbox[ii * 2u + 1u];
+        } else { blo = *(DUST_RO(f32x4))(&a.boxes[ii].lo[0]); bhi = *(DUST_RO(f32x4))(&a.boxes[ii].hi[0]); }
+        const float lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
+        for (uint64_t rest = need; rest != 0ull;) {
+          const uint32_t ra = (uint32_t)__builtin_ctzll(rest);
+          rest &= rest - 1ull;
+          const bool two = rest != 0ull;
+          const uint32_t rb = two ? (uint32_t)__builtin_ctzll(rest) : ra;
+          rest &= rest - 1ull;   // (0 & anything = 0 when there was no second ray)
+          const int src = (int)(half ? rb : ra);
+          const V3 ro = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+          const V3 ri = mk(__shfl(inv_d.x, src), __shfl(inv_d.y, src), __shfl(inv_d.z, src));
+          float te, tx;
+          bool box;
+          if (zero_axis) box = slab_box(ro, mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src)), ri, lo, hi, te, tx);
+          else box = slab_box_nonzero(ro, ri, lo, hi, te, tx);
+          const uint64_t bal = __ballot(box && have && (half == 0u || two));
+          if (lane == ra) mask = (uint32_t)bal;
+          if (two && lane == rb) mask = (uint32_t)(bal >> 32);
+        }
+      } else
+#endif
       for (uint32_t k = 0; k < cnt; ++k) {
         PROF_COUNT(P_N_CAND_ITER, 1);
         const uint32_t ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[base + k]) & 0xFFFFu;
@@ -1161,19 +1225,9 @@ __device__ void trace_ray(ArgsRef a_in, bool active, V3 o, V3 d, float tmin, flo
   PROF_LEAVE(P_TRACE_RAY);
 }
 
-// ------------------------------------------------------------------ incoherent rays: 64 independent ray lanes per wavefront
-// A packet of gather or surfel rays lasts as long as its longest ray: 15 loop trips for rays that need 2.9 on average, 19 %
-// of the lanes active inside the walk (round 2). Here a wavefront is 64 LANES that each carry one ray through a small state
-// machine -- fetch a ray, scan the candidate list, pop the nearest candidate and enter it, walk one cell per step, shade --
-// and every trip of the wave's loop runs the ONE phase most of its lanes are waiting in (ballot + popcount per state). A lane
-// whose ray is finished is shaded and refilled with the NEXT ray of the wave's work item while its neighbours walk on, so a
-// phase never runs for a handful of lanes while the rest idle, and the item's cull is shared by several packets' worth of rays.
-// What a ray computes is what trace_ray / trace_instance compute for it (walk_begin + walk_step are trace_instance's prologue
-// and loop body, verbatim); only which rays share a wavefront when changes -- never a result
-// (test_gi_does_not_depend_on_visiting_order_or_grouping runs both paths).
-#ifdef DUST_POOL_STATS
-static __device__ unsigned long long g_pool_stats[16];  // per phase: trips, lanes served (experiment builds only)
-#endif
+// ------------------------------------------------------------------ one ray per lane: a visit as a state a lane carries (k_ray_walk, gi.hip)
+// walk_begin + walk_step are trace_instance's prologue and loop body, verbatim: what a ray computes is what trace_ray / trace_instance
+// compute for it; only which rays share a wavefront when changes -- never a result.
 struct WalkState {          // one lane's visit of one instance
   V3 o, d, inv;             // object-space ray, inv = 1 / d (IEEE division: the intersection shader's reciprocal)
   float t, tx_stop, near_tol;
@@ -1213,6 +1267,7 @@ __device__ __forceinline__ bool walk_begin(WalkState& w, const Model& m, uint32_
   w.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   float te, tx;
   if (!slab_box(o, d, w.inv, m.bmin, m.bmax, te, tx)) return false;
+  if (in_brick_plane<RT>(o, d)) return false;
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   float t = fmaxf(te, 0.0f);
   if (RT >= 2) t = fmaxf(t, tmin * (1.0f - 1e-6f));
@@ -1309,137 +1364,6 @@ __device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevM
   w.screen = next_screen;
   w.t = fmaxf(w.t, tn);
   return w.t * (1.0f - 2e-6f) > w.tx_stop;
-}
-
-// The ray source of a work item: entries [begin, end) of some list. fetch() turns an entry into a ray (false: nothing to
-// trace for it, and nothing to shade); shade() consumes the finished ray. Both run on whatever lanes the scheduler hands them.
-enum : uint32_t { LS_IDLE = 0, LS_SCAN, LS_POP, LS_WALK, LS_DONE };
-constexpr uint32_t kScanBatch = 32;  // candidates per scan: one mask word per lane
-#ifndef DUST_REFILL_LANES
-#define DUST_REFILL_LANES 32
-#endif
-constexpr uint32_t kRefillLanes = DUST_REFILL_LANES;  // finished + empty lanes at which a wave stops tracing to shade and refill
-template <int RT, int MODE, class Src>
-__device__ void trace_pool(ArgsRef a_in, Src& src, uint32_t begin, uint32_t end, const uint32_t* cand, uint32_t ncand,
-                           float tmin, float tmax, bool any_hit, LaneStats& st) {
-  ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);
-  begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)begin);
-  end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t lower = (1ull << lane) - 1ull;
-  uint32_t next = begin;
-  uint32_t state = LS_IDLE, idx = 0;
-  V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv_w = mk(0, 0, 0);
-  float t_scene = INFINITY;
-  uint32_t base = 0, mask = 0;
-  Hit best;
-  best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
-  WalkState w;
-  w.o = w.d = w.inv = mk(0, 0, 0); w.t = w.tx_stop = w.near_tol = 0.0f; w.ijk[0] = w.ijk[1] = w.ijk[2] = 0;
-  w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0; w.inst = 0;
-  for (;;) {
-    const uint32_t n_walk = (uint32_t)__popcll(__ballot(state == LS_WALK)), n_pop = (uint32_t)__popcll(__ballot(state == LS_POP));
-    const uint32_t n_scan = (uint32_t)__popcll(__ballot(state == LS_SCAN)), n_done = (uint32_t)__popcll(__ballot(state == LS_DONE));
-    const uint64_t b_idle = __ballot(state == LS_IDLE);
-    const uint32_t n_fetch = min((uint32_t)__popcll(b_idle), end - next);
-    // Which phase runs this trip. Tracing first: of walk / pop / scan the one with the most lanes waiting (ties go to the
-    // walk, then to what feeds it). Finished rays are shaded -- and their lanes refilled -- only when that buys something:
-    // when half the wave is waiting for it and the item has rays left to hand out, or when nothing is left to trace
-    // (shading is the most expensive phase per trip, and it is as cheap for 64 lanes as for 6).
-    uint32_t pick = LS_WALK, most = n_walk;
-    if (n_pop > most) { pick = LS_POP; most = n_pop; }
-    if (n_scan > most) { pick = LS_SCAN; most = n_scan; }
-    const uint32_t n_free = n_done + (uint32_t)__popcll(b_idle);
-    if (most == 0u || (next < end && n_free >= kRefillLanes)) {
-      if (n_done) { pick = LS_DONE; most = n_done; }
-      else if (n_fetch) { pick = LS_IDLE; most = n_fetch; }
-    }
-    if (most == 0u) break;
-#ifdef DUST_POOL_STATS
-    if (lane == 0) { atomicAdd(&g_pool_stats[pick * 2], 1ull); atomicAdd(&g_pool_stats[pick * 2 + 1], (unsigned long long)most); }
-#endif
-    ArgsRef a = reload_args(a_in);
-    if (pick == LS_WALK) {
-      if (state == LS_WALK) {
-        const DUST_CONST_AS DevVisit& v = a.visits[w.inst];
-        if (walk_step<RT, MODE>(w, &v.m, tmin, tmax, any_hit, best, st)) state = LS_POP;
-      }
-    } else if (pick == LS_POP) {
-      if (state == LS_POP) {
-        // the lane's nearest remaining candidate of this batch, unless the ray is settled in front of it
-        uint32_t mine = 0xFFFFFFFFu;
-        if (mask != 0u) {
-          const uint32_t c = cand[base + (uint32_t)__builtin_ctz(mask)];
-          mask &= mask - 1u;
-          const float t_lo = __uint_as_float(c & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
-          if ((best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo) { mask = 0u; base = ncand; }
-          else mine = c & 0xFFFFu;
-        }
-        if (mine != 0xFFFFFFFFu) {
-          if (COUNT) st.instances_tested += 1;
-          const DUST_CONST_AS DevVisit& v = a.visits[mine];
-          if (walk_begin<RT, MODE>(w, v.m, mine, xform_point(v.w2o, o), xform_dir(v.w2o, d), tmin)) state = LS_WALK;
-        } else if (mask == 0u) {
-          state = LS_DONE;
-          if (base + kScanBatch < ncand) {  // sorted by earliest entry: a ray settled in front of the next batch's first candidate is done
-            const float t_lo = __uint_as_float(cand[base + kScanBatch] & 0xFFFF0000u) * (1.0f - 1e-5f) - 1e-4f;
-            if (!((best.found && (any_hit || best.t < t_lo)) || t_scene < t_lo)) { base += kScanBatch; state = LS_SCAN; }
-          }
-        }
-      }
-    } else if (pick == LS_SCAN) {
-      // one batch of the candidate list against the rays of the lanes that wait for it: the lowest such batch first (a
-      // uniform loop over its boxes -- scalar loads -- with one slab test per lane and box)
-      uint32_t b = state == LS_SCAN ? base : 0xFFFFFFFFu;
-#pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, sh));
-      b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-      const bool me = state == LS_SCAN && base == b;
-      const uint32_t cnt = ncand - b < kScanBatch ? ncand - b : kScanBatch;
-      const bool zero_axis = __any(me && (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f));
-      uint32_t found = 0;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t ii = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[b + k]) & 0xFFFFu;
-        const DUST_CONST_AS DevBox& bx = a.boxes[ii];
-        float lo[3], hi[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { lo[q] = bx.lo[q]; hi[q] = bx.hi[q]; }
-        float te, tx;
-        const bool box = zero_axis ? slab_box(o, d, inv_w, lo, hi, te, tx) : slab_box_nonzero(o, inv_w, lo, hi, te, tx);
-        found |= box ? 1u << k : 0u;
-      }
-      if (me) { mask = found; state = LS_POP; }
-    } else if (pick == LS_DONE) {
-      if (state == LS_DONE) {
-        if (COUNT && best.found) st.hits += 1;
-        src.shade(a, idx, o, d, best);
-        state = LS_IDLE;
-      }
-    } else {  // fetch: the idle lanes take the item's next entries, in lane order
-      const uint32_t rank = (uint32_t)__popcll(b_idle & lower);
-      const bool take = state == LS_IDLE && next + rank < end;
-      if (take) {
-        idx = next + rank;
-        best.found = false; best.t = tmax; best.inst = 0; best.block = 0; best.voxel = 0;
-        if (src.fetch(a, idx, o, d)) {
-          if (COUNT) st.rays += 1;
-          // world-space reciprocals feed only the conservative box tests (1e-5 slack): v_rcp_f32's 1 ulp is enough
-          inv_w = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-          t_scene = INFINITY;
-          if (ncand > 8u) {  // when the ray leaves the union of all instance boxes (lets sky-bound rays stop early)
-            float te_s, tx_s;
-            const bool in = slab_box(o, d, inv_w, a.world_min, a.world_max, te_s, tx_s);
-            t_scene = in ? tx_s * (1.0f + 1e-5f) + 1e-3f : -1.0f;
-          }
-          base = 0; mask = 0;
-          state = ncand ? LS_SCAN : LS_DONE;
-        } else {
-          src.skip(a, idx);  // (an entry without a ray: whatever its slot must hold is written now)
-        }
-      }
-      next = min(end, next + (uint32_t)__popcll(b_idle));
-    }
-  }
 }
 
 // ------------------------------------------------------------------ work distribution

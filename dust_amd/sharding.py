@@ -52,6 +52,28 @@ def balanced_cuts(strip_cost, world: int, height: int, align: int = 8):
     return cuts + [height]
 
 
+def rebalance_cuts(strip_cost, cuts, band_ms, world: int, height: int, align: int = 8):
+    """One round of proportional correction of cost-balanced cuts from MEASURED band-step times (a frame is done when its slowest band
+    is, and a tile-cost map taken from one whole-frame launch predicts a band's step under four frames in flight only to +-15 %: round 5's
+    N = 8 emulation had seven bands at 0.032-0.034 ms and one at 0.0425). The strips of band r keep their relative costs and are scaled
+    so that they add up to band_ms[r]; the cuts are then made again on the rescaled map. Returns (cuts, rescaled strip costs): feed the
+    map back in for the next round. A band without rows or without a time keeps its strips' costs."""
+    import numpy as np
+    n = -(-height // align)
+    c = np.asarray(strip_cost, np.float64).reshape(-1).copy() if strip_cost is not None else np.zeros(0)
+    if len(c) != n or not np.isfinite(c).all() or c.sum() <= 0:
+        c = np.ones(n)
+    c = c / c.sum()
+    c = c + 1e-3 / n
+    out = c.copy()
+    for r in range(world):
+        lo, hi = cuts[r] // align, -(-cuts[r + 1] // align)
+        t = float(band_ms[r]) if r < len(band_ms) else 0.0
+        if hi > lo and t > 0.0 and np.isfinite(t):
+            out[lo:hi] = c[lo:hi] * (t / c[lo:hi].sum())
+    return balanced_cuts(out, world, height, align), out
+
+
 def layout_from_cuts(rank: int, cuts, height: int, align: int = 8):
     """band_layout for bands of unequal height: (per_rows, (r0, r1), (s0, s1)) with per_rows the tallest band (a multiple of `align`)
     and the send slice [r0, r0 + per_rows) -- the band and whatever follows it in the rank's render target, which must therefore

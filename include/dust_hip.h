@@ -289,6 +289,10 @@ typedef struct DustHipFrameParams {
   uint32_t frame_index;  /* push constant frame_index (standard.rs:252,457-463) */
   uint32_t rand;         /* push constant rand (standard.rs:449-456) */
   uint32_t row_begin, row_end; /* rows of the frame this call renders (multi-GPU bands); 0,0 = all */
+  /* ---- appended in round 6 (a caller whose struct_size ends at row_end gets zeroes: the whole pool on this device) */
+  uint32_t surfel_rank, surfel_world; /* DUST_PASS_SURFEL | DUST_PASS_GI_SHARDED with surfel_world >= 1: this call runs the pool's ordering and
+                                  TRACES only rank surfel_rank's share of the position-ordered pool (see dust_hip_gi_surfel_exchange_run,
+                                  which completes the pass); surfel_world == 0: the whole pass, as before */
 } DustHipFrameParams;
 
 typedef struct DustHipPassStats {
@@ -314,7 +318,8 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const
  * kernels run beside it. It reads the scene and writes only the library-owned GI buffers; every library call that conflicts with
  * it (the next final gather, dust_hip_scene_commit, model edits, the GI state accessors) waits for it on the device, and
  * dust_hip_sync and every synchronous read-back wait for both streams -- a caller that orders its own work on the context's
- * stream (e.g. a collective that reads a bound plane) needs nothing more. DUST_HIP_NO_SIDE_STREAM=1 keeps the pass in place. */
+ * stream (e.g. a collective that reads a bound plane) needs nothing more. DustHipPipelineConfig.side_stream = DUST_SIDE_STREAM_OFF keeps
+ * the pass in place. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
 /* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
@@ -366,6 +371,14 @@ DustStatus dust_hip_pipeline_write_gi(DustHipPipeline*, uint32_t which, const vo
  *      gather read, commits the winning surfels to the pool, clears slot_owner
  *   6. dust_hip_render_frame(SURFEL [| ACCUMULATE] | DUST_PASS_GI_SHARDED, rows as in 1 for ACCUMULATE)
  * With DUST_PASS_GI_ORDERED in step 6 every rank's hash and pool stay bit-identical to the single-GPU run.
+ * Step 6 replicates the whole surfel pass on every rank -- 0.23 ms of the castle's 0.65 ms GI frame, which caps 8 ranks at 1.3-1.7 x.
+ * Round 6 shards its TRACE (85 % of the pass) as well; the trace only reads the hash (identical on every rank after step 5):
+ *   6a. dust_hip_render_frame(SURFEL | GI_ORDERED | GI_SHARDED [| ACCUMULATE], surfel_rank = r, surfel_world = N): orders the pool by
+ *       position (replicated: 50 us) and traces the slots [r S, (r + 1) S) of that order, S = ceil(groups / N) x 64 -- the records
+ *       {request 32 B, replacement 16 B, sun payload 16 B} go to staging arrays in SLOT order, a rank's share one contiguous run
+ *   6b. dust_hip_gi_surfel_exchange_run: all-gather of the three arrays (64 B per slot: 22 MB for 345 600 slots), then on every rank
+ *       the records move to their surfels, the trace's hash stamps are repeated, and the ordered apply runs (replicated: 30 us)
+ * -- bit-identical to the single-device ordered run again (tests/test_gpu_comm.py, test_gpu_gi_sharded.py).
  * dust_hip_pipeline_gi_exchange allocates (once) and returns the three device buffers the collectives run on;
  * padded_rows >= height is the row count of `touched` (world_size x band_rows).
  * A rank whose band lies past the end of the frame (small frames on many GPUs) skips steps 1 and the ACCUMULATE of 6 but still takes
@@ -418,6 +431,34 @@ DustStatus dust_hip_pipeline_clear(DustHipPipeline*);
  * 1/n of the slots, so that n frames' launches run side by side instead of each waiting behind the others' stragglers (row bands
  * of one frame on 8 GPUs, four in flight: 0.045 -> 0.037 ms per band). 1 (the default): a launch may take the whole device. 1..16. */
 DustStatus dust_hip_pipeline_set_frames_in_flight(DustHipPipeline*, uint32_t n);
+/* Everything that decides WHICH kernels a pipeline's frames run and on how much of the device -- what the reference's plugin takes as
+ * its settings (RenderPlugin, crates/render/src/lib.rs:35-56; the frames in flight of rhyolite_bevy/src/lib.rs:58). Defaults (a
+ * zeroed struct but for struct_size) are the production configuration; nothing here is read from the environment. May be called
+ * between any two frames: launches enqueued afterwards follow it. */
+#define DUST_GI_PATH_AUTO 0u     /* packets of 64 rays (k_final_gather, k_surfel_trace); the final gather of a scene that holds a 4096^3
+                                    tree as a ray stream (one ray per lane, lanes refilled: DESIGN.md section 4) */
+#define DUST_GI_PATH_PACKETS 1u  /* packets everywhere */
+#define DUST_GI_PATH_STREAMS 2u  /* both GI passes as ray streams (measured slower on scenes of many instances) */
+#define DUST_SIDE_STREAM_AUTO 0u /* the surfel pass on the context's second stream, beside the next frame's primary / AO kernel */
+#define DUST_SIDE_STREAM_OFF 1u  /* in place, on the context's stream */
+#define DUST_IN_FLIGHT_SHARE 0u  /* n frames in flight: every launch takes 1/n of the workgroup slots (row bands of an N-GPU frame) */
+#define DUST_IN_FLIGHT_ALL 1u    /* every launch asks for ALL slots: the next frame's workgroups start on the CUs the previous frame's tail
+                                    has left (whole frames on one GPU) */
+#define DUST_RESERVE_AUTO 0xFFFFFFFFu
+typedef struct DustHipPipelineConfig {
+  uint32_t struct_size;
+  uint32_t reserve_blocks;    /* workgroup slots (multiples of 8) the persistent traversal launches leave empty so that another queue's
+                                 kernels -- RCCL's send / receive -- can become resident beside them (they hold every VGPR of the SIMDs
+                                 they run on). DUST_RESERVE_AUTO (the default of dust_hip_pipeline_create): 0 until the pipeline takes part
+                                 in a collective of a communicator with world > 1, 32 from then on. A value the device cannot spare (it keeps 8 slots) is ignored */
+  uint32_t gi_path;           /* DUST_GI_PATH_* */
+  uint32_t side_stream;       /* DUST_SIDE_STREAM_* */
+  uint32_t side_share;        /* percent (5..90) of the slots the surfel pass takes on the second stream; 0 = calibrated from one timed frame */
+  uint32_t frames_in_flight;  /* 1..16, as dust_hip_pipeline_set_frames_in_flight; 0 = leave as it is */
+  uint32_t in_flight_slots;   /* DUST_IN_FLIGHT_* */
+} DustHipPipelineConfig;
+DustStatus dust_hip_pipeline_configure(DustHipPipeline*, const DustHipPipelineConfig*);
+DustStatus dust_hip_pipeline_get_config(const DustHipPipeline*, DustHipPipelineConfig* out /* struct_size set by the caller */);
 
 /* ===================================================================== multi-GPU: one process per GPU, RCCL over xGMI
  * The reference renders on one device; its plugin entry is where devices would be selected (crates/render/src/lib.rs:58-134).
@@ -462,6 +503,13 @@ DustStatus dust_hip_comm_sync(DustHipComm*);
  * shorter in the frame), dust_hip_gi_export(row_begin, row_end), all-reduce SUM of `merged`, dust_hip_gi_import(..., frame_index).
  * A rank whose band lies past the end of the frame passes (height, height). */
 DustStatus dust_hip_gi_exchange_run(DustHipPipeline*, DustHipComm*, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index);
+/* Step 6b of the protocol: completes a surfel pass whose trace was sharded (dust_hip_render_frame with surfel_world >= 1, the same
+ * world as the communicator's), on the context's stream: all-gather of the staged records (three ncclAllGather in one group; a loopback
+ * group copies), then -- replicated on every rank -- records to their surfels + the trace's hash stamps, and the apply of the hash inserts
+ * in surfel order (the deterministic apply of DUST_PASS_GI_ORDERED, whatever the frame asked for: every rank must end with the same hash).
+ * A NULL communicator completes the pass with no exchange (a world of one; one emulated rank, whose peers' records are whatever the
+ * staging arrays hold). DUST_ERR_NOT_READY without a sharded trace pending on the pipeline. */
+DustStatus dust_hip_gi_surfel_exchange_run(DustHipPipeline*, DustHipComm*, uint32_t frame_index);
 
 /* Device function evaluation: runs ONE of the device functions the traversal / shading kernels are built from on n
  * independent inputs (host arrays in, host arrays out, synchronous). The reference has no counterpart -- its shaders are

@@ -328,6 +328,14 @@ class StandardPipeline {
   void restart_denoiser() { check(dust_hip_pipeline_restart_denoiser(h_)); }
   // the host's frames in flight (rhyolite_bevy/src/lib.rs:58): launches then share the device instead of queueing
   void set_frames_in_flight(uint32_t n) { check(dust_hip_pipeline_set_frames_in_flight(h_, n)); }
+  // the plugin's settings for this pipeline (RenderPlugin, crates/render/src/lib.rs:35-56): read, change the fields of interest, write back
+  DustHipPipelineConfig config() const {
+    DustHipPipelineConfig c{};
+    c.struct_size = sizeof c;
+    check(dust_hip_pipeline_get_config(h_, &c));
+    return c;
+  }
+  void configure(const DustHipPipelineConfig& c) { check(dust_hip_pipeline_configure(h_, &c)); }
   void bind_plane(DustHipPlane plane, void* device_ptr, size_t bytes) { check(dust_hip_pipeline_bind_plane(h_, plane, device_ptr, bytes)); }
   template <class T>
   std::vector<T> read_plane(DustHipPlane plane) {
@@ -370,13 +378,21 @@ class DeviceComm {
   ~DeviceComm() { dust_hip_comm_destroy(h_); }
   DeviceComm(const DeviceComm&) = delete;
   // rows [cuts[r], cuts[r+1]) of `plane` from every rank r to `root` (its own plane when dst is null)
+  // (the library reads cuts[0..world]: a shorter vector would be an out-of-bounds host read)
+  void check_cuts(const std::vector<uint32_t>& cuts) const {
+    uint32_t world = 0;
+    check(dust_hip_comm_info(h_, nullptr, &world, nullptr));
+    if (cuts.size() != size_t(world) + 1) throw Error(DUST_ERR_INVALID_ARGUMENT, "band cuts: want world + 1 row indices");
+  }
   uint64_t gather_bands(StandardPipeline& p, DustHipPlane plane, const std::vector<uint32_t>& cuts, uint32_t root, void* dst = nullptr, size_t dst_bytes = 0) {
+    check_cuts(cuts);
     uint64_t ticket = 0;
     check(dust_hip_gather_bands(p.raw(), h_, plane, cuts.data(), root, dst, dst_bytes, &ticket));
     return ticket;
   }
   // several planes (bit i of the mask = DustHipPlane i) in one collective, each into the root pipeline's own plane
   uint64_t gather_planes(StandardPipeline& p, uint32_t plane_mask, const std::vector<uint32_t>& cuts, uint32_t root) {
+    check_cuts(cuts);
     uint64_t ticket = 0;
     check(dust_hip_gather_planes(p.raw(), h_, plane_mask, cuts.data(), root, &ticket));
     return ticket;
@@ -384,6 +400,7 @@ class DeviceComm {
   void gi_exchange(StandardPipeline& p, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t frame_index) {
     check(dust_hip_gi_exchange_run(p.raw(), h_, row_begin, row_end, band_rows, frame_index));
   }
+  void gi_surfel_exchange(StandardPipeline& p, uint32_t frame_index) { check(dust_hip_gi_surfel_exchange_run(p.raw(), h_, frame_index)); }
   void wait(uint64_t ticket = 0) { check(dust_hip_comm_wait(h_, ticket)); }
   void sync() { check(dust_hip_comm_sync(h_)); }
   DustHipComm* raw() const { return h_; }

@@ -42,9 +42,11 @@ class StubPipe:
     def set_frames_in_flight(self, n): self.calls.append(("in_flight", n))
     def configure_gi(self, *a): self.calls.append("configure_gi")
     def clear(self): self.calls.append("clear")
-    def render(self, scene, cam, sky, passes, frame_index=1, rand=0, rows=(0, 0)):
+    def render(self, scene, cam, sky, passes, frame_index=1, rand=0, rows=(0, 0), surfel_shard=(0, 0)):
         r0, r1 = rows if rows[1] else (0, H)
         self.n_render += 1
+        if surfel_shard[1]:
+            self.calls.append(("surfel_shard",) + tuple(surfel_shard))
         self.last = {"passes": passes, "rows": (r0, r1), "frame": frame_index}
         if passes == L.PASS_DENOISE:
             self.calls.append(("denoise", frame_index, (r0, r1)))
@@ -104,6 +106,7 @@ class StubComm:
         return self.gather_bands(pipe, L.PLANE_ILLUMINANCE, cuts, root)
     def wait(self, ticket=0): StubComm.log.append(("wait", ticket))
     def sync(self): StubComm.log.append(("sync",))
+    def gi_surfel_exchange(self, pipe, frame_index): StubComm.log.append(("gi_surfel_exchange", frame_index))
     def gi_exchange(self, pipe, r0, r1, band_rows, frame_index):
         StubComm.log.append(("gi_exchange", r0, r1, band_rows, frame_index))
         pipe.gi_export(r0, r1)
@@ -186,6 +189,8 @@ if rank == 0:
         assert all(c[1] > 0 for c in StubComm.log if c[0] == "wait")
         if gi:
             assert ("gi_exchange", 0, 24, 24, 1) in StubComm.log, StubComm.log[:8]
+            # the surfel trace sharded over the two ranks, completed by the library's all-gather + apply, once per frame
+            assert ("surfel_shard", 0, 2) in calls and ("gi_surfel_exchange", 1) in StubComm.log and "sharded" in strong["parallelism"], strong["parallelism"]
     else:
         assert "torch.distributed" in strong["collectives"], strong
     print("BENCH_RANKS_OK", json.dumps(out)[:200])

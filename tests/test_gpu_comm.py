@@ -91,10 +91,13 @@ def test_loopback_refuses_what_a_collective_cannot_be():
         comms[0].gather_bands(q, L.PLANE_DEPTH, [0, 16, 32])          # a pipeline of another context
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_loopback_gi_exchange_equals_single_device(world):
+@pytest.mark.parametrize("world,shard_trace", [(2, False), (3, False), (2, True), (3, True), (8, True)])
+def test_loopback_gi_exchange_equals_single_device(world, shard_trace):
     """dust_hip_gi_exchange_run (all-reduce MAX, all-gather, export, all-reduce SUM, import inside the library) drives the sharded GI
-    frame of test_gpu_gi_sharded.py: every rank's hash, pool and band equal the single-pipeline run bit for bit."""
+    frame of test_gpu_gi_sharded.py: every rank's hash, pool and band equal the single-pipeline run bit for bit.
+    shard_trace (round 6): the surfel TRACE is sharded too -- rank r traces slots [r S, (r + 1) S) of the position-ordered pool into slot-ordered
+    staging arrays, dust_hip_gi_surfel_exchange_run all-gathers them, repeats the trace's hash stamps and applies in surfel order: still
+    the single-device hash and pool, bit for bit (the pool size 776 leaves the last of 8 ranks a short share, 13 groups over 8 ranks)."""
     W, H = 192, 104
     cap, pool = 16384, 97 * 8
     ctx = api.Context(device=0)
@@ -123,7 +126,12 @@ def test_loopback_gi_exchange_equals_single_device(world):
         for r, p in enumerate(ranks):
             comms[r].gi_exchange(p, bands[r][0], bands[r][1], per, frame)
         for r, p in enumerate(ranks):
-            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
+            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd, surfel_shard=(r, world) if shard_trace else (0, 0))
+        if shard_trace:
+            with pytest.raises(L.DustError):   # a pending trace must be completed before the pipeline's next GI pass
+                ranks[0].render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd, surfel_shard=(0, world))
+            for r, p in enumerate(ranks):
+                comms[r].gi_surfel_exchange(p, frame)
         ctx.sync()
         h_ref, s_ref = ref.read_gi()
         ill_ref = ref.read_plane(L.PLANE_ILLUMINANCE)

@@ -207,3 +207,42 @@ def test_degenerate_cameras_and_transforms_neither_hang_nor_fault():
     again.render(scene, base, sky, GI, frame_index=1, rand=5)
     for x, y in zip(want, _planes(again)):
         assert np.array_equal(x, y)
+
+
+def test_pipeline_config_round_trips_and_changes_no_result(monkeypatch):
+    """DustHipPipelineConfig (round 6): the production knobs arrive through the C ABI, not the environment. What is set is what is read
+    back; out-of-range fields are refused and leave the pipeline as it was; and none of them changes a result -- GI frames with both
+    passes as ray streams, with slots reserved, with the surfel pass in place and with every launch asking for all slots while
+    'three frames are in flight' give the planes, hash and pool of the default configuration, bit for bit."""
+    for k in ("DUST_HIP_RAY_STREAM", "DUST_HIP_PACKET_GI", "DUST_HIP_NO_SIDE_STREAM", "DUST_HIP_SIDE_SHARE", "DUST_HIP_RESERVE_BLOCKS"):
+        monkeypatch.delenv(k, raising=False)
+    desc = P.small_scene(seed=21, n_models=3, n_instances=7)
+    cam, sky = P.camera_for((90.0, 60.0, -80.0)), P.sky_state()
+    ctx = api.Context(device=0)
+    scene = P.hip_scene(ctx, desc)
+    pipe = _pipe(ctx, 136, 72, gi=True)
+    assert pipe.get_config() == {"reserve_blocks": "auto", "gi_path": "auto", "side_stream": "auto", "side_share": 0, "frames_in_flight": 1,
+                                 "in_flight_slots": "share"}
+    pipe.configure(reserve_blocks=40, gi_path="streams", side_stream="off", side_share=30, frames_in_flight=3, in_flight_slots="all")
+    assert pipe.get_config() == {"reserve_blocks": 40, "gi_path": "streams", "side_stream": "off", "side_share": 30, "frames_in_flight": 3,
+                                 "in_flight_slots": "all"}
+    for bad in ({"gi_path": 3}, {"side_stream": 2}, {"side_share": 3}, {"side_share": 95}, {"frames_in_flight": 17}, {"in_flight_slots": 2}):
+        with pytest.raises(L.DustError):
+            pipe.configure(**bad)
+    assert pipe.get_config()["gi_path"] == "streams" and pipe.get_config()["reserve_blocks"] == 40
+    small = L.PipelineConfig(4)   # a struct_size below this library's: refused, nothing read
+    assert ctx._lib.dust_hip_pipeline_configure(pipe._h, small) == L.ERR_INVALID_ARGUMENT
+    outs = []
+    for cfg in ({}, {"gi_path": "streams"}, {"gi_path": "packets", "reserve_blocks": 32, "side_stream": "off"},
+                {"frames_in_flight": 3, "in_flight_slots": "all", "side_share": 25}, {"frames_in_flight": 2, "in_flight_slots": "share"},
+                {"reserve_blocks": 100000}):   # (more slots than the device has: the launch keeps what it needs)
+        p_ = _pipe(ctx, 136, 72, gi=True)
+        p_.configure(**cfg)
+        for f in range(1, 5):
+            p_.render(scene, cam, sky, GI, frame_index=f, rand=synth.frame_rand(4, f))
+        outs.append((_planes(p_), p_.read_gi()))
+    assert int((outs[0][1][0][:, 0] != 0).sum()) > 20
+    for planes, (h, sp) in outs[1:]:
+        for x, y in zip(outs[0][0], planes):
+            assert np.array_equal(x, y)
+        assert np.array_equal(outs[0][1][0], h) and outs[0][1][1].tobytes() == sp.tobytes()

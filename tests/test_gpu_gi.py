@@ -116,7 +116,7 @@ def test_surfel_position_sort_only_regroups(monkeypatch):
 
 
 _SWITCHES = ("DUST_HIP_DEBUG", "DUST_HIP_NO_GATHER_ORDER", "DUST_HIP_NO_SURFEL_SORT", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
-             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RAY_LANES", "DUST_HIP_RAY_STREAM", "DUST_HIP_NO_STREAM_LDS",
+             "DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RAY_STREAM", "DUST_HIP_NO_STREAM_LDS",
              "DUST_HIP_STREAM_REFILL")
 
 
@@ -155,16 +155,15 @@ def test_gi_does_not_depend_on_visiting_order_or_grouping(monkeypatch):
     visited in (sorted candidate list vs index order, DUST_HIP_DEBUG bit 4; every lane on its own instance vs the whole
     wave on one, bit 8) nor of which rays share a wavefront
     (octant-ordered gather packets, position-ordered surfels), which wave traces which tile when (cost-ordered hand-out), where
-    the cull reads its boxes from, the launch shape, or whether gather rays run a packet at a time or as refilled ray lanes
-    (DUST_HIP_RAY_LANES: a lane shades its finished ray and takes the work item's next one while its neighbours walk on), or
-    as ray streams (DUST_HIP_RAY_STREAM: every ray finds its instances in the top-level grid and is walked on a lane of its own).
+    the cull reads its boxes from, the launch shape, or whether the GI rays run a packet at a time or as ray streams
+    (gi_path = streams, spelled DUST_HIP_RAY_STREAM for the Python shim: every ray finds its instances in the top-level grid and is
+    walked on a lane of its own).
     Caught a build whose out-of-line neighbour visit passed the
     hit record through the stack and then resolved such ties differently."""
     _, _, _, _, _, st = _castle_gi_states(monkeypatch, [{}, {"DUST_HIP_DEBUG": "4"}, {"DUST_HIP_DEBUG": "8"}, {"DUST_HIP_NO_GATHER_ORDER": "1"},
                                                        {"DUST_HIP_NO_GATHER_ORDER": "1", "DUST_HIP_NO_SURFEL_SORT": "1", "DUST_HIP_DEBUG": "4"},
                                                        {"DUST_HIP_NO_TILE_ORDER": "1", "DUST_HIP_NO_LDS_BOXES": "1"},
                                                        {"DUST_HIP_BLOCK": "256", "DUST_HIP_BLOCKS_PER_CU": "1"},
-                                                       {"DUST_HIP_RAY_LANES": "1"}, {"DUST_HIP_RAY_LANES": "1", "DUST_HIP_DEBUG": "4"},
                                                        # the passes as ray streams (gi.hip: binned per ray over the top-level grid, one ray per lane):
                                                        # top-level data in LDS / in memory, lanes refilled one by one / only when all are done
                                                        {"DUST_HIP_RAY_STREAM": "1"}, {"DUST_HIP_RAY_STREAM": "1", "DUST_HIP_NO_STREAM_LDS": "1", "DUST_HIP_STREAM_REFILL": "1"},
@@ -330,34 +329,3 @@ def test_clustered_apply_equals_serial_apply(monkeypatch):
         assert (states[0][0][:, 0] != 0).sum() > 100
         for x, y in zip(*states):
             assert np.array_equal(x, y), capacity
-
-
-def test_split_gather_equals_the_fused_one(monkeypatch):
-    """DUST_HIP_GATHER_SPLIT: the final gather as a trace-only kernel (hit records) + a shading pass in pixel order -- what the gather
-    rays find and what the shading does with it are the same operations, so every plane, the hash and the pool are bit-identical."""
-    desc = P.small_scene(seed=12, n_models=3, n_instances=6, size=(28, 28, 28))
-    sky, cam = P.sky_state(), P.camera_for((80.0, 60.0, 90.0))
-    w, h = 136, 72
-    n0, n5 = synth.stbn_scalar(layers=4), synth.stbn_unitvec3_cosine(layers=4)
-    passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION | L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_GI_ORDERED
-    outs = []
-    for env in (None, "DUST_HIP_GATHER_SPLIT", "DUST_HIP_GATHER_JOIN_FIRST"):
-        if env:
-            monkeypatch.setenv("DUST_HIP_GATHER_SPLIT", "1")
-            monkeypatch.setenv(env, "1")
-        ctx = api.Context(device=0)
-        scene = P.hip_scene(ctx, desc)
-        pipe = api.StandardPipeline(ctx, w, h)
-        pipe.set_noise(0, n0)
-        pipe.set_noise(5, n5)
-        pipe.configure_gi(4099, 512)
-        for f in range(1, 6):
-            pipe.render(scene, cam, sky, passes, frame_index=f, rand=synth.frame_rand(2, f))
-        outs.append((P.read_hip_gbuffer(pipe), pipe.read_gi()))
-        monkeypatch.delenv("DUST_HIP_GATHER_SPLIT", raising=False)
-        monkeypatch.delenv("DUST_HIP_GATHER_JOIN_FIRST", raising=False)
-    for g, (hh, sp) in outs[1:]:
-        for k in outs[0][0]:
-            assert outs[0][0][k].tobytes() == g[k].tobytes(), k
-        assert np.array_equal(outs[0][1][0], hh) and outs[0][1][1].tobytes() == sp.tobytes()
-    assert int((outs[0][1][0][:, 0] != 0).sum()) > 20

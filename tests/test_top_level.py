@@ -128,3 +128,24 @@ def test_bad_arguments_are_refused():
     stack = np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (4200, 1))
     with pytest.raises(L.DustError):
         api.top_level_build(stack)
+
+
+def test_an_elongated_scene_of_long_boxes_ends_in_one_cell_instead_of_spinning():
+    """The coarsening loop of build_grid halves the density until the item list fits a cell word's 20 index bits. A corridor (aspect
+    1000 : 1 : 1) of boxes that each span its length never got there: density x n <= 1 clamps the target to ONE cell, but the dims come
+    from ext / cbrt(V) and stay (100, 1, 1) -- stationary state, 2 M items, a host hang in dust_hip_scene_commit (round 5's advisor).
+    The loop now notices that its dims no longer change, forces one cell, and reports what that cell cannot list (more than 4095 boxes)."""
+    import time
+    from dust_amd import _lib as L
+    n = 20000
+    rng = np.random.default_rng(9)
+    yz = rng.uniform(0.0, 0.9, (n, 2))
+    b = np.concatenate([np.zeros((n, 1)), yz, np.full((n, 1), 1000.0), yz + 0.1], axis=1).astype(np.float32)
+    t0 = time.time()
+    with pytest.raises(L.DustError) as e:
+        api.top_level_build(b)
+    assert e.value.status == L.ERR_UNSUPPORTED and time.time() - t0 < 60
+    # the same corridor with few enough boxes for one cell: a grid comes back, one cell or a few, every box listed
+    t = api.top_level_build(b[:3000])
+    first, count = t["cells"] & ((1 << 20) - 1), t["cells"] >> 20
+    assert count.sum() == len(t["items"]) < (1 << 20) and count.max() <= 4095

@@ -21,17 +21,16 @@ from dust_amd import _lib as L, api, synth  # noqa: E402
 def random_switches(rng):
     """a random combination of the library's diagnostic switches (read when a pipeline is created) and a context of its own with a
     random LDS budget for staged roots"""
-    for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM", "RAY_LANES",
-                 "EQUAL_BANDS", "NO_DILATE", "NO_WIDE_FUSED", "FORCE_MOVING", "DILATE_STILL", "GATHER_SPLIT", "GATHER_JOIN_FIRST",   # (round 4: the hand-out's new knobs)
-                 "RAY_STREAM", "NO_STREAM_LDS", "FLAT_CULL", "PACKET_GI"):   # (round 5: the GI passes as ray streams, the cull's hierarchy off)
+    for name in ("NO_FUSE", "NO_TILE_ORDER", "NO_GATHER_ORDER", "NO_SURFEL_SORT", "NO_LDS_BOXES", "NO_SIDE_STREAM",
+                 "EQUAL_BANDS", "NO_DILATE", "NO_WIDE_FUSED", "FORCE_MOVING",   # (round 4: the hand-out's knobs)
+                 "RAY_STREAM", "NO_STREAM_LDS", "FLAT_CULL", "PACKET_GI"):   # (round 5: the GI passes as ray streams, the cull's hierarchy off;
+                                                                             #  RAY_STREAM / PACKET_GI / NO_SIDE_STREAM reach the library through api.StandardPipeline's config)
         os.environ.pop("DUST_HIP_" + name, None)
         if rng.random() < 0.3:
             os.environ["DUST_HIP_" + name] = "1"
     os.environ.pop("DUST_HIP_BLOCK", None)
     if rng.random() < 0.6:   # (unset: the fused kernel may take the 1024-thread shape)
         os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([128, 256, 512])))
-    os.environ["DUST_HIP_COST_KEEP_SHIFT"] = str(int(rng.choice([0, 1, 3])))
-    os.environ["DUST_HIP_MOVING_REFRESH"] = str(int(rng.choice([1, 2, 4])))
     os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
     os.environ["DUST_HIP_STREAM_REFILL"] = str(int(rng.choice([1, 8, 16, 48, 64])))
     os.environ["DUST_HIP_GRID_DENSITY"] = str(float(rng.choice([0.01, 1.0, 12.0, 100.0])))
