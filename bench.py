@@ -328,6 +328,8 @@ def measure_curve(be, dist, args, lanes, shard):
     passes = L.PASS_PRIMARY | L.PASS_AMBIENT_OCCLUSION
     if gi_mode:  # diffuse GI through the surfel-fed spatial hash
         passes |= L.PASS_FINAL_GATHER | L.PASS_SURFEL | L.PASS_ACCUMULATE
+        if os.environ.get("DUST_BENCH_GI_ORDERED"):   # (diagnostic: one GPU with the deterministic apply an N-rank job needs)
+            passes |= L.PASS_GI_ORDERED
     bands = shard == "bands"
     denoise = bool(getattr(args, "denoise", False)) and not gi_mode
     if denoise and world == 1:

@@ -187,6 +187,10 @@ DustStatus run_local_gi(LocalGroup& g, hipStream_t st) {
     DUST_TRY(dust_internal::gi_exchange_view(g.calls[r].pipe, W * c0.band_rows, &ex[r]));
     if (ex[r].pool_size != ex[0].pool_size || ex[r].width != ex[0].width) return set_error(DUST_ERR_INVALID_ARGUMENT, "the ranks' GI buffers differ in size");
   }
+  if (W == 1) {   // a group of one (an emulated rank, a world-1 job): nothing to reduce or gather, and no wait
+    DUST_TRY(dust_hip_gi_export(g.calls[0].pipe, g.calls[0].row_begin, g.calls[0].row_end));
+    return dust_hip_gi_import(g.calls[0].pipe, g.calls[0].row_begin, g.calls[0].row_end, c0.frame_index);
+  }
   // the pointer tables the reduction kernels read (uploaded from `host`, which the wait below keeps alive until the copy is done)
   void** table = nullptr;
   HIP_TRY(hipMalloc(&table, sizeof(void*) * W * 2));
