@@ -405,6 +405,7 @@ struct Tuning {
   uint32_t side_prio = 3;       // issue priority floor of the surfel pass on the second stream
   uint32_t stream_refill = 16;  // STREAM_REFILL, STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
   uint32_t stream_top_iters = 8;
+  uint32_t in_flight_oversub = 0;  // IN_FLIGHT_OVERSUB (percent)
   bool no_stream_lds = false;   // NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
   bool packet_gi() const { return gi_path != DUST_GI_PATH_STREAMS; }    // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace)
   bool packet_only() const { return gi_path == DUST_GI_PATH_PACKETS; }  // ... even where the streams are the default
@@ -435,6 +436,7 @@ struct Tuning {
     t.dilate = !flag("NO_DILATE");
     t.wide_fused = !flag("NO_WIDE_FUSED") && !flag("BLOCK");
     t.force_moving = flag("FORCE_MOVING");
+    t.in_flight_oversub = std::min(100u, num("IN_FLIGHT_OVERSUB", 0));
     return t;
   }
 };
@@ -470,6 +472,7 @@ struct DustHipPipeline {
   DeviceBuffer exposure;  // Histogram {u32 histogram[256]; f32 avg} (auto_exposure.playout)
   // hash-fed GI state (standard.rs:334-358): spatial hash, surfel pool, per-frame scratch
   DeviceBuffer gi_hash, gi_pool, gi_owner, gi_pixel_surfel, gi_requests, gi_replacement, gi_sun_payload;
+  DeviceBuffer gi_apply_alive, gi_apply_dead;  // the deterministic apply's marks (k_surfel_apply_mark)
   DeviceBuffer gi_sort_keys[2], gi_sort_vals[2], gi_sort_scratch;  // radix sort ping-pong (position order of the pool, then the apply order)
   DeviceBuffer gi_fg_hits;  // per pixel: the hit record of its gather ray (k_ray_stream / k_final_gather -> k_final_gather_shade)
   // ray streams (gi.hip): the compacted rays of the two GI passes, the surfel rays' hit records, and per pass two ray counters used in turn
@@ -1746,9 +1749,14 @@ static DustStatus ensure_stream_buffers(DustHipPipeline* p, bool gather, bool su
 static DustStatus apply_ordered(DustHipPipeline* p, dust::FrameArgs& b, hipStream_t st) {
   uint32_t* sk[2] = {static_cast<uint32_t*>(p->gi_sort_keys[0].p), static_cast<uint32_t*>(p->gi_sort_keys[1].p)};
   uint32_t* sv[2] = {static_cast<uint32_t*>(p->gi_sort_vals[0].p), static_cast<uint32_t*>(p->gi_sort_vals[1].p)};
-  if (p->tune.debug & 16u) { HIP_TRY(dust::launch_surfel_apply(b, 1, st)); return DUST_OK; }
+  // keys -> sort by hash location -> marks (which requests the frame applies: k_surfel_apply_mark) -> the apply, parallel over clusters
+  // or (DUST_HIP_DEBUG bit 16) the serial loop in surfel order it is checked against
   b.gi.sort_keys = sk[0];
   b.gi.sort_vals = sv[0];
+  b.apply_alive = static_cast<unsigned long long*>(p->gi_apply_alive.p);
+  b.apply_dead = static_cast<uint8_t*>(p->gi_apply_dead.p);
+  b.apply_words = (p->gi_pool_size + 63u) / 64u;
+  b.apply_starts = b.apply_alive + b.apply_words + 1;
   HIP_TRY(dust::launch_surfel_apply(b, 2, st));
   uint32_t bits = 1;
   while ((1ull << bits) <= uint64_t(p->gi_capacity)) ++bits;  // locations 0 .. capacity (capacity itself = "no insert")
@@ -1756,7 +1764,8 @@ static DustStatus apply_ordered(DustHipPipeline* p, dust::FrameArgs& b, hipStrea
   HIP_TRY(dust::radix_sort_pairs(p->gi_sort_scratch.p, sk[0], sv[0], sk[1], sv[1], p->gi_pool_size, bits, &in_b, st));
   b.gi.apply_keys = sk[in_b ? 1 : 0];
   b.gi.apply_vals = sv[in_b ? 1 : 0];
-  HIP_TRY(dust::launch_surfel_apply(b, 3, st));
+  HIP_TRY(dust::launch_surfel_apply(b, 4, st));
+  HIP_TRY(dust::launch_surfel_apply(b, (p->tune.debug & 16u) ? 1 : 3, st));
   return DUST_OK;
 }
 // shard_world >= 1: the trace of rank shard_rank's share of the ordered pool only, records staged in slot order, nothing applied
@@ -2022,7 +2031,8 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   // (DUST_IN_FLIGHT_ALL: every launch asks for all of them -- whole frames one behind the other on two or three streams: the next frame's
   //  workgroups become resident on the CUs the previous frame's last tiles have left)
   const bool share_slots = p->frames_in_flight > 1 && tune.in_flight_slots == DUST_IN_FLIGHT_SHARE;
-  const uint32_t frame_slots = share_slots ? std::max(8u, (main_resident / p->frames_in_flight) & ~7u) : main_resident;
+  // (diagnostic IN_FLIGHT_OVERSUB = percent: each of the n launches asks for that much more than its 1/n -- the extra workgroups wait for a slot)
+  const uint32_t frame_slots = share_slots ? std::min(main_resident, std::max(8u, ((main_resident / p->frames_in_flight) * (100u + tune.in_flight_oversub) / 100u) & ~7u)) : main_resident;
   const uint32_t grid = std::max(8u, std::min<uint32_t>(frame_slots, (total_tiles + 7) / 8));
   {  // FNV-1a over what decides a tile's cost
     uint64_t k = 1469598103934665603ull;
@@ -2308,6 +2318,9 @@ DustStatus dust_hip_pipeline_configure_gi(DustHipPipeline* p, uint32_t hash_capa
   HIP_TRY(p->gi_sun_payload.alloc(size_t(surfel_pool_size) * 16));
   for (DeviceBuffer* b : {&p->gi_sort_keys[0], &p->gi_sort_keys[1], &p->gi_sort_vals[0], &p->gi_sort_vals[1]}) HIP_TRY(b->alloc(size_t(surfel_pool_size) * 4));
   HIP_TRY(p->gi_sort_scratch.alloc(dust::radix_sort_scratch_bytes(surfel_pool_size)));
+  HIP_TRY(p->gi_apply_alive.alloc(((size_t(surfel_pool_size) + 63) / 64 + 1) * 8 * 3));   // alive, cluster starts, run starts
+  HIP_TRY(p->gi_apply_dead.alloc(size_t(surfel_pool_size)));
+  HIP_TRY(hipMemsetAsync(p->gi_apply_dead.p, 0, size_t(surfel_pool_size), p->ctx->stream));
   // (the ray streams' buffers -- 48 B per pixel and more -- are made by the first frame that takes a stream path: ensure_stream_buffers)
   for (DeviceBuffer* b : {&p->gi_rays_fg, &p->gi_groups_fg, &p->gi_fg_hits, &p->gi_rays_sf, &p->gi_groups_sf, &p->gi_unbinned, &p->gi_hits_sf}) b->release();
   p->gi_capacity = hash_capacity;

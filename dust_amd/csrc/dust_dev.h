@@ -46,6 +46,7 @@ constexpr uint32_t kFlatCullMax = 256;   // instances up to which the packet cul
 constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
 constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
+constexpr uint32_t kApplyKeep = 8;  // DUST_PASS_GI_ORDERED: inserts of ONE key that a frame applies (the last kApplyKeep in surfel order; gi.hip, k_surfel_apply_mark)
 
 struct DevN4 {
   uint32_t mask_lo, mask_hi;
@@ -272,6 +273,13 @@ struct FrameArgs {
   DevSurfel* sf_stage_repl;
   float* sf_stage_sun;
   uint32_t sf_group_begin, sf_group_count;
+  // the deterministic apply's "superseded" marks (k_surfel_apply_mark): bit i of apply_alive = the request at position i of the
+  // location-sorted order is applied; apply_dead[j] = surfel j's request is not (the same fact by surfel index, for the serial loop)
+  unsigned long long* apply_alive;
+  uint8_t* apply_dead;
+  unsigned long long* apply_starts;   // [0, words): bit i = position i begins a CLUSTER (requests whose probe windows may overlap); [words, 2 words): bit i =
+                                      // position i begins a RUN of one location. A thread finds where its cluster and its runs end by scanning words, not keys
+  uint32_t apply_words;
 };
 
 }  // namespace dust

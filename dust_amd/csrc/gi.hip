@@ -513,14 +513,14 @@ __global__ void __launch_bounds__(64) k_surfel_apply_ordered(const FrameArgs) {
   for (uint32_t base = 0; base < a.gi.pool_size; base += 64u) {
     const uint32_t i = base + lane;
     bool work = false;
-    if (i < a.gi.pool_size) work = (a.gi.requests[i].dir_flags & 0x100u) || a.gi.replacement[i].direction != 0xFFFFFFFFu;
+    if (i < a.gi.pool_size) work = ((a.gi.requests[i].dir_flags & 0x100u) && !(a.apply_dead && a.apply_dead[i])) || a.gi.replacement[i].direction != 0xFFFFFFFFu;
     uint64_t mask = __ballot(work);
     if (lane == 0) {
       while (mask) {
         const uint32_t j = base + (uint32_t)__ffsll((long long)mask) - 1u;
         mask &= mask - 1ull;
         const DevHashRequest rq = a.gi.requests[j];
-        if (rq.dir_flags & 0x100u) {
+        if ((rq.dir_flags & 0x100u) && !(a.apply_dead && a.apply_dead[j])) {
           HashKey k;
           k.x = rq.kx; k.y = rq.ky; k.z = rq.kz; k.dir = rq.dir_flags & 0xFFu;
           const f32x4 sp = reinterpret_cast<const f32x4*>(a.gi.sun_payload)[j];  // radiance + sun term, as the shaders add them
@@ -553,20 +553,61 @@ __global__ void k_surfel_apply_keys(const FrameArgs) {  // hash location of ever
     if (r.direction != 0xFFFFFFFFu) a.gi.pool[j] = r;
   }
 }
+// Which requests a frame applies. Thousands of pixels' gather rays end on the same brick face, so thousands of surfels carry the SAME hash
+// key, and the serial definition -- every request, one after the other -- is a dependent chain of decode / blend / encode per key:
+// 0.27-0.43 ms for the castle's hottest faces (one thread, ~0.25 us per insert, 1 300 inserts), on EVERY rank of an N-GPU job, which
+// needs this mode to keep its replicated hashes identical. The reference's own shader does not apply them all either: invocations that
+// run together read the same entry and the last store wins (spatial_hash.glsl:147-195 claims only the fingerprint atomically). The
+// defined order here: sort the frame's requests by (hash location, surfel index); a request is SUPERSEDED when the request kApplyKeep
+// places further on has the same location and the same key -- of a run of one key, the last kApplyKeep (8) stay --; what stays is applied
+// in surfel-index order. A legal outcome of the race, the same on every rank and in the oracle (oracle/shade.c, surfel_apply), and
+// the chains are short: clusters 0.27 ms -> see docs/EXPERIMENTS.md round 6.
+// One thread per sorted position: bit i of apply_alive, byte vals[i] of apply_dead (every surfel index occurs once in vals).
+__global__ void __launch_bounds__(256) k_surfel_apply_mark(const FrameArgs) {
+  ArgsRef a = launch_args();
+  const uint32_t n = a.gi.pool_size, none = a.gi.hash_capacity;
+  const uint32_t rounded = (n + 63u) & ~63u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+    bool alive = false, cluster_start = true, run_start = true;   // (positions behind the end: boundaries, so that every scan stops there)
+    if (i < n) {
+      const uint32_t loc = a.gi.apply_keys[i], j = a.gi.apply_vals[i];
+      const uint32_t before = i > 0u ? a.gi.apply_keys[i - 1u] : 0u;
+      cluster_start = i == 0u || loc == none || loc - before > 2u;
+      run_start = i == 0u || loc != before;
+      alive = loc != none;
+      if (alive && i + kApplyKeep < n && a.gi.apply_keys[i + kApplyKeep] == loc) {
+        const u32x4 k0 = *reinterpret_cast<const u32x4*>(&a.gi.requests[j]);
+        const u32x4 k1 = *reinterpret_cast<const u32x4*>(&a.gi.requests[a.gi.apply_vals[i + kApplyKeep]]);
+        if (k0.x == k1.x && k0.y == k1.y && k0.z == k1.z && ((k0.w ^ k1.w) & 0xFFu) == 0u) alive = false;
+      }
+      a.apply_dead[j] = alive ? 0 : 1;
+    }
+    const uint64_t bal = __ballot(alive), bc = __ballot(cluster_start), br = __ballot(run_start);
+    if ((threadIdx.x & 63u) == 0) { a.apply_alive[i >> 6] = bal; a.apply_starts[i >> 6] = bc; a.apply_starts[a.apply_words + (i >> 6)] = br; }
+  }
+}
+// first applied position in [pos, end), or end
+__device__ __forceinline__ uint32_t next_alive(const unsigned long long* alive, uint32_t pos, uint32_t end) {
+  while (pos < end) {
+    const unsigned long long w = alive[pos >> 6] >> (pos & 63u);
+    if (w != 0ull) { pos += (uint32_t)__builtin_ctzll(w); return pos < end ? pos : end; }
+    pos = (pos | 63u) + 1u;
+  }
+  return end;
+}
 __shared__ uint32_t g_apply_slab[256][25];  // k_surfel_apply_clusters: a thread's staged probe windows (8 entries, padded to 25 words)
 __global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) {
   ArgsRef a = launch_args();
   const uint32_t n = a.gi.pool_size, none = a.gi.hash_capacity;
+  const unsigned long long* alive = a.apply_alive;
+  const unsigned long long* cstart = a.apply_starts;                  // cluster boundaries, run boundaries (k_surfel_apply_mark): a cluster of a
+  const unsigned long long* rstart = a.apply_starts + a.apply_words;  // thousand requests ends twenty words on, not a thousand dependent loads on
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!((cstart[i >> 6] >> (i & 63u)) & 1ull)) continue;  // not the first request of its cluster
     const uint32_t loc = a.gi.apply_keys[i];
     if (loc == none) continue;
-    if (i > 0 && loc - a.gi.apply_keys[i - 1] <= 2u) continue;  // not the first request of its cluster
-    uint32_t end = i + 1;
-    for (uint32_t prev = loc; end < n; ++end) {
-      const uint32_t next = a.gi.apply_keys[end];
-      if (next == none || next - prev > 2u) break;
-      prev = next;
-    }
+    // (clusters are cut on ALL requests, superseded ones included: a superset of what interacts; positions behind n are boundaries)
+    const uint32_t end = next_alive(cstart, i + 1u, (n + 63u) & ~63u);
     auto request = [&](uint32_t j, uint32_t& fp, V3& value) {
       const DevHashRequest rq = a.gi.requests[j];
       HashKey key;
@@ -583,20 +624,19 @@ __global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) 
       uint32_t* base = a.gi.hash + (size_t)loc * 3;
 #pragma unroll
       for (int k = 0; k < 9; ++k) win.w[k] = base[k];
-      // eight requests at a time: their (independent) loads are in flight together, then the eight inserts run as one chain
+      // eight applied requests at a time: their (independent) loads are in flight together, then the inserts run as one chain
       // of arithmetic on the register window
       constexpr uint32_t kBatch = 8;
-      for (uint32_t k0 = i; k0 < end; k0 += kBatch) {
+      for (uint32_t pos = next_alive(alive, i, end); pos < end;) {
+        uint32_t at[kBatch], cnt = 0;
+        while (cnt < kBatch && pos < end) { at[cnt++] = pos; pos = next_alive(alive, pos + 1u, end); }
         uint32_t fp[kBatch];
         V3 value[kBatch];
 #pragma unroll
-        for (uint32_t b = 0; b < kBatch; ++b) {
-          const uint32_t k = k0 + b < end ? k0 + b : end - 1u;
-          request(a.gi.apply_vals[k], fp[b], value[b]);
-        }
+        for (uint32_t b = 0; b < kBatch; ++b) request(a.gi.apply_vals[at[b < cnt ? b : cnt - 1u]], fp[b], value[b]);
 #pragma unroll
         for (uint32_t b = 0; b < kBatch; ++b)
-          if (k0 + b < end) hash_insert_window(win, fp[b], value[b], a.frame_index);
+          if (b < cnt) hash_insert_window(win, fp[b], value[b], a.frame_index);
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) base[k] = win.w[k];
@@ -610,9 +650,8 @@ __global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) 
     bool fits = true;
     for (uint32_t k = i; k < end;) {
       const uint32_t l = a.gi.apply_keys[k];
-      uint32_t e2 = k + 1;
-      while (e2 < end && a.gi.apply_keys[e2] == l) ++e2;
-      if (n_runs < kRuns) { run_at[n_runs] = k; run_end[n_runs] = e2; run_loc[n_runs] = l; }
+      const uint32_t e2 = next_alive(rstart, k + 1u, end);   // where the run of this location ends
+      if (n_runs < kRuns) { run_at[n_runs] = next_alive(alive, k, e2); run_end[n_runs] = e2; run_loc[n_runs] = l; }
       else fits = false;
       ++n_runs;
       k = e2;
@@ -626,17 +665,18 @@ __global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) 
       for (uint32_t k = 0; k < words; ++k) slab[k] = base[k];
       uint32_t head[kRuns];
 #pragma unroll
-      for (uint32_t r = 0; r < kRuns; ++r) head[r] = r < n_runs ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
-      for (uint32_t done = 0; done < end - i; ++done) {
+      for (uint32_t r = 0; r < kRuns; ++r) head[r] = (r < n_runs && run_at[r] < run_end[r]) ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
+      for (;;) {
         uint32_t best = 0;
 #pragma unroll
         for (uint32_t r = 1; r < kRuns; ++r) best = head[r] < head[best] ? r : best;
+        if (head[best] == 0xFFFFFFFFu) break;
         uint32_t j = 0, l = 0;
 #pragma unroll
         for (uint32_t r = 0; r < kRuns; ++r)
           if (r == best) {
             j = head[r]; l = run_loc[r];
-            run_at[r] += 1;
+            run_at[r] = next_alive(alive, run_at[r] + 1u, run_end[r]);
             head[r] = run_at[r] < run_end[r] ? a.gi.apply_vals[run_at[r]] : 0xFFFFFFFFu;
           }
         uint32_t fp;
@@ -649,14 +689,15 @@ __global__ void __launch_bounds__(256) k_surfel_apply_clusters(const FrameArgs) 
       for (uint32_t k = 0; k < words; ++k) base[k] = slab[k];
       continue;
     }
-    // anything wider: through memory, in ascending surfel index found by repeated minimum
+    // anything wider: through memory, in ascending surfel index found by repeated minimum over the applied requests
     uint32_t last = 0;
-    for (uint32_t done = 0; done < end - i; ++done) {
+    for (uint32_t done = 0;; ++done) {
       uint32_t j = 0xFFFFFFFFu, at = i;
-      for (uint32_t k = i; k < end; ++k) {
+      for (uint32_t k = next_alive(alive, i, end); k < end; k = next_alive(alive, k + 1u, end)) {
         const uint32_t v = a.gi.apply_vals[k];
         if ((done == 0 || v > last) && v < j) { j = v; at = k; }
       }
+      if (j == 0xFFFFFFFFu) break;
       last = j;
       uint32_t fp;
       V3 value;
@@ -862,6 +903,8 @@ __device__ __forceinline__ uint32_t bin_ray(ArgsRef a, const TopSource& src, boo
 }
 
 // RT 2: gather rays (rough.rint, closest hit), RT 3: surfel rays (closest hit, or any hit where DevRay::flags bit 0 is set).
+// (Round 6 also ran the PIXEL passes of a 4096^3 scene through this kernel -- camera rays as RT 0, the AO pass's sun and AO rays as RT 1, with
+// ray-making and shading kernels around them --: 4.32 ms against the fused packet kernel's 2.53, removed; docs/EXPERIMENTS.md.)
 // Statistics slots (counting build): rays without the any-hit flag -> stats[0] for RT 2 / stats[1] for RT 3, any-hit rays -> stats[0];
 // the rays that met no box never reach this kernel: the ray-making kernels counted them (gi.unbinned) and block 0 adds them here.
 template <int RT, int MODE>
@@ -870,6 +913,8 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
   // the workgroup's LDS: the roots (as stage_roots), behind them the enter records when they fit (FrameArgs::sl_walk)
   prof_begin();
   if (blockIdx.x == 0 && threadIdx.x < kRegions) a0.next_work_counters[threadIdx.x * kCounterStride] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a0.started_word)  // (dust_dev.h: a frame's first traversal launch tells the host it is running)
+    __hip_atomic_store((uint32_t*)a0.started_word, a0.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   copy16(g_lds, a0.root_table, a0.n_lds_models * kN16LdsBytes);
   if (a0.sl_walk.enters != 0xFFFFFFFFu) copy16(g_lds + a0.n_lds_models * kN16LdsBytes + a0.sl_walk.enters, a0.enters, a0.n_instances * (uint32_t)sizeof(DevEnter));
   __syncthreads();
@@ -896,7 +941,7 @@ __global__ void __launch_bounds__(1024, 4) k_ray_walk(const FrameArgs) {
   ts.cell = 0; ts.prev = kNoCell; ts.cur = ts.end = 0; ts.t_end = 0.0f;
   WalkState w;
   w.o = w.d = w.inv = mk(0, 0, 0); w.t = w.tx_stop = w.near_tol = 0.0f; w.ijk[0] = w.ijk[1] = w.ijk[2] = 0;
-  w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0; w.inst = 0;
+  w.stepped = 0; w.cl_main = 2; w.steps = 0; w.screen = false; w.prev_whole = false; midcache_reset(w.mc); w.inst = 0;
   w.lds_slot = -1; w.extent = 0; w.root = nullptr; w.dense_mask = nullptr;
   LaneStats cur = {0, 0, 0, 0, 0, 0}, st_closest = {0, 0, 0, 0, 0, 0}, st_any = {0, 0, 0, 0, 0, 0};
   TopSource memsrc;  // (a ray with more candidates than its record holds walks the grid itself, out of memory: rare)
@@ -1229,11 +1274,12 @@ hipError_t launch_surfel_trace(const FrameArgs& a_in, uint32_t grid, uint32_t bl
   return hipGetLastError();
 }
 // mode 0: concurrent (racy, as the reference); 1: serial in surfel order (one wavefront); 2: keys for the clustered apply;
-// 3: the clustered apply itself (after the sort)
+// 3: the clustered apply itself (after the sort and the marks); 4: the marks (after the sort)
 hipError_t launch_surfel_apply(const FrameArgs& a, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_surfel_apply_racy, dim3(pool_grid(a)), dim3(256), 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL(k_surfel_apply_ordered, dim3(1), dim3(64), 0, s, a);
   else if (mode == 2) hipLaunchKernelGGL(k_surfel_apply_keys, dim3(pool_grid(a)), dim3(256), 0, s, a);
+  else if (mode == 4) hipLaunchKernelGGL(k_surfel_apply_mark, dim3(pool_grid(a)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_surfel_apply_clusters, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -8,11 +8,7 @@ namespace dust {
 // ==================================================================== primary visibility
 // primary.rgen:8-22 + hit.rint + hit.rchit:16-95 + miss.rmiss:7-17 for one packet. Returns, per lane, what the later
 // passes read back from the G-buffer: the hit distance (INFINITY on a miss) and the packed normal texel.
-// store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient
-// occlusion pass overwrites the texel of every hit pixel anyway.
-template <int MODE>
-__device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
-                                              float& hitT, uint32_t& normal_packed);
+// (primary_shade -- hit.rchit + miss.rmiss for one packet -- lives in traverse.hpp)
 template <int MODE>
 __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint32_t* cand, LaneStats& st,
                                                bool store_illuminance, float& hitT, uint32_t& normal_packed) {
@@ -27,66 +23,6 @@ __device__ __forceinline__ void primary_packet(ArgsRef a, const Packet& p, uint3
   primary_shade<MODE>(reload_args(a), p, o, d, h, store_illuminance, hitT, normal_packed);
   PROF_LEAVE(P_PRIMARY_SHADE);
 }
-template <int MODE>
-__device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
-                                              float& hitT, uint32_t& normal_packed) {
-  hitT = INFINITY;
-  normal_packed = 0;
-  if (!p.valid) return;
-  const size_t pix = (size_t)p.py * a.width + p.px;
-  if (!h.found) {
-    const V3 dir = normalize3(d);
-    const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
-    store_radiance(a.g.denoised, pix, mk(div_const(s0.x + s1.x, 3.14f), div_const(s0.y + s1.y, 3.14f), div_const(s0.z + s1.z, 3.14f)), 100000.0f);
-    DUST_NT_STORE(0xFFFFFFFFu, &a.g.albedo[pix]);
-    DUST_NT_STORE(INFINITY, &a.g.depth[pix]);
-    store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
-    return;
-  }
-  // Hit pixels. The instance and model records are read through SCALAR loads: the pixels of an 8x8 packet hit one or two
-  // instances, so the hit lanes are taken one distinct instance at a time (the first remaining lane's, wave-uniform through
-  // readfirstlane) -- 40 matrix floats and the model's pointers arrive in SGPRs instead of 50 VGPRs per lane.
-  bool todo = true;
-  while (todo) {
-    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.inst);
-    if (h.inst != cur) continue;
-    todo = false;
-    InstanceRef in = a.instances[cur];
-    ModelRef m = a.visits[cur].m;  // the instance's model record by the instance's index (a.models[in.model] is a round trip behind `in`)
-    const uint32_t block = resolve_block(m, h.block);
-    const DustHipBlock b = load_block(m.blocks + block);
-    const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
-    const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
-    const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
-    const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
-    const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
-    const V3 nw = xform_dir(in.o2w, no);
-    if (store_illuminance) store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
-    const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
-    const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
-    const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
-    const uint32_t pal = m.materials[b.material_ptr + voff];
-    const uint32_t col = m.palette[pal];
-    DUST_NT_STORE(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
-                                             div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
-    DUST_NT_STORE(h.t, &a.g.depth[pix]);
-    hitT = h.t;
-    normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
-    DUST_NT_STORE(normal_packed, &a.g.normal[pix]);
-    DUST_NT_STORE((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
-    const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
-    const V3 hpm = xform_point(in.w2o, hpw);
-    DUST_RO(float) P = in.prev;
-    const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
-    const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
-    const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
-    const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
-    const V3 hp = div3(mk(hx, hy, hz), hw);
-    store_half4(a.g.motion, pix, hp.x - hpw.x, hp.y - hpw.y, hp.z - hpw.z, 0.0f);
-  }
-}
-
 // ==================================================================== sun shadow + ambient occlusion
 // ambient_occlusion.rgen:14-66 + .rint + .rchit + .rmiss + nee.rmiss:11-22 for one packet.
 // hitT / normal_packed / payload are what the raygen shader loads from img_depth / img_normal / img_illuminance.

@@ -388,6 +388,7 @@ struct MidCache {  // the 16-cell the ray was last in and its mid-node index (sa
   uint32_t mid;
   uint64_t mask4;  // DEEP variants only: which 4^3 cells of that 16-cell hold a brick (all ones for two-level models)
 };
+__device__ __forceinline__ void midcache_reset(MidCache& mc) { mc.key = -1; mc.mid = 0; mc.mask4 = 0; }
 
 // Ray against an axis-aligned box, conservative (slack on both ends). inv = 1/d per component (IEEE divide). A zero
 // direction component constrains nothing along t and instead requires the origin to lie in the slab (1e-3 margin);
@@ -483,6 +484,8 @@ __device__ __forceinline__ uint64_t find_brick(const Model& m, int x, int y, int
       if (DEEP) {
         // one 16-byte load instead of mask word -> rank prefix + base -> (per 4-cell) brick mask: the cell's mid index and
         // its child mask arrive together, and the walk then crosses the 16-cell's empty 4-cells without touching memory
+        // (Round 6 requested the NEXT 16-cell's record a trip ahead -- which cell the ray enters after this one is geometry, not data --:
+        //  k_primary_ao<2> 2.52 -> 3.26 ms. The deep walk is bound by issue at 128 registers, not by this load's latency; docs/EXPERIMENTS.md.)
         const u32x4 cell = *(DUST_RO(u32x4))(m.l2_cells + ((size_t)l2 * 4096u + idx2));
         if (cell.x == 0xFFFFFFFFu) { cell_log2 = 4; return 0; }
         if (COUNT && count) st.upper_descents += 1;
@@ -737,7 +740,7 @@ __device__ void trace_instance(ModelRef m, uint32_t inst, V3 o, V3 d, float tmin
   uint32_t stepped = 0;   // bit a: axis a crossed a plane on the last step
   uint32_t cl_main = 2;
   MidCache mc;
-  mc.key = -1; mc.mid = 0; mc.mask4 = 0;
+  midcache_reset(mc);
   const bool zero_axis = DEEP && __any(d.x == 0.0f || d.y == 0.0f || d.z == 0.0f);  // (of the lanes in this visit)
   bool prev_whole = false;  // DEEP: the cell the walk has just left was a whole 16-cell (or larger) with nothing untested in it
   const float tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
@@ -1020,6 +1023,8 @@ __device__ uint32_t cull_instances(ArgsRef a, bool any_active, const Range3& org
       float t_g;
       uint64_t groups = __ballot(test(glo, ghi, g < a.n_groups, t_g));
       if (lane == 0) { cand[kMaxCand + (gbase >> 5)] = (uint32_t)groups; cand[kMaxCand + (gbase >> 5) + 1u] = (uint32_t)(groups >> 32); }
+      // (Round 6 requested the NEXT group's boxes before testing the current ones -- a software-pipelined loop, one memory round trip hidden per
+      //  group --: the castle + 4 000 props 0.4352 / 0.4352 -> 0.4423 / 0.4452 ms. The loop is not waiting for these loads; the extra registers cost more.)
       while (groups != 0ull) {
         const uint32_t gi = gbase + (uint32_t)__builtin_ctzll(groups);
         groups &= groups - 1ull;
@@ -1234,6 +1239,7 @@ struct WalkState {          // one lane's visit of one instance
   int ijk[3];
   uint32_t stepped, cl_main, steps;
   bool screen;
+  bool prev_whole;          // DEEP: the cell the walk has just left was a whole 16-cell (or larger) with nothing untested in it (trace_instance)
   MidCache mc;
   uint32_t inst;
   // what a step of a two-level model reads of its record, taken along when the visit starts (a lane's model is its own: read
@@ -1286,8 +1292,8 @@ __device__ __forceinline__ bool walk_begin(WalkState& w, const Model& m, uint32_
     const float q = (oo[a] + dd[a] * t) - (float)b0;
     screen = screen | ((q <= 4.0f * w.near_tol) & (b0 - 1 >= blo)) | ((q >= 4.0f - 4.0f * w.near_tol) & (b0 + 4 <= bhi));
   }
-  w.t = t; w.screen = screen; w.stepped = 0; w.cl_main = 2; w.steps = 0;
-  w.mc.key = -1; w.mc.mid = 0; w.mc.mask4 = 0;
+  w.t = t; w.screen = screen; w.stepped = 0; w.cl_main = 2; w.steps = 0; w.prev_whole = false;
+  midcache_reset(w.mc);
   w.tx_stop = tx * (1.0f + 1e-5f) + 1e-5f;
   return true;
 }
@@ -1315,6 +1321,38 @@ __device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevM
     ModelLite lm;
     lm.root = w.root; lm.dense_mask = w.dense_mask; lm.lds_slot = w.lds_slot; lm.l2 = nullptr; lm.l2_cells = nullptr;
     mask = find_brick<MODE>(lm, w.ijk[0], w.ijk[1], w.ijk[2], w.cl_main, key, w.mc, st, true, w.o, w.d, w.inv);
+  }
+  // (trace_instance's refinement of `screen` for a whole 16-cell with nothing untested in it, verbatim: only a brick ACROSS the entered face
+  //  can need the neighbour visit -- without it the camera, sun and AO rays of a 4096^3 tree, which take sparse cells whole, made the call on
+  //  most of the trips whose entry point lies near a brick plane)
+  if (DEEP && __builtin_expect(w.screen, 0) && w.cl_main >= 4u) {
+    bool near16 = false, across_needed = true, sided = true;
+    uint32_t near4 = 0;
+    int c[3] = {w.ijk[0], w.ijk[1], w.ijk[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (w.stepped & (1u << a)) {
+        c[a] = dd[a] > 0.0f ? (w.ijk[a] & ~15) - 1 : (w.ijk[a] & ~15) + 16;  // back across the face
+      } else {
+        const float pa = oo[a] + dd[a] * w.t;
+        const float r4 = pa * 0.25f;
+        if (fabsf(r4 - rintf(r4)) <= w.near_tol) {
+          near4 += 1u;
+          const int b0 = w.ijk[a] & ~3;
+          const float q = pa - (float)b0;
+          if (q <= 8.0f * w.near_tol) { c[a] = b0 - 1; near16 = near16 | ((b0 & 15) == 0); }
+          else if (q >= 4.0f - 8.0f * w.near_tol) { c[a] = b0 + 4; near16 = near16 | (((b0 + 4) & 15) == 0); }
+          else sided = false;
+        }
+      }
+    }
+    if (w.stepped == 0u || near4 == 0u) across_needed = false;
+    else if (__popc(w.stepped) == 1 && near4 == 1u && sided) {
+      const int kd = ((c[0] >> 4) << 16) | ((c[1] >> 4) << 8) | (c[2] >> 4);
+      const uint32_t bd = ((uint32_t)((c[0] >> 2) & 3) << 4) | ((uint32_t)((c[1] >> 2) & 3) << 2) | (uint32_t)((c[2] >> 2) & 3);
+      if (w.prev_whole || (kd == w.mc.key && !((w.mc.mask4 >> bd) & 1ull))) across_needed = false;
+    }
+    w.screen = (__popc(w.stepped) > 1) | near16 | !sided | across_needed;
   }
   const int S = 1 << w.cl_main;
   float ta[3], tn = INFINITY;
@@ -1359,6 +1397,7 @@ __device__ __forceinline__ bool walk_step(WalkState& w, const DUST_CONST_AS DevM
     if (COUNT) st.bricks_tested += nv[7];
   }
   if (stuck || outside) return true;
+  if (DEEP) w.prev_whole = w.cl_main >= 4u;
   w.ijk[0] = next_ijk[0]; w.ijk[1] = next_ijk[1]; w.ijk[2] = next_ijk[2];
   w.stepped = next_stepped;
   w.screen = next_screen;
@@ -1798,6 +1837,70 @@ __device__ void brick_surfel(ArgsRef a, const Hit& h, V3 o, V3 d, HashKey& key, 
   sf.x = cw.x; sf.y = cw.y; sf.z = cw.z; sf.direction = face;
   avg_albedo = b.avg_albedo;
 }
+// ------------------------------------------------------------------ primary shading (hit.rchit:16-95 + miss.rmiss:7-17) for the lanes of one 8x8 pixel block
+// Returns, per lane, what the later passes read back from the G-buffer: the hit distance (INFINITY on a miss) and the packed normal texel.
+// store_illuminance: hit.rchit:57 zeroes img_illuminance; the fused kernel skips that store because the ambient occlusion pass
+// overwrites the texel of every hit pixel anyway.
+template <int MODE>
+__device__ __forceinline__ void primary_shade(ArgsRef a, const Packet& p, V3 o, V3 d, const Hit& h, bool store_illuminance,
+                                              float& hitT, uint32_t& normal_packed) {
+  hitT = INFINITY;
+  normal_packed = 0;
+  if (!p.valid) return;
+  const size_t pix = (size_t)p.py * a.width + p.px;
+  if (!h.found) {
+    const V3 dir = normalize3(d);
+    const V3 s0 = sky_radiance(a.sky, dir), s1 = sun_radiance(a.sky, dir);
+    store_radiance(a.g.denoised, pix, mk(div_const(s0.x + s1.x, 3.14f), div_const(s0.y + s1.y, 3.14f), div_const(s0.z + s1.z, 3.14f)), 100000.0f);
+    DUST_NT_STORE(0xFFFFFFFFu, &a.g.albedo[pix]);
+    DUST_NT_STORE(INFINITY, &a.g.depth[pix]);
+    store_half4(a.g.motion, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
+  // Hit pixels. The instance and model records are read through SCALAR loads: the pixels of an 8x8 packet hit one or two
+  // instances, so the hit lanes are taken one distinct instance at a time (the first remaining lane's, wave-uniform through
+  // readfirstlane) -- 40 matrix floats and the model's pointers arrive in SGPRs instead of 50 VGPRs per lane.
+  bool todo = true;
+  while (todo) {
+    const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.inst);
+    if (h.inst != cur) continue;
+    todo = false;
+    InstanceRef in = a.instances[cur];
+    ModelRef m = a.visits[cur].m;  // the instance's model record by the instance's index (a.models[in.model] is a round trip behind `in`)
+    const uint32_t block = resolve_block(m, h.block);
+    const DustHipBlock b = load_block(m.blocks + block);
+    const V3 oo = xform_point(in.w2o, o), od = xform_dir(in.w2o, d);
+    const V3 hpo = mk(h.t * od.x + oo.x, h.t * od.y + oo.y, h.t * od.z + oo.z);
+    const V3 off = mk((float)(h.voxel >> 4), (float)((h.voxel >> 2) & 3u), (float)(h.voxel & 3u));
+    const V3 ctr = mk(((float)b.x + off.x) + 0.5f, ((float)b.y + off.y) + 0.5f, ((float)b.z + off.z) + 0.5f);
+    const V3 no = cubed_normalize(mk(hpo.x - ctr.x, hpo.y - ctr.y, hpo.z - ctr.z));
+    const V3 nw = xform_dir(in.o2w, no);
+    if (store_illuminance) store_half4(a.g.illuminance, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t m1 = (uint32_t)b.mask, m2 = (uint32_t)(b.mask >> 32);
+    const uint32_t ma = h.voxel < 32u ? (m1 & ((1u << (h.voxel & 31u)) - 1u)) : m1;
+    const uint32_t mb = h.voxel >= 32u ? (m2 & ((1u << ((h.voxel - 32u) & 31u)) - 1u)) : 0u;
+    const uint32_t voff = (uint32_t)__popc(ma) + (uint32_t)__popc(mb);
+    const uint32_t pal = m.materials[b.material_ptr + voff];
+    const uint32_t col = m.palette[pal];
+    DUST_NT_STORE(pack_rgb10a2(div_const((float)(col & 255u), 255.0f), div_const((float)((col >> 8) & 255u), 255.0f),
+                                             div_const((float)((col >> 16) & 255u), 255.0f), 1.0f), &a.g.albedo[pix]);
+    DUST_NT_STORE(h.t, &a.g.depth[pix]);
+    hitT = h.t;
+    normal_packed = nrd_pack_normal(nw, 1.0f, (float)pal);
+    DUST_NT_STORE(normal_packed, &a.g.normal[pix]);
+    DUST_NT_STORE((h.voxel << 24) | (h.inst & 0xFFFFu) | (pal << 16), &a.g.voxel_id[pix]);
+    const V3 hpw = mk(h.t * d.x + o.x, h.t * d.y + o.y, h.t * d.z + o.z);
+    const V3 hpm = xform_point(in.w2o, hpw);
+    DUST_RO(float) P = in.prev;
+    const float hx = ((P[0] * hpm.x + P[4] * hpm.y) + P[8] * hpm.z) + P[12];
+    const float hy = ((P[1] * hpm.x + P[5] * hpm.y) + P[9] * hpm.z) + P[13];
+    const float hz = ((P[2] * hpm.x + P[6] * hpm.y) + P[10] * hpm.z) + P[14];
+    const float hw = ((P[3] * hpm.x + P[7] * hpm.y) + P[11] * hpm.z) + P[15];
+    const V3 hp = div3(mk(hx, hy, hz), hw);
+    store_half4(a.g.motion, pix, hp.x - hpw.x, hp.y - hpw.y, hp.z - hpw.z, 0.0f);
+  }
+}
+
 }  // namespace
 
 // the launch's hand-out schedule (next_packet): tiles per band, the exact-quotient multiplier for tile / tiles_x, and how many

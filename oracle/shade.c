@@ -862,7 +862,8 @@ void orc_pass_ao(const OrcScene* s, int mode, const OrcCamera* cam, const OrcSky
  *   final gather: pixels in row-major order (the highest pixel index that enqueues wins a surfel slot);
  *   surfel pass : phase 1 -- every surfel traces its rays and reads the hash AS IT WAS AT THE START OF THE PASS
  *                            (Get still stamps last_accessed_frame, a write of the same value from everyone);
- *                 phase 2 -- the SpatialHashInsert calls and pool replacements are applied in surfel-index order.
+ *                 phase 2 -- the SpatialHashInsert calls and pool replacements are applied in surfel-index order; of the frame's
+ *                            inserts of ONE key the last ORC_APPLY_KEEP (surfel_apply: the concurrent invocations' lost updates).
  */
 typedef struct OrcHashEntry { uint32_t fingerprint, radiance; uint16_t last_accessed_frame, sample_count; } OrcHashEntry;
 typedef struct OrcSurfel { float pos[3]; uint32_t direction; } OrcSurfel;
@@ -1145,12 +1146,37 @@ static void surfel_trace_range(const OrcScene* s, int mode, const OrcSky* sky, c
     }
   }
 }
+/* Which of a frame's SpatialHashInsert calls land. The reference's invocations run concurrently and only the fingerprint is claimed
+ * atomically (spatial_hash.glsl:147-195): of the invocations that insert ONE key together, those that read the entry before the
+ * others' stores see the same old state, and the last store wins. The defined order (DESIGN.md "GI order"; the HIP path's
+ * k_surfel_apply_mark states the same rule): the frame's insert requests are sorted by (hash location, surfel index); a request is
+ * SUPERSEDED -- not applied -- when the request ORC_APPLY_KEEP places further on in that order has the same location and the same key
+ * (of a run of requests with one key, the last ORC_APPLY_KEEP stay); the others are applied in surfel-index order. */
+#define ORC_APPLY_KEEP 8u
+typedef struct { uint32_t loc, idx; } ApplyOrder;
+static int apply_order_cmp(const void* a, const void* b) {
+  const ApplyOrder *x = (const ApplyOrder*)a, *y = (const ApplyOrder*)b;
+  if (x->loc != y->loc) return x->loc < y->loc ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
 static void surfel_apply(OrcGI* gi, const SurfelReq* req, uint32_t frame_index) {
   const uint32_t N = gi->pool_size;
+  ApplyOrder* ord = (ApplyOrder*)malloc((size_t)N * sizeof(ApplyOrder));
+  uint8_t* dead = (uint8_t*)calloc(N, 1);
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < N; ++i)
+    if (req[i].kind == 1) { ord[n].loc = key_location(req[i].key, gi->capacity); ord[n].idx = i; ++n; }
+  qsort(ord, n, sizeof(ApplyOrder), apply_order_cmp);
+  for (uint32_t p = 0; p + ORC_APPLY_KEEP < n; ++p) {
+    const ApplyOrder *x = &ord[p], *y = &ord[p + ORC_APPLY_KEEP];
+    const HashKey *kx = &req[x->idx].key, *ky = &req[y->idx].key;
+    if (x->loc == y->loc && kx->x == ky->x && kx->y == ky->y && kx->z == ky->z && kx->dir == ky->dir) dead[x->idx] = 1;
+  }
   for (uint32_t i = 0; i < N; ++i) { /* phase 2: in surfel order */
-    if (req[i].kind == 1) hash_insert(gi, req[i].key, req[i].value, frame_index);
+    if (req[i].kind == 1 && !dead[i]) hash_insert(gi, req[i].key, req[i].value, frame_index);
     if (req[i].replace) gi->pool[i % N] = req[i].repl;
   }
+  free(ord); free(dead);
 }
 void orc_pass_surfel(const OrcScene* s, int mode, const OrcSky* sky, const uint8_t* noise0, const uint8_t* noise5, uint32_t rnd,
                      uint32_t frame_index, OrcGI* gi, OrcRayStats* st_sun, OrcRayStats* st_cos) {

@@ -24,7 +24,10 @@ python bench.py --camera orbit --steps 240 --no-cpu-baseline > "$out/${tag}_benc
 python bench.py --workload teapot_cpu > "$out/${tag}_bench_teapot_cpu.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
-DUST_HIP_RAY_LANES=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ray_lanes.log" 2>> "$out/${tag}_bench.err"
+# round 6: two whole frames in flight on one GPU (each on half of the slots / every launch asking for all of them), the deterministic apply on one GPU
+python bench.py --frames-in-flight 2 --in-flight-slots share --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined.log" 2>> "$out/${tag}_bench.err"
+python bench.py --frames-in-flight 2 --in-flight-slots all --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined_all.log" 2>> "$out/${tag}_bench.err"
+DUST_BENCH_GI_ORDERED=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ordered_inplace.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 # round 5: thousands of instances (the packet cull's 64-wide hierarchy against every box for every packet), the GI passes as ray streams
 # (opt-in on the castle, the default for the deep tree's gather), N-rank denoise on one GPU
@@ -34,12 +37,24 @@ DUST_HIP_RAY_STREAM=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --
 DUST_HIP_RAY_STREAM=1 python bench.py --workload deep --steps 30 --no-cpu-baseline > "$out/${tag}_bench_deep_stream.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_PACKET_GI=1 python bench.py --workload deep --steps 30 --no-cpu-baseline > "$out/${tag}_bench_deep_packet.log" 2>> "$out/${tag}_bench.err"
 python bench.py --denoise --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_denoise.log" 2>> "$out/${tag}_bench.err"
-# what ONE rank of an N-GPU row-band run does between collectives (four frames in flight, launches on a quarter of the slots each): every band of N = 2, 4, 8
+# what ONE rank of an N-GPU row-band run does between collectives (four frames in flight, launches on a quarter of the slots each, 32 slots reserved):
+# every band of N = 8 while the cuts are balanced on measured band steps (round 6), the timed region on the SLOWEST band; N = 2 and 4 likewise
 : > "$out/${tag}_bench_bands_emulated.log"
-for n in 2 4 8; do for r in $(seq 0 $((n - 1))); do
-  DUST_HIP_RESERVE_BLOCKS=32 DUST_BENCH_EMULATE_BAND=$r/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
-    python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'band': '$r/$n', 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['kernel_ms'], 'frames_in_flight': j['config']['frames_in_flight'], 'rays_per_step': j['config']['rays_per_step_all_gpus']}))" >> "$out/${tag}_bench_bands_emulated.log"
-done; done
+for n in 2 4 8; do
+  DUST_BENCH_EMULATE_BAND=all/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
+    python -c "import sys,json; j=json.loads(sys.stdin.read()); c=j['config']; print(json.dumps({'bands': $n, 'slowest_band': c['emulated_band'], 'ms_per_step_slowest': j['ms_per_step'], 'band_steps_ms': c['band_steps_ms'], 'band_balance': c['band_balance'], 'frames_in_flight': c['frames_in_flight']}))" >> "$out/${tag}_bench_bands_emulated.log"
+done
+# ... and of an N = 8 GI job (round 6: pixel passes on the band, the exchange's export / import, 1/8 of the surfel trace, ordering + ordered apply replicated; one frame in flight)
+: > "$out/${tag}_bench_gi_bands_emulated.log"
+for spec in "gi 1920 1080 100" "gi 3840 2160 60" "deep 1920 1080 30"; do
+  set -- $spec
+  python bench.py --workload $1 --width $2 --height $3 --steps $4 --no-cpu-baseline 2>> "$out/${tag}_bench.err" |
+    python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'workload': '$1', 'frame': [$2, $3], 'band': 'whole frame, one GPU', 'ms_per_step': j['ms_per_step'], 'kernels_ms': j['roofline']['kernels_ms']}))" >> "$out/${tag}_bench_gi_bands_emulated.log"
+  for r in 0 1 2 3 4 5 6 7; do
+    DUST_BENCH_EMULATE_BAND=$r/8 python bench.py --workload $1 --width $2 --height $3 --steps $4 --no-cpu-baseline 2>> "$out/${tag}_bench.err" | tail -1 |
+      python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'workload': '$1', 'frame': [$2, $3], 'band': '$r/8', 'ms_per_step': j['ms_per_step'], 'kernels_ms': j['roofline']['kernels_ms']}))" >> "$out/${tag}_bench_gi_bands_emulated.log"
+  done
+done
 
 # a 1/8 band launched ALONE, one frame in flight: what single-frame strong scaling on 8 GPUs would get from the kernel
 : > "$out/${tag}_bench_band_alone.log"
@@ -58,6 +73,10 @@ rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_deep -- \
     python "$R/bench.py" --workload deep --steps 10 --warmup 2 --no-cpu-baseline > "$out/${tag}_bench_deep_prof.log" 2>&1
 DUST_HIP_RAY_STREAM=1 DUST_HIP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi_stream -- \
     python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_stream_prof.log" 2>&1
+DUST_BENCH_EMULATE_BAND=3/8 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi_band -- \
+    python "$R/bench.py" --workload gi --width 3840 --height 2160 --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_band_prof.log" 2>&1
+python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_gi_band_results.db') \
+    --json "$out/${tag}_kernel_stats_gi_band_4k.json" > "$out/${tag}_kernel_stats_gi_band_4k.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_gi_stream_results.db') \
     --json "$out/${tag}_kernel_stats_gi_stream.json" > "$out/${tag}_kernel_stats_gi_stream.txt" 2>&1
 python "$R/profiles/summarize_rocprof.py" $(find "$out/prof_$tag" -name 'bench_deep_results.db') \
@@ -104,6 +123,7 @@ for v in stream packet; do
 done
 unset DUST_HIP_RAY_STREAM
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
+python "$R/tools/diag/surfel_items.py" 40 > "$out/${tag}_surfel_items.txt" 2>&1
 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times.txt" 2>&1
 DUST_HIP_EQUAL_BANDS=1 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times_equal_bands.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
