@@ -402,8 +402,12 @@ def measure_curve(be, dist, args, lanes, shard):
             if rd == rounds:
                 break
             band_cuts, strip_cost = sharding.rebalance_cuts(strip_cost, band_cuts, ms_now, en, H)
+            if world > 1:   # (every rank rescaled ITS OWN cost map: rank 0's cuts are everybody's)
+                agreed = torch.tensor(band_cuts, dtype=torch.int64, device=be.device)
+                dist.broadcast(agreed, src=0)
+                band_cuts = [int(v) for v in agreed.tolist()]
         if best is not None:
-            band_cuts, band_steps_ms = best   # (the best set seen: a correction may overshoot)
+            band_cuts, band_steps_ms = best   # (the best set seen: a correction may overshoot; the same on every rank: the times were all-gathered, the cuts broadcast)
             if er_all:
                 er = max(range(en), key=lambda r: band_steps_ms[r])
         per_rows, rows, send = sharding.layout_from_cuts(er, band_cuts, H)
@@ -788,12 +792,13 @@ def extra_curves(args, be, noise0, noise5, base):
         rec["scene"] = f"the castle + 4000 scattered props: {sc['info']['n_instances']} instances of {sc['info']['n_models']} models"
         return rec
     def pipelined(depth):
-        """The headline's frames, `depth` of them in flight on streams, contexts and G-buffers of their own, every launch asking for all
-        workgroup slots (the reference's host keeps up to three frames in flight, rhyolite_bevy/src/lib.rs:58): the next frame's workgroups
-        become resident on the CUs the previous frame's last tiles have left, so a step no longer pays its launch's tail, staging and gap.
+        """The headline's frames, `depth` of them in flight on streams, contexts and G-buffers of their own, each launch on 1 / depth of the
+        workgroup slots (the reference's host keeps up to three frames in flight, rhyolite_bevy/src/lib.rs:58): a launch's staging, the gap
+        behind it and half of its tail are hidden behind its neighbour. (Every launch asking for ALL slots -- the next frame's workgroups
+        taking the CUs the previous frame's tail leaves -- measured worse: docs/EXPERIMENTS.md, round 6.)
         Per-kernel HIP-event times are inflated by the overlap: the roofline here is algorithmic bytes per STEP over ms_per_step."""
         a = argparse.Namespace(**vars(args))
-        a.steps, a.warmup, a.in_flight_slots = max(args.extra_steps, 60), 0, "all"
+        a.steps, a.warmup, a.in_flight_slots = max(args.extra_steps, 60), 0, "share"
         lanes = []
         for i in range(depth):
             lane = be.open_lane(a, base.sc)
@@ -811,7 +816,6 @@ def extra_curves(args, be, noise0, noise5, base):
                              "note": "bytes per step / ms_per_step (whole-step rate): with launches overlapping, the HIP-event duration of one launch "
                                      "(kernels_ms) includes the time it shares the device with its neighbours' and is not what a step costs"}}
     run("pipelined", lambda: pipelined(2))
-    run("pipelined_3", lambda: pipelined(3))
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
     run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
     run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))

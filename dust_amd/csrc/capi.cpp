@@ -406,6 +406,7 @@ struct Tuning {
   uint32_t stream_refill = 16;  // STREAM_REFILL, STREAM_TOP_ITERS: FrameArgs::stream_refill / stream_top_iters
   uint32_t stream_top_iters = 8;
   uint32_t in_flight_oversub = 0;  // IN_FLIGHT_OVERSUB (percent)
+  bool wide_share = false;         // WIDE_SHARE: two frames in flight on half of the slots each as 1024-thread workgroups, one per CU (experiment)
   bool no_stream_lds = false;   // NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
   bool packet_gi() const { return gi_path != DUST_GI_PATH_STREAMS; }    // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace)
   bool packet_only() const { return gi_path == DUST_GI_PATH_PACKETS; }  // ... even where the streams are the default
@@ -437,6 +438,7 @@ struct Tuning {
     t.wide_fused = !flag("NO_WIDE_FUSED") && !flag("BLOCK");
     t.force_moving = flag("FORCE_MOVING");
     t.in_flight_oversub = std::min(100u, num("IN_FLIGHT_OVERSUB", 0));
+    t.wide_share = flag("WIDE_SHARE");
     return t;
   }
 };
@@ -2077,6 +2079,11 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
         grid == resident) {
       fblock = 1024;
       fgrid = std::max(8u, std::min<uint32_t>(uint32_t(ctx->num_cus), (total_tiles + 7) / 8));
+    } else if (tune.wide_fused && tune.wide_share && block == 512 && bpc == 2 && !ctx->side_busy && share_slots && p->frames_in_flight == 2 && !reserve_blocks &&
+               lds_wide <= ctx->max_lds && grid == frame_slots && frame_slots * 2u == resident) {
+      // two whole frames in flight, each on half of the slots: half of the CUs each, one 1024-thread workgroup per CU
+      fblock = 1024;
+      fgrid = std::max(8u, (frame_slots / 2u) & ~7u);
     }
     say_start(a);
     HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));

@@ -188,10 +188,12 @@ def assert_parity(res):
         assert res.get(k, 0.0) <= 1e-3, f"{k} = {res[k]} exceeds 1e-3 ({res})"  # north_star tolerance
 
 
-def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n5, seed=3, gi_sizes=None):
+def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n5, seed=3, gi_sizes=None, shard_trace=False):
     """SURVEY 8e option i with the collectives done by hand: `world` pipelines on one GPU play the ranks (row bands for the
     pixel passes, the exchange of dust_hip_pipeline_gi_exchange, replicated ordered surfel pass); asserts that every rank's
-    spatial hash, surfel pool and own illuminance band equal the single-pipeline run bit for bit. Returns the reference hash."""
+    spatial hash, surfel pool and own illuminance band equal the single-pipeline run bit for bit. Returns the reference hash.
+    shard_trace: the surfel TRACE sharded over the ranks as well (round 6): rank r traces its share of the ordered pool, a loopback group's
+    dust_hip_gi_surfel_exchange_run gathers the records, repeats the stamps and applies."""
     from dust_amd import sharding
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -242,7 +244,12 @@ def sharded_gi_vs_single_device(ctx, scene, cam, sky, w, h, world, frames, n0, n
                 p.gi_import(bands[r][0], bands[r][1], frame)
             else:
                 p.gi_import(h, h, frame)   # a rank past the end of the frame: every stamp is another band's (as bench.py does)
-            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd)
+            p.render(scene, cam, sky, L.PASS_SURFEL | L.PASS_GI_ORDERED | L.PASS_GI_SHARDED, frame, rnd, surfel_shard=(r, world) if shard_trace else (0, 0))
+        if shard_trace:
+            if frame == 1:
+                comms = api.Comm.local(ctx, world)
+            for r, p in enumerate(ranks):
+                comms[r].gi_surfel_exchange(p, frame)
         ctx.sync()
     h_ref, s_ref = ref.read_gi()
     ill_ref = ref.read_plane(L.PLANE_ILLUMINANCE)

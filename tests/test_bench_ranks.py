@@ -40,6 +40,9 @@ class StubPipe:
         self.n_render = 0
     def set_noise(self, *a): pass
     def set_frames_in_flight(self, n): self.calls.append(("in_flight", n))
+    if os.environ.get("BENCH_REBALANCE", "0") != "0":   # (with `configure` the band cuts are rebalanced from measured band steps)
+        def configure(self, frames_in_flight=None, in_flight_slots=None, **kw):
+            self.calls.append(("in_flight", frames_in_flight))
     def configure_gi(self, *a): self.calls.append("configure_gi")
     def clear(self): self.calls.append("clear")
     def render(self, scene, cam, sky, passes, frame_index=1, rand=0, rows=(0, 0), surfel_shard=(0, 0)):
@@ -144,7 +147,8 @@ class StubBackend:
 
 
 args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", str(W), "--height", str(H),
-                    "--workload", workload, "--no-cpu-baseline"] + (["--denoise"] if os.environ.get("BENCH_DENOISE") == "1" else []))
+                    "--workload", workload, "--no-cpu-baseline", "--band-rebalance", os.environ.get("BENCH_REBALANCE", "0")]
+                   + (["--denoise"] if os.environ.get("BENCH_DENOISE") == "1" else []))
 bench.SETTLE_STEPS = 2
 # the ranks' own clocks disagree about how many more settle frames are due (rank 0: as many as allowed, rank 1: none); every step
 # holds a collective, so they must settle on one count or the job hangs
@@ -171,9 +175,12 @@ if rank == 0:
     assert len(be.pipes) == (1 if gi else 4)      # row bands of a non-GI workload: four frames in flight, a pipeline each
     assert strong["settle_steps"] == weak["settle_steps"] == 2 + 5, (strong, weak)
     assert ("in_flight", 1 if gi else 4) in calls
-    if not gi:
+    if not gi and os.environ.get("BENCH_REBALANCE", "0") == "0":
         assert strong["band_rows"] == [0, 8, 40], strong   # 5 strips costing 5,5,1,1,1 (rank 0's map; rank 1 measured 6,6,1,1,1): the boundary nearest to half the cost is after the first
         assert "equal measured cost" in strong["parallelism"]
+    if not gi and os.environ.get("BENCH_REBALANCE", "0") != "0":   # cuts corrected from the ranks' own band-step times: rank 0's are everybody's (the gathers above checked every band's rows)
+        cuts = strong["band_rows"]
+        assert cuts[0] == 0 and cuts[-1] == H and len(cuts) == 3 and cuts[1] % 8 == 0, strong
     if gi:
         assert "clear" in calls and ("export", 0, 24) in calls
     if os.environ.get("BENCH_NATIVE") == "1":   # the library's own collectives: gathers with rotating roots, tickets waited for, the GI exchange in one call
@@ -203,7 +210,7 @@ dist.destroy_process_group()
 '''
 
 
-def _run(workload, native=False, denoise=False):
+def _run(workload, native=False, denoise=False, rebalance=0):
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -211,7 +218,7 @@ def _run(workload, native=False, denoise=False):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
-                   BENCH_WORKLOAD=workload, BENCH_NATIVE="1" if native else "0", BENCH_DENOISE="1" if denoise else "0")
+                   BENCH_WORKLOAD=workload, BENCH_NATIVE="1" if native else "0", BENCH_DENOISE="1" if denoise else "0", BENCH_REBALANCE=str(rebalance))
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT={ROOT!r}\n" + WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
@@ -234,6 +241,13 @@ def test_bench_rank_function_two_ranks_native_collectives():
     one gi_exchange call per frame) has executed before an 8-GPU node runs it over RCCL"""
     _run("primary_ao", native=True)
     _run("gi", native=True)
+
+
+def test_bench_rank_function_two_ranks_rebalanced_bands():
+    """--band-rebalance (round 6): every rank times its own band, the times are all-gathered, the cuts corrected and rank 0's broadcast --
+    each rank rescales its OWN cost map, so without the broadcast the ranks would render different bands; the stand-in's gather asserts that
+    every band of the assembled frame carries its rank and its rows"""
+    _run("primary_ao", native=True, rebalance=2)
 
 
 def test_bench_rank_function_two_ranks_denoised_frames():

@@ -35,7 +35,8 @@ for seed in range(first, first + n):
     world = int(rng.choice([2, 3, 4, 5, 8, 9]))
     sizes = (int(rng.choice([61, 509, 4093, 1 << 14])), int(rng.choice([97, 777, 2048])))
     try:
-        P.sharded_gi_vs_single_device(ctx, scene, cam, P.sky_state(), w, h, world, int(rng.integers(2, 5)), n0, n5, seed=seed, gi_sizes=sizes)
+        P.sharded_gi_vs_single_device(ctx, scene, cam, P.sky_state(), w, h, world, int(rng.integers(2, 5)), n0, n5, seed=seed, gi_sizes=sizes,
+                                      shard_trace=seed % 2 == 1)   # (odd seeds: the surfel trace sharded over the ranks as well, round 6)
     except AssertionError as e:
         bad.append(seed)
         from dust_amd import sharding
