@@ -71,6 +71,13 @@ def parse(argv=None):
                     help="frames of the sequence on the GPU at once, each on a stream, context and G-buffer of its own (0 = auto: 4 for "
                          "row bands on N > 1 GPUs, where a rank's launch is as long as its most expensive tile and most of the GPU would "
                          "idle behind it; 1 otherwise). GI workloads run one frame at a time (every frame reads the previous one's hash)")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="one GPU, primary_ao: this many consecutive frames of the sequence (at most 8) go to the device in ONE call and ONE persistent "
+                         "launch (dust_hip_render_frames: G-buffers of their own on one context and stream; a wavefront that finds frame i without tiles "
+                         "goes on to frame i + 1, so the launch's tail, root staging and inter-launch gap are paid once per launch; every frame's planes "
+                         "are the bits the frame rendered alone gives). 1 = a launch per frame (rounds 1-5's headline; the default line carries it as "
+                         "curves.one_frame_per_launch). Default: 4 on one GPU -- the reference's host keeps up to three frames in flight, "
+                         "rhyolite_bevy/src/lib.rs:58 -- and 1 for GI workloads, N > 1 GPUs, emulated bands and --frames-in-flight runs")
     ap.add_argument("--in-flight-slots", choices=["auto", "share", "all"], default="auto",
                     help="with several frames in flight: share = every launch on 1/D of the workgroup slots (row bands: a band is as long as its "
                          "heaviest tile, D of them side by side fill the device); all = every launch asks for ALL slots, so the next frame's workgroups "
@@ -189,6 +196,16 @@ class HipBackend:
         if self.world > 1 or os.environ.get("DUST_BENCH_EMULATE_BAND"):
             lane.pipe.configure(reserve_blocks=32)
         lane.enter = lambda: self.torch.cuda.stream(lane.stream)
+        return lane
+
+    def open_batch_lane(self, args, first):
+        """A further frame of a batched launch (dust_hip_render_frames): a pipeline (G-buffer) of its own on the FIRST lane's context, stream and scene."""
+        lane = Lane()
+        lane.stream, lane.ctx, lane.sc = first.stream, first.ctx, first.sc
+        lane.pipe = self.api.StandardPipeline(lane.ctx, args.width, args.height)
+        if self.world > 1 or os.environ.get("DUST_BENCH_EMULATE_BAND"):
+            lane.pipe.configure(reserve_blocks=32)   # (as open_lane: frames of one launch have one configuration)
+        lane.enter = first.enter
         return lane
 
     def build_scene(self, args, ctx=None):
@@ -344,11 +361,16 @@ def measure_curve(be, dist, args, lanes, shard):
         per_rows, rows, send = sharding.band_layout(er, en, H)
         send = (send[0], en * per_rows)  # (sizes the padded render target as the N-rank run would)
     D = len(lanes)
+    # --frames-per-launch: the D lanes are G-buffers on ONE context; D consecutive steps are one dust_hip_render_frames call = one launch
+    fpl = int(getattr(args, "frames_per_launch", 0) or 0)
+    batched = fpl > 1 and world == 1 and not gi_mode and D == fpl and all(ln.ctx is lanes[0].ctx for ln in lanes)
     slots_mode = getattr(args, "in_flight_slots", "auto")
     if slots_mode == "auto":
         slots_mode = "share" if (bands and (world > 1 or emulate)) else "all"
     for lane in lanes:
-        if hasattr(lane.pipe, "configure"):
+        if batched:
+            pass   # (one launch at a time, on every slot)
+        elif hasattr(lane.pipe, "configure"):
             lane.pipe.configure(frames_in_flight=D, in_flight_slots=slots_mode)  # D launches side by side on 1/D of the workgroup slots each, or one behind the other's tail
         else:
             lane.pipe.set_frames_in_flight(D)
@@ -377,7 +399,12 @@ def measure_curve(be, dist, args, lanes, shard):
             for phase in (BAL_WARM, BAL_STEPS):
                 be.sync()
                 t0 = time.perf_counter()
-                for k in range(phase):
+                for k in range(0, phase, D if batched else 1):
+                    if batched:
+                        idx = [1 + k + j for j in range(D)]
+                        be.api.StandardPipeline.render_frames([ln.pipe for ln in lanes], lanes[0].sc["scene"], cam, sky, passes, idx,
+                                                              [synth.frame_rand(1, v) for v in idx], rows=rws)
+                        continue
                     ln = lanes[k % D]
                     ln.pipe.render(ln.sc["scene"], cam, sky, passes, frame_index=1 + k, rand=synth.frame_rand(1, 1 + k), rows=rws)
                 be.sync()
@@ -529,6 +556,22 @@ def measure_curve(be, dist, args, lanes, shard):
         elif world > 1:
             gather.submit_view(targets[k % S][send[0]:send[1]])  # asynchronous gather, straight from the target
 
+    def steps_from(first, n):
+        """steps first .. first + n - 1: one launch each, or (--frames-per-launch) D of them per dust_hip_render_frames call"""
+        if not batched:
+            for i in range(n):
+                step(first + i)
+            return
+        i = 0
+        while i < n:
+            m = min(D, n - i)
+            ks = [first + i + j for j in range(m)]
+            idx = [(1 + k) if bands else sharding.sample_frame_index(k, rank, world) for k in ks]
+            if have_rows:
+                be.api.StandardPipeline.render_frames([lanes[(k % S) % D].pipe for k in ks], lanes[0].sc["scene"], cam, sky, passes, idx,
+                                                      [synth.frame_rand(1, v) for v in idx], rows=rows if bands else (0, 0))
+            i += m
+
     def barrier():
         gather.finish()
         if world > 1:
@@ -560,9 +603,9 @@ def measure_curve(be, dist, args, lanes, shard):
     # ranks agree (max) on how many more make up SETTLE_SECONDS at the rate the slowest of them measured.
     settle = 0
     t_settle = time.perf_counter()
-    while settle < max(args.warmup, SETTLE_STEPS):
-        step(1 + settle)
-        settle += 1
+    n_fixed = max(args.warmup, SETTLE_STEPS)
+    steps_from(1, n_fixed)
+    settle += n_fixed
     barrier()
     spent = time.perf_counter() - t_settle
     more = 0 if spent >= SETTLE_SECONDS else min(SETTLE_MAX_STEPS, int((SETTLE_SECONDS - spent) / max(spent / max(settle, 1), 1e-6)) + 1)
@@ -570,15 +613,15 @@ def measure_curve(be, dist, args, lanes, shard):
         agreed = torch.tensor([more], dtype=torch.int64, device=be.device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
         more = int(agreed.item())
-    for _ in range(more):
-        step(1 + settle)
-        settle += 1
+    if batched:
+        more = -(-more // D) * D   # whole launches
+    steps_from(1 + settle, more)
+    settle += more
     barrier()
     for lane in lanes:
         lane.pipe.mark_kernel_times()  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE (no wait) ...
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        step(1 + settle + i)
+    steps_from(1 + settle, args.steps)   # (EXACTLY args.steps frames: a last launch of fewer frames if D does not divide them)
     barrier()
     elapsed = time.perf_counter() - t_start
     gc.enable()
@@ -608,7 +651,10 @@ def measure_curve(be, dist, args, lanes, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": D, "in_flight_slots": slots_mode if D > 1 else None, "band_cuts": band_cuts,
+            "frames_per_launch": D if batched else 1,
+            # frames per launch of the timed region, averaged (a last launch of fewer frames counts): what a launch's algorithmic bytes are a multiple of
+            "launch_frames": (args.steps / -(-args.steps // D)) if batched else 1.0,
+            "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": 1 if batched else D, "in_flight_slots": slots_mode if D > 1 else None, "band_cuts": band_cuts,
             "comm": "native" if native else "torch", "denoise": denoise, "band_balance": balance_log or None,
             "band_steps_ms": [round(v, 4) for v in band_steps_ms] if band_steps_ms else None, "emulated_band": (f"{er}/{en}" if emulate else None)}
 
@@ -619,7 +665,7 @@ def compact(curve, gi_mode):
     d = acct["dominant"]
     ms = curve["ms"]
     fused = ms[1] == 0.0
-    kernels = dict({"k_primary_ao": round(ms[0], 4)} if fused else {"k_primary": round(ms[0], 4), "k_ambient_occlusion": round(ms[1], 4)},
+    kernels = dict({("k_primary_ao_batch" if curve.get("frames_per_launch", 1) > 1 else "k_primary_ao"): round(ms[0], 4)} if fused else {"k_primary": round(ms[0], 4), "k_ambient_occlusion": round(ms[1], 4)},
                    **acct["kernels_ms_extra"])
     return {"value": round(curve["mrays"], 2), "unit": "Mrays/s", "ms_per_step": round(curve["ms_per_step"], 4),
             "rays_per_step": int(curve["rays_per_step"]), "settle_steps": curve["settle"], "kernels_ms": kernels,
@@ -815,6 +861,33 @@ def extra_curves(args, be, noise0, noise5, base):
                              "peak": HBM_PEAK_GBPS, "frac": round(achieved / HBM_PEAK_GBPS, 6),
                              "note": "bytes per step / ms_per_step (whole-step rate): with launches overlapping, the HIP-event duration of one launch "
                                      "(kernels_ms) includes the time it shares the device with its neighbours' and is not what a step costs"}}
+    def batched(fpl):
+        """The headline's frames, `fpl` consecutive ones per call and per persistent LAUNCH (dust_hip_render_frames / k_primary_ao_batch): G-buffers of
+        their own on the headline's context, stream and scene; a wavefront that finds frame i without tiles takes frame i + 1's descriptor and queue,
+        so a launch's tail, root staging and the gap behind it are paid once for `fpl` frames. One launch at a time: its HIP-event duration is what
+        its frames cost, and the roofline is the launch's own (fpl frames' algorithmic bytes over that duration)."""
+        a = argparse.Namespace(**vars(args))
+        a.steps, a.warmup, a.frames_per_launch = -(-max(args.extra_steps, 60) // fpl) * fpl, 0, fpl
+        lanes = [base]
+        for _ in range(fpl - 1):
+            lane = be.open_batch_lane(a, base)
+            lane.pipe.set_noise(5, noise5)
+            lanes.append(lane)
+        c = measure_curve(be, None, a, lanes, "bands")
+        rec = compact(c, False)
+        rec["steps"], rec["frames_per_launch"] = a.steps, c["frames_per_launch"]
+        step_bytes = rec["roofline"]["algorithmic_bytes_per_launch"] / c["launch_frames"]
+        rec["roofline"]["whole_step_frac"] = round(step_bytes / (c["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)   # bytes per step / ms_per_step: gaps between launches included
+        return rec
+    def one_frame_per_launch():
+        """rounds 1-5's headline: every frame a launch of its own (dust_hip_render_frame), one at a time"""
+        a = argparse.Namespace(**vars(args))
+        a.steps, a.warmup, a.frames_per_launch = max(args.extra_steps, 60), 0, 1
+        rec = compact(measure_curve(be, None, a, [base], "bands"), False)
+        rec["steps"], rec["frames_per_launch"] = a.steps, 1
+        return rec
+    run("one_frame_per_launch", one_frame_per_launch)
+    run("eight_frames_per_launch", lambda: batched(8))
     run("pipelined", lambda: pipelined(2))
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
     run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
@@ -845,7 +918,8 @@ def account(curve, gi_mode):
     if gi_mode and max(ms_fg, ms_sf) > ms_primary:
         dominant = ("final_gather", bytes_fg, ms_fg) if ms_fg >= ms_sf else ("surfel_trace", bytes_sf, ms_sf)
     elif ms_ao == 0.0:   # primary + AO ran as one fused kernel (the default)
-        dominant = ("primary_ao", bytes_primary + bytes_ao, ms_primary)
+        lf = float(curve.get("launch_frames", 1.0))   # (--frames-per-launch: one launch carries that many frames' bytes)
+        dominant = ("primary_ao_batch" if lf > 1.0 else "primary_ao", (bytes_primary + bytes_ao) * lf, ms_primary)
     else:
         dominant = ("ambient_occlusion", bytes_ao, ms_ao) if ms_ao >= ms_primary else ("primary", bytes_primary, ms_primary)
     achieved = dominant[1] / (dominant[2] * 1e-3) / 1e9 if dominant[2] > 0 else 0.0
@@ -883,6 +957,21 @@ def run_rank(args, be, dist):
             pipe.configure_gi(*(getattr(pipe, "_gi", None) or (32 * 1024 * 1024, 720 * 480)))
             pipe.clear()
         in_flight = 1 if gi_mode else (args.frames_in_flight or (4 if (world > 1 and shard == "bands") else 1))
+        fpl = args.frames_per_launch
+        if fpl is None:   # the default: four frames per launch where nothing else was asked for
+            fpl = 4 if (world == 1 and not gi_mode and not args.frames_in_flight and not os.environ.get("DUST_BENCH_EMULATE_BAND")
+                        and not getattr(args, "denoise", False)) else 1
+        if fpl > 1 and world == 1 and not gi_mode and hasattr(be, "open_batch_lane"):
+            # --frames-per-launch: that many G-buffers on the first lane's context; consecutive steps share a launch (dust_hip_render_frames)
+            batch_lanes = [lanes_for(1)[0]]
+            for _ in range(min(fpl, 8) - 1):
+                bl = be.open_batch_lane(args, batch_lanes[0])
+                bl.pipe.set_noise(5, noise5)
+                batch_lanes.append(bl)
+            a_b = argparse.Namespace(**vars(args))
+            a_b.frames_per_launch = len(batch_lanes)
+            curves[shard] = measure_curve(be, dist, a_b, batch_lanes, shard)
+            continue
         curves[shard] = measure_curve(be, dist, args, lanes_for(in_flight), shard)
     main_curve = curves[wanted[0]]
     if rank != 0:
@@ -914,11 +1003,14 @@ def run_rank(args, be, dist):
     roofline = {"bound": "hbm", "kernel": "k_" + dominant[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(dominant[1]), "kernel_ms": round(dominant[2], 4),
-                "kernel_ms_source": f"HIP events on the launch stream around the launches of every 4th frame of the timed region ({main_curve['launches']} launches "
+                # (--frames-per-launch: ONE launch renders that many frames = steps; its bytes and its duration are those of all of them)
+                "frames_per_launch": main_curve.get("frames_per_launch", 1),
+                "kernel_ms_per_frame": round(dominant[2] / float(main_curve.get("launch_frames", 1.0)), 4),
+                "kernel_ms_source": f"HIP events on the launch stream around the launches of every 4th frame of the timed region (a launch of 4 or more frames: every launch; {main_curve['launches']} launches "
                                     "averaged; an event record costs the stream ~6 us, so bracketing every launch would take 5 % off the rate it measures)"
                                     + (f"; {main_curve['frames_in_flight']} frames in flight on streams of their own: a launch's duration includes the time it "
                                        "shares the GPU with its neighbours'" if main_curve["frames_in_flight"] > 1 else ""),
-                "kernels_ms": dict({"k_primary_ao": round(ms_primary, 4)} if fused else
+                "kernels_ms": dict({("k_primary_ao_batch" if main_curve.get("frames_per_launch", 1) > 1 else "k_primary_ao"): round(ms_primary, 4)} if fused else
                                    {"k_primary": round(ms_primary, 4), "k_ambient_occlusion": round(ms_ao, 4)}, **kernels_ms_extra),
                 "per_rank_kernel_ms": [{"primary_ao" if fused else "primary": round(v[0], 4),
                                         **({"ambient_occlusion": round(v[1], 4)} if not fused else {}),
@@ -938,6 +1030,9 @@ def run_rank(args, be, dist):
 
     def parallelism(c):
         root_txt = "k % N for step k (rotating root)" if c["assemble"] == "rotate" and world > 1 else "0"
+        if c.get("frames_per_launch", 1) > 1:
+            return (f"1 GPU, {c['frames_per_launch']} consecutive frames per persistent launch (dust_hip_render_frames: G-buffers of their own, one context and "
+                    "stream; every frame's planes bit-identical to the frame rendered alone, tests/test_gpu_batch.py); a step is still ONE frame")
         if c["shard"] == "bands":
             return ((f"bands x{world}: one frame in {world} row bands of about equal measured cost, cut at rows {c['band_cuts']}" if c.get("band_cuts") else
                      f"bands x{world}: one frame in {world} row bands of {c['per_rows']} rows")
@@ -962,6 +1057,7 @@ def run_rank(args, be, dist):
                    "vox_models": info["n_models"], "instances": info["n_instances"], "voxels": info["n_voxels"],
                    "bricks": sc["n_bricks"], "scene_build_s": round(sc["t_load"], 3), "untimed_steps_before_timing": main_curve["settle"],
                    "frames_in_flight": main_curve["frames_in_flight"], "in_flight_slots": main_curve.get("in_flight_slots"), "denoise": bool(main_curve.get("denoise")),
+                   "frames_per_launch": main_curve.get("frames_per_launch", 1),
                    **({"emulated_band": main_curve["emulated_band"]} if main_curve.get("emulated_band") else {}),
                    **({"band_steps_ms": main_curve["band_steps_ms"], "band_balance": main_curve["band_balance"]} if main_curve.get("band_steps_ms") else {}),
                    "rays_per_step": {n: int(x.rays) for n, x in zip(NAMES, st)}, "rays_per_step_all_gpus": int(main_curve["rays_per_step"])},

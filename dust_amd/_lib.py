@@ -170,6 +170,7 @@ SYMBOLS = {
     "dust_hip_pipeline_destroy": (None, [_P]),
     "dust_hip_pipeline_set_noise": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
     "dust_hip_render_frame": (C.c_int, [_P, _P, C.POINTER(Camera), C.POINTER(Sky), C.POINTER(FrameParams)]),
+    "dust_hip_render_frames": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p), _P, C.POINTER(Camera), C.POINTER(Sky), C.POINTER(FrameParams)]),
     "dust_hip_pipeline_pass_stats": (C.c_int, [_P, C.c_uint32, C.POINTER(PassStats)]),
     "dust_hip_pipeline_kernel_times": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "dust_hip_pipeline_tile_costs": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _u32p, _u32p]),

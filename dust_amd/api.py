@@ -466,6 +466,21 @@ class StandardPipeline:
         fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1], surfel_shard[0], surfel_shard[1])
         L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
 
+    @staticmethod
+    def render_frames(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0)):
+        """dust_hip_render_frames: frame i -- cameras[i], skies[i], frame_indices[i], rands[i] -- into pipes[i], the results of len(pipes)
+        render() calls in that order; primary + AO frames of distinct pipelines of one context share ONE persistent launch (up to 8 frames each).
+        cameras / skies: one per frame, or a single Camera / Sky for all of them."""
+        n = len(pipes)
+        cams = (L.Camera * n)(*[(cameras if isinstance(cameras, L.Camera) else cameras[i]) for i in range(n)])
+        one_sky = isinstance(skies, L.Sky) or (not isinstance(skies, (list, tuple)))
+        sk = (L.Sky * n)(*[((skies if isinstance(skies, L.Sky) else sky_struct(skies)) if one_sky else
+                            (skies[i] if isinstance(skies[i], L.Sky) else sky_struct(skies[i]))) for i in range(n)])
+        fps = (L.FrameParams * n)(*[L.FrameParams(C.sizeof(L.FrameParams), passes, int(frame_indices[i]), int(rands[i]) & 0xFFFFFFFF, rows[0], rows[1], 0, 0)
+                                    for i in range(n)])
+        hs = (C.c_void_p * n)(*[p._h for p in pipes])
+        L.check(pipes[0]._lib.dust_hip_render_frames(n, hs, scene._h, cams, sk, fps))
+
     def pass_stats(self, index):
         st = L.PassStats()
         L.check(self._lib.dust_hip_pipeline_pass_stats(self._h, index, C.byref(st)))

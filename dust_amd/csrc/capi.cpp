@@ -28,6 +28,7 @@ namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
+hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, uint32_t experiment, hipStream_t);
 hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
 hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t);
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
@@ -408,6 +409,7 @@ struct Tuning {
   uint32_t in_flight_oversub = 0;  // IN_FLIGHT_OVERSUB (percent)
   bool wide_share = false;         // WIDE_SHARE: two frames in flight on half of the slots each as 1024-thread workgroups, one per CU (experiment)
   bool no_stream_lds = false;   // NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
+  uint32_t batch_experiment = 0;  // BATCH_EXPERIMENT: bits of launch_primary_ao_batch's schedule experiments
   bool packet_gi() const { return gi_path != DUST_GI_PATH_STREAMS; }    // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace)
   bool packet_only() const { return gi_path == DUST_GI_PATH_PACKETS; }  // ... even where the streams are the default
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -439,6 +441,7 @@ struct Tuning {
     t.force_moving = flag("FORCE_MOVING");
     t.in_flight_oversub = std::min(100u, num("IN_FLIGHT_OVERSUB", 0));
     t.wide_share = flag("WIDE_SHARE");
+    t.batch_experiment = num("BATCH_EXPERIMENT", 0);
     return t;
   }
 };
@@ -1848,12 +1851,22 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   return DUST_OK;
 }
-DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
-                                 const DustHipSky* sky, const DustHipFrameParams* fp_in) {
+// Several frames in one persistent launch (dust_hip_render_frames): the frames after the first ("followers") are PREPARED -- descriptor, work
+// counters, tile order -- and left in `frames[1 ..]`; the first frame ("lead"), prepared last, launches k_primary_ao_batch over all of them.
+struct BatchJoin {
+  dust::FrameArgs frames[dust::kMaxBatch];
+  uint32_t n = 0;      // frames of the launch
+  uint32_t slot = 0;   // where the follower being prepared goes
+};
+enum class FrameRole { Single, Follower, Lead };
+// every argument check of a frame, before anything is enqueued or changed (a frame that has started is finished); fp_copy: the caller's
+// parameters widened to this library's struct
+static DustStatus check_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam, const DustHipSky* sky,
+                              const DustHipFrameParams* fp_in, DustHipFrameParams& fp_copy) {
   if (!p || !s || !cam || !sky || !fp_in) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
   // (round 6 appended surfel_rank / surfel_world: a caller compiled against the struct that ends at row_end gets zeroes for them)
   if (fp_in->struct_size < offsetof(DustHipFrameParams, surfel_rank)) return fail(DUST_ERR_INVALID_ARGUMENT, "DustHipFrameParams.struct_size is smaller than this library's DustHipFrameParams");
-  DustHipFrameParams fp_copy{};
+  fp_copy = DustHipFrameParams{};
   std::memcpy(&fp_copy, fp_in, std::min<size_t>(fp_in->struct_size, sizeof fp_copy));
   const DustHipFrameParams* fp = &fp_copy;
   if (p->ctx != s->ctx) return fail(DUST_ERR_INVALID_ARGUMENT, "pipeline and scene belong to different contexts");
@@ -1882,6 +1895,18 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     return fail(DUST_ERR_NOT_READY, "a sharded surfel trace is pending on this pipeline: dust_hip_gi_surfel_exchange_run completes it before the next GI pass");
   if (sharded && (fp->passes & DUST_PASS_FINAL_GATHER) && !p->gi_touched.p)
     return fail(DUST_ERR_NOT_READY, "DUST_PASS_GI_SHARDED: call dust_hip_pipeline_gi_exchange first");
+  {
+    const uint32_t re = fp->row_end ? fp->row_end : p->height;
+    if (fp->row_begin >= re || re > p->height) return fail(DUST_ERR_INVALID_ARGUMENT, "bad row range");
+  }
+  return DUST_OK;
+}
+static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam, const DustHipSky* sky,
+                                    const DustHipFrameParams* fp_in, FrameRole role, BatchJoin* join) {
+  DustHipFrameParams fp_copy{};
+  { DustStatus cs = check_frame(p, s, cam, sky, fp_in, fp_copy); if (cs != DUST_OK) return cs; }
+  const DustHipFrameParams* fp = &fp_copy;
+  const bool sharded = (fp->passes & DUST_PASS_GI_SHARDED) != 0;
   if ((fp->passes & (DUST_PASS_FINAL_GATHER | DUST_PASS_SURFEL)) && !p->gi_hash.p) {
     DustStatus gs = dust_hip_pipeline_configure_gi(p, dust::kSpatialHashCapacity, dust::kSurfelPoolSize);
     if (gs != DUST_OK) return gs;
@@ -1992,7 +2017,10 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
   p->stats_valid = false;
   // An event pair around a launch costs the stream ~6 us per record (a marker packet the next dispatch waits behind): 5 % of a
   // 0.23 ms frame. A context that only wants averages over a run of frames (bench.py) times every 4th frame's launches.
-  p->timed_frame = ctx->timing && (p->frame_counter++ % ctx->timing_stride) == 0;
+  // (a follower of a batched launch has no launch of its own to time: the lead's pair brackets the launch of all of its frames)
+  // -- at the same rate PER FRAME as single launches are: a launch of n frames counts as n of the stride
+  const uint32_t stride = role == FrameRole::Lead ? std::max(1u, ctx->timing_stride / join->n) : ctx->timing_stride;
+  p->timed_frame = role != FrameRole::Follower && ctx->timing && (p->frame_counter++ % stride) == 0;
   // (a frame that is not timed has no times: dust_hip_pipeline_pass_stats must not hand out an earlier frame's)
   if (!p->timed_frame) for (bool& v : p->ev_valid) v = false;
   // while a surfel pass may be running on the second stream, the primary / AO kernels leave it its share of the slots (persistent
@@ -2066,15 +2094,23 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     s->slots[s->current].last_seq = x.started_seq;
   };
   if (calibrate) HIP_TRY(hipEventRecord(p->side_cal.p0, st));
+  if (role != FrameRole::Single && (!fuse || count)) return fail(DUST_ERR_INVALID_ARGUMENT, "a batched frame must be a fused primary + AO frame");  // (dust_hip_render_frames checks)
   if (fuse) {
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
+    if (role == FrameRole::Follower) {   // prepared; the lead launches it
+      join->frames[join->slot] = a;
+      for (bool& v : p->ev_valid) v = false;
+      return DUST_OK;
+    }
     if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
     // One 1024-thread workgroup per CU when the kernel has the device to itself (no surfel pass beside it, one frame in flight,
     // no slots reserved, the default block size): the roots are staged once per CU and sixteen waves share a tile queue
     uint32_t fblock = block, fgrid = grid;
-    const size_t lds_wide = size_t(a.n_lds_models) * dust::kN16LdsBytes + 16u * (dust::kMaxCand * 8 + 8) + 16 + size_t(a.n_lds_boxes) * 32;
+    const size_t batch_lds = role == FrameRole::Lead ? 16u * (join->n - 1u) : 0u;   // a tile queue per further frame
+    if (lds + batch_lds > ctx->max_lds) return fail(DUST_ERR_INVALID_ARGUMENT, "staged roots and candidate lists exceed the device's LDS");
+    const size_t lds_wide = size_t(a.n_lds_models) * dust::kN16LdsBytes + 16u * (dust::kMaxCand * 8 + 8) + 16 + size_t(a.n_lds_boxes) * 32 + batch_lds;
     if (tune.wide_fused && block == 512 && bpc == 2 && !ctx->side_busy && !share_slots && !reserve_blocks && lds_wide <= ctx->max_lds &&
         grid == resident) {
       fblock = 1024;
@@ -2086,7 +2122,12 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
       fgrid = std::max(8u, (frame_slots / 2u) & ~7u);
     }
     say_start(a);
-    HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
+    if (role == FrameRole::Lead) {
+      join->frames[0] = a;
+      HIP_TRY(dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, tune.batch_experiment, st));
+    } else {
+      HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
+    }
     a.started_word = nullptr;
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
   }
@@ -2230,6 +2271,67 @@ DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, cons
     p->stats_valid = true;
   }
   return DUST_OK;
+}
+
+DustStatus dust_hip_render_frame(DustHipPipeline* p, const DustHipScene* s, const DustHipCamera* cam,
+                                 const DustHipSky* sky, const DustHipFrameParams* fp_in) {
+  return render_frame_impl(p, s, cam, sky, fp_in, FrameRole::Single, nullptr);
+}
+// The frames [0, n) can share one launch: fused primary + AO frames and nothing else, of distinct pipelines of the scene's context with one
+// frame size, one row band and the same launch-shaping settings, and no surfel pass outstanding beside them.
+static bool batchable(uint32_t n, DustHipPipeline* const* pipes, const DustHipScene* s, const DustHipFrameParams* fps) {
+  if (n < 2 || n > dust::kMaxBatch) return false;
+  const DustHipPipeline* p0 = pipes[0];
+  if (p0->ctx != s->ctx || p0->ctx->side_busy) return false;
+  const uint32_t want = DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION;
+  for (uint32_t i = 0; i < n; ++i) {
+    const DustHipPipeline* p = pipes[i];
+    const Tuning& t = p->tune; const Tuning& t0 = p0->tune;
+    if (p->ctx != p0->ctx || p->width != p0->width || p->height != p0->height) return false;
+    if (fps[i].passes != want || fps[i].row_begin != fps[0].row_begin || fps[i].row_end != fps[0].row_end) return false;
+    if (t.no_fuse || t.block != t0.block || t.blocks_per_cu != t0.blocks_per_cu || t.no_lds_boxes != t0.no_lds_boxes || t.wide_fused != t0.wide_fused ||
+        t.debug != t0.debug || t.static_rounds != t0.static_rounds || t.reserve_blocks != t0.reserve_blocks || p->in_collective != p0->in_collective ||
+        t.in_flight_slots != t0.in_flight_slots || p->frames_in_flight != p0->frames_in_flight)
+      return false;
+    for (uint32_t j = 0; j < i; ++j)
+      if (pipes[j] == p) return false;   // (the same pipeline twice: the second frame overwrites the first -- in sequence)
+  }
+  return true;
+}
+DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pipelines, const DustHipScene* s, const DustHipCamera* cameras,
+                                  const DustHipSky* skies, const DustHipFrameParams* params) {
+  if (!pipelines || !s || !cameras || !skies || !params) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
+  if (!n_frames) return DUST_OK;
+  return guarded([&]() -> DustStatus {
+  // every frame's arguments are checked before the first one is enqueued
+  std::vector<DustHipFrameParams> fps(n_frames);
+  for (uint32_t i = 0; i < n_frames; ++i) {
+    // (params[] is an array of THIS library's struct: every element must say so, or the stride is not ours)
+    if (params[i].struct_size != sizeof(DustHipFrameParams)) return fail(DUST_ERR_INVALID_ARGUMENT, "dust_hip_render_frames: params[i].struct_size must be sizeof(DustHipFrameParams)");
+    DustStatus cs = check_frame(pipelines[i], s, &cameras[i], &skies[i], &params[i], fps[i]);
+    if (cs != DUST_OK) return cs;
+  }
+  for (uint32_t at = 0; at < n_frames;) {
+    const uint32_t n = std::min<uint32_t>(dust::kMaxBatch, n_frames - at);
+    if (!batchable(n, pipelines + at, s, fps.data() + at)) {   // one frame, or frames that cannot share a launch: in sequence, the same results
+      DustStatus rs = render_frame_impl(pipelines[at], s, &cameras[at], &skies[at], &params[at], FrameRole::Single, nullptr);
+      if (rs != DUST_OK) return rs;
+      at += 1;
+      continue;
+    }
+    BatchJoin join;
+    join.n = n;
+    for (uint32_t i = 1; i < n; ++i) {
+      join.slot = i;
+      DustStatus rs = render_frame_impl(pipelines[at + i], s, &cameras[at + i], &skies[at + i], &params[at + i], FrameRole::Follower, &join);
+      if (rs != DUST_OK) return rs;
+    }
+    DustStatus rs = render_frame_impl(pipelines[at], s, &cameras[at], &skies[at], &params[at], FrameRole::Lead, &join);
+    if (rs != DUST_OK) return rs;
+    at += n;
+  }
+  return DUST_OK;
+  });
 }
 
 DustStatus dust_hip_pipeline_pass_stats(DustHipPipeline* p, uint32_t pass, DustHipPassStats* out) {

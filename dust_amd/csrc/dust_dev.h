@@ -46,6 +46,7 @@ constexpr uint32_t kFlatCullMax = 256;   // instances up to which the packet cul
 constexpr uint32_t kMaxCand = 160;       // per-wave candidate list capacity: one u32 {entry time hi16 | id16} each, twice (sort staging)
 constexpr uint32_t kSurfelPoolSize = 720 * 480;  // surfel.glsl:2, standard.rs:338
 constexpr uint32_t kSpatialHashCapacity = 32u * 1024u * 1024u;  // spatial_hash.glsl:1
+constexpr uint32_t kMaxBatch = 8;   // frames ONE persistent launch of the fused pixel passes can carry (dust_hip_render_frames; BatchArgs)
 constexpr uint32_t kApplyKeep = 8;  // DUST_PASS_GI_ORDERED: inserts of ONE key that a frame applies (the last kApplyKeep in surfel order; gi.hip, k_surfel_apply_mark)
 
 struct DevN4 {
@@ -280,6 +281,20 @@ struct FrameArgs {
   unsigned long long* apply_starts;   // [0, words): bit i = position i begins a CLUSTER (requests whose probe windows may overlap); [words, 2 words): bit i =
                                       // position i begins a RUN of one location. A thread finds where its cluster and its runs end by scanning words, not keys
   uint32_t apply_words;
+  // ---- round 6, second half: several frames in ONE persistent launch (dust_hip_render_frames, k_primary_ao_batch). Set in the FIRST descriptor of
+  // a BatchArgs only: how many of its descriptors are frames of this launch. 0 / 1 everywhere else.
+  uint32_t batch_frames;
+  uint32_t band_tries;        // bands a workgroup tries before it gives the frame up: kRegions (its own, then the others'), or 1 for a frame of a batched launch that is
+                              // not the last (experiment BATCH_OWN_BANDS: the other bands' leftovers are their own workgroups' business, this one goes on to the next frame)
+  uint32_t prio_off;          // experiment BATCH_NO_PRIO: tiles start at issue priority 0 whatever their place in the order
+};
+
+// The kernel argument of k_primary_ao_batch: up to kMaxBatch whole launch descriptors, one per frame, side by side in the kernel-argument segment
+// (8.5 KB; the runtime takes 16 KB, probed on an MI355X). The frames share scene, frame size, rows and launch geometry -- what is staged in LDS and
+// how the waves are numbered --; camera, sky, noise slices, planes, tile order / costs / cuts and work counters are each frame's own. A wave that
+// finds frame f without tiles goes on to frame f + 1: ONE launch tail, one staging and one inter-launch gap for batch_frames frames.
+struct BatchArgs {
+  FrameArgs f[kMaxBatch];
 };
 
 }  // namespace dust

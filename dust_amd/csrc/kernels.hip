@@ -235,6 +235,42 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
   flush_stats<MODE>(a0, 2, st_ao);
 }
 
+// Several frames in ONE persistent launch (dust_hip_render_frames): the kernel argument is a BatchArgs, `batch_frames` whole launch
+// descriptors side by side. The frames share what is staged in LDS (one scene) and the launch geometry; a wave that finds frame f without
+// tiles -- its own band's, then the others' -- takes the next frame's descriptor and queue and goes on, so the launch has ONE tail (waves idle
+// behind the last long tiles), one staging of the roots and one inter-launch gap for all of its frames: the per-launch costs that are what
+// is left of the 1080p frame (4 % + 1 % + 1.9 %). Each frame writes the planes of ITS pipeline with the bits the single-frame
+// kernel writes (same packets, same arithmetic; tests/test_gpu_batch.py). The reference keeps up to three frames in flight
+// (rhyolite_bevy/src/lib.rs:58); the GI passes cannot ride along: a frame's gather reads the hash its predecessor's surfel pass wrote.
+// Frames after the first are not dealt a first round (with_schedule_follower): their waves arrive one by one and take the most expensive
+// tiles left, in order.
+template <int MODE>
+__global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao_batch(const BatchArgs) {
+  ArgsRef lead = launch_args();
+  stage_roots(lead);
+  uint32_t* cand = wave_cand_list(lead);
+  LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};  // (never a counting build: dead)
+  const uint32_t n_frames = lead.batch_frames;
+#pragma unroll 1
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const DUST_CONST_AS FrameArgs* fq = &launch_args() + f;
+    asm volatile("" : "+s"(fq));
+    ArgsRef a0 = *fq;
+    // (frame 0's set was zeroed by stage_roots; nobody reads these before the next launch of that pipeline, stream-ordered behind this one)
+    if (f != 0u && blockIdx.x == 0 && threadIdx.x < kRegions) a0.next_work_counters[threadIdx.x * kCounterStride] = 0u;
+    WorkCursor wc = cursor_begin();
+    wc.frame = f;
+    Packet p;
+    while (next_packet(a0, wc, p)) {
+      float hitT;
+      uint32_t npk;
+      primary_packet<MODE>(reload_args(a0), p, cand, st, false, hitT, npk);
+      ao_packet<MODE>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));
+    }
+  }
+  prof_end();
+}
+
 // ==================================================================== N-frame mean (stands in for NRD)
 __global__ void k_accumulate(const FrameArgs) {
   ArgsRef a = launch_args();
@@ -669,6 +705,29 @@ hipError_t launch_primary_ao(const FrameArgs& a_in, uint32_t grid, uint32_t bloc
   DUST_LAUNCH_MODE(k_primary_ao, count, a_in);
   return hipGetLastError();
 }
+// n frames (2 .. kMaxBatch) in one launch; frames[0] decides the kernel variant and the geometry. Frames after the first: no dealt round.
+// experiment bits (diagnostic, Tuning::batch_experiment): 1 = the further frames are dealt a first round too, 2 = no position priorities in frames
+// before the last, 4 = frames before the last: a workgroup stays on its own band
+hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, uint32_t experiment, hipStream_t s) {
+  if (n < 1u || n > kMaxBatch) return hipErrorInvalidValue;
+  const size_t lds = lds_bytes(frames[0], block) + 16u * (n - 1u);   // + a tile queue per further frame (frame_queue)
+  BatchArgs b;
+  for (uint32_t i = 0; i < n; ++i) {
+    b.f[i] = with_schedule(frames[i], grid, block);
+    if (i && !(experiment & 1u)) b.f[i].static_rounds = 0u;
+    if ((experiment & 2u) && i + 1u < n) b.f[i].prio_off = 1u;
+    if ((experiment & 4u) && i + 1u < n) b.f[i].band_tries = 1u;
+    b.f[i].batch_frames = i ? 0u : n;
+  }
+  for (uint32_t i = n; i < kMaxBatch; ++i) b.f[i] = b.f[0];   // (never read)
+  switch ((b.f[0].deep ? 2 : 0) | (b.f[0].n_groups ? 4 : 0)) {
+    case 0: hipLaunchKernelGGL(k_primary_ao_batch<0>, dim3(grid), dim3(block), lds, s, b); break;
+    case 2: hipLaunchKernelGGL(k_primary_ao_batch<2>, dim3(grid), dim3(block), lds, s, b); break;
+    case 4: hipLaunchKernelGGL(k_primary_ao_batch<4>, dim3(grid), dim3(block), lds, s, b); break;
+    default: hipLaunchKernelGGL(k_primary_ao_batch<6>, dim3(grid), dim3(block), lds, s, b); break;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_ambient_occlusion(const FrameArgs& a_in, uint32_t grid, uint32_t block, bool count, hipStream_t s) {
   const size_t lds = lds_bytes(a_in, block);
   DUST_LAUNCH_MODE(k_ambient_occlusion, count, a_in);
@@ -690,7 +749,8 @@ hipError_t configure_kernels(size_t max_lds) {
   const void* fns[] = {
       (const void*)k_primary<0>, (const void*)k_primary<1>, (const void*)k_primary<2>, (const void*)k_primary<3>, (const void*)k_primary<4>, (const void*)k_primary<5>, (const void*)k_primary<6>, (const void*)k_primary<7>,
       (const void*)k_ambient_occlusion<0>, (const void*)k_ambient_occlusion<1>, (const void*)k_ambient_occlusion<2>, (const void*)k_ambient_occlusion<3>, (const void*)k_ambient_occlusion<4>, (const void*)k_ambient_occlusion<5>, (const void*)k_ambient_occlusion<6>, (const void*)k_ambient_occlusion<7>,
-      (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>, (const void*)k_primary_ao<4>, (const void*)k_primary_ao<5>, (const void*)k_primary_ao<6>, (const void*)k_primary_ao<7>};
+      (const void*)k_primary_ao<0>, (const void*)k_primary_ao<1>, (const void*)k_primary_ao<2>, (const void*)k_primary_ao<3>, (const void*)k_primary_ao<4>, (const void*)k_primary_ao<5>, (const void*)k_primary_ao<6>, (const void*)k_primary_ao<7>,
+      (const void*)k_primary_ao_batch<0>, (const void*)k_primary_ao_batch<2>, (const void*)k_primary_ao_batch<4>, (const void*)k_primary_ao_batch<6>};
   for (const void* f : fns) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
     if (e != hipSuccess) return e;

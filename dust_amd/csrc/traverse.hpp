@@ -1429,6 +1429,7 @@ struct Packet {
 // (even) and 16 (+5 %: tail).
 struct WorkCursor {
   uint32_t round;       // dealt rounds taken so far
+  uint32_t frame;       // k_primary_ao_batch: which frame of the launch the wave is handing itself tiles of (0 everywhere else: folded away)
 };
 __device__ __forceinline__ uint32_t band_static_tickets(uint32_t band) {  // waves whose own band this is
   return ((gridDim.x + 7u - band) >> 3) * (blockDim.x >> 6);
@@ -1436,6 +1437,7 @@ __device__ __forceinline__ uint32_t band_static_tickets(uint32_t band) {  // wav
 __device__ __forceinline__ WorkCursor cursor_begin() {
   WorkCursor w;
   w.round = 0;
+  w.frame = 0;
   return w;
 }
 // After the dealt rounds a workgroup's waves share a small queue in LDS: {next, end} in one 64-bit word, taken from
@@ -1449,6 +1451,16 @@ constexpr uint32_t kGrabBatch = DUST_GRAB_BATCH;
 constexpr uint32_t kQueueDone = 0x80000000u;  // {end = 0, next >= kQueueDone}: no tiles left anywhere
 __device__ __forceinline__ unsigned long long* block_queue(ArgsRef a) {  // behind the per-wave candidate lists, zeroed by stage_roots
   return reinterpret_cast<unsigned long long*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u));
+}
+__device__ __forceinline__ u32x4* lds_boxes(ArgsRef a) {  // behind the queue and the per-wave tile accounts (16-byte aligned: every part before it is)
+  return reinterpret_cast<u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
+}
+// A launch of several frames (k_primary_ao_batch) has a tile queue {next, end} + band_try PER FRAME: a wave that has seen frame f's queue done moves
+// on while its neighbours are still on frame f's last tiles, so the two queues are live at once. Frame 0's is block_queue; the others' stand behind
+// the boxes, at the very end of the launch's LDS (lds_bytes + 16 per further frame).
+__device__ __forceinline__ unsigned long long* frame_queue(ArgsRef a, uint32_t frame) {
+  if (frame == 0u) return block_queue(a);
+  return reinterpret_cast<unsigned long long*>(lds_boxes(a) + a.n_lds_boxes * 2u) + (frame - 1u) * 2u;
 }
 // The tile a wave is working on and when it started, in the wave's LDS slot behind the workgroup's queue: next_packet closes
 // the previous tile's account (cycles -> a.tile_cost) when the wave comes back for more. No register is carried for it.
@@ -1484,7 +1496,7 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     // waves that give way have slack.
     // (round 4: without these priorities the kernel is 8-10 % slower; six other gradings and static per-slot priorities: no better)
     const uint32_t rank = pos < (per >> 5) ? 3u : (pos < (per >> 3) ? 2u : (pos < (per >> 1) ? 1u : 0u));
-    const uint32_t prio = rank > a.prio_floor ? rank : a.prio_floor;
+    const uint32_t prio = a.prio_off ? 0u : (rank > a.prio_floor ? rank : a.prio_floor);
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
@@ -1516,7 +1528,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     if (pos < bn) { packet_of_tile(a, blo + pos, pos, bn, p); PROF_LEAVE(P_GRAB); return true; }
     w.round = a.static_rounds;  // (a band shorter than the deal: on to the queue, which is empty for it too)
   }
-  unsigned long long* q = block_queue(a);
+  unsigned long long* q = frame_queue(a, w.frame);
   volatile unsigned long long* qv = q;
   volatile uint32_t* band_try = reinterpret_cast<volatile uint32_t*>(q + 1);  // bands this workgroup has given up on
   for (;;) {
@@ -1537,7 +1549,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     // exactly empty: this wave refills. Own band first, then the others' (a band stays in one XCD's L2 while it lasts).
     uint32_t bt = (uint32_t)__builtin_amdgcn_readfirstlane((int)*band_try);
     for (;;) {
-      if (bt >= kRegions) {
+      if (bt >= a.band_tries) {
         if (lane == 0) *qv = (unsigned long long)kQueueDone;
         account_tile(a, 0xFFFFFFFFu);
         PROF_LEAVE(P_GRAB);
@@ -1564,9 +1576,6 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
   }
 }
 
-__device__ __forceinline__ u32x4* lds_boxes(ArgsRef a) {  // behind the queue and the per-wave tile accounts (16-byte aligned: every part before it is)
-  return reinterpret_cast<u32x4*>(g_lds + a.n_lds_models * kN16LdsBytes + (blockDim.x >> 6) * (kMaxCand * 8u + 8u) + 16u);
-}
 __device__ __forceinline__ void prof_begin() {
 #ifdef DUST_PROFILE
   if ((threadIdx.x & 63u) == 0)
@@ -1593,6 +1602,7 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.started_word)  // (dust_dev.h: the frame's first launch tells the host it is running)
     __hip_atomic_store((uint32_t*)a.started_word, a.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(block_queue(a))[threadIdx.x] = 0u;  // {next, end} = {0, 0}: empty; band_try = 0
+  if (a.batch_frames > 1u && threadIdx.x < 4u * (a.batch_frames - 1u)) reinterpret_cast<uint32_t*>(frame_queue(a, 1u))[threadIdx.x] = 0u;  // the further frames' queues
   if (threadIdx.x < (blockDim.x >> 6) * 2u) reinterpret_cast<uint32_t*>(block_queue(a) + 2)[threadIdx.x] = 0xFFFFFFFFu;  // per-wave tile accounts: none open
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
@@ -1918,6 +1928,7 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;
   a.static_rounds = rounds >= 1u ? 1u : 0u;  // (see next_packet: dealing more than the first round was measured and lost)
   if (a.static_rounds_request != 0xFFFFFFFFu) a.static_rounds = a.static_rounds_request;
+  if (!a.band_tries) a.band_tries = kRegions;
   return a;
 }
 // kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model), bit 2 = LARGE (more than kFlatCullMax instances)

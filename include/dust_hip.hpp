@@ -319,6 +319,23 @@ class StandardPipeline {
     check(s);
     return true;
   }
+  // Frames in flight (rhyolite_bevy/src/lib.rs:58): n frames, frame i into pipelines[i], as n render() calls in that order; primary + AO frames of
+  // distinct pipelines of one context share one persistent launch (dust_hip_render_frames). false where any of them is not ready.
+  static bool render_frames(StandardPipeline* const* pipelines, uint32_t n, const Scene& scene, const DustHipCamera* cameras, const DustHipSky* skies,
+                            uint32_t passes, const uint32_t* frame_indices, const uint32_t* rands, uint32_t row_begin = 0, uint32_t row_end = 0) {
+    std::vector<DustHipPipeline*> hs(n);
+    std::vector<DustHipFrameParams> fps(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      hs[i] = pipelines[i]->h_;
+      fps[i] = DustHipFrameParams{};
+      fps[i].struct_size = sizeof(DustHipFrameParams);
+      fps[i].passes = passes; fps[i].frame_index = frame_indices[i]; fps[i].rand = rands[i]; fps[i].row_begin = row_begin; fps[i].row_end = row_end;
+    }
+    const DustStatus s = dust_hip_render_frames(n, hs.data(), scene.raw(), cameras, skies, fps.data());
+    if (s == DUST_ERR_NOT_READY) return false;
+    check(s);
+    return true;
+  }
   // NRDPipeline settings / DenoiserEvent::Restart for DUST_PASS_DENOISE
   void set_denoiser(const ReblurSettings& r) {
     DustHipDenoiseParams dp{sizeof(DustHipDenoiseParams), r.max_accumulated_frame_num, r.disocclusion_threshold, r.luminance_sigma_scale,
