@@ -369,7 +369,7 @@ def measure_curve(be, dist, args, lanes, shard):
         slots_mode = "share" if (bands and (world > 1 or emulate)) else "all"
     for lane in lanes:
         if batched:
-            pass   # (one launch at a time, on every slot)
+            lane.pipe.configure(frames_in_flight=1, in_flight_slots=slots_mode)   # one launch at a time, on every slot; the frames of a launch have ONE configuration
         elif hasattr(lane.pipe, "configure"):
             lane.pipe.configure(frames_in_flight=D, in_flight_slots=slots_mode)  # D launches side by side on 1/D of the workgroup slots each, or one behind the other's tail
         else:
@@ -634,6 +634,13 @@ def measure_curve(be, dist, args, lanes, shard):
     ms = [(ev_ms[k] / ev_n[k]) if ev_n[k] else 0.0 for k in range(4)]
     if not gi_mode:
         ms[2] = ms[3] = 0.0
+    # --frames-per-launch: did the frames share launches? (dust_hip_render_frames enqueues frames that do not qualify one after the other, with the
+    # same results: a launch of D frames lasts about D steps, a frame's own launch one.) If they did not, the line says so and accounts per frame.
+    launch_frames = (args.steps / -(-args.steps // D)) if batched else 1.0
+    shared_launches = batched and ms[0] > 0.6 * launch_frames * (elapsed / args.steps * 1e3)
+    if batched and not shared_launches:
+        sys.stderr.write("bench.py: --frames-per-launch: the frames did not share a launch (kernel time of ONE frame); accounted per frame\n")
+        launch_frames = 1.0
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
     rays_all = torch.tensor([float(rays_rank)], dtype=torch.float64, device=be.device)
@@ -651,9 +658,9 @@ def measure_curve(be, dist, args, lanes, shard):
     return {"shard": shard, "scaling": "strong" if bands else "weak", "elapsed": elapsed, "rays_per_step": rays,
             "ms_per_step": elapsed / args.steps * 1e3, "mrays": rays * args.steps / elapsed / 1e6, "ranks_seen": int(seen.item()),
             "st": st, "ms": ms, "launches": max(ev_n) if ev_n else 0, "per_rank": [[float(x) for x in v.tolist()] for v in per_rank],
-            "frames_per_launch": D if batched else 1,
+            "frames_per_launch": D if (batched and shared_launches) else 1,
             # frames per launch of the timed region, averaged (a last launch of fewer frames counts): what a launch's algorithmic bytes are a multiple of
-            "launch_frames": (args.steps / -(-args.steps // D)) if batched else 1.0,
+            "launch_frames": launch_frames,
             "per_rows": per_rows, "assemble": assemble, "slices": slices, "settle": settle, "frames_in_flight": 1 if batched else D, "in_flight_slots": slots_mode if D > 1 else None, "band_cuts": band_cuts,
             "comm": "native" if native else "torch", "denoise": denoise, "band_balance": balance_log or None,
             "band_steps_ms": [round(v, 4) for v in band_steps_ms] if band_steps_ms else None, "emulated_band": (f"{er}/{en}" if emulate else None)}
@@ -992,6 +999,8 @@ def run_rank(args, be, dist):
             key = "castle-standin" if not deep else "deep-tree"
             if pm.get("workload") == key and abs(pm.get("scale", 1.0) - args.scale) < 1e-9:
                 traffic = pm.get("hbm_bytes_per_launch", {}).get(dominant[0])
+                if dominant[0] == "primary_ao_batch" and main_curve.get("frames_per_launch") != pm.get("primary_ao_batch_frames"):
+                    traffic = None   # (the counter passes' launches carried another number of frames)
             if deep:
                 traffic = pm.get("deep", {}).get("hbm_bytes_per_launch", {}).get(dominant[0])
             if traffic is not None:

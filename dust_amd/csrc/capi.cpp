@@ -28,7 +28,7 @@ namespace dust {
 hipError_t launch_primary(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_ambient_occlusion(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
 hipError_t launch_primary_ao(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, hipStream_t);
-hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, uint32_t experiment, hipStream_t);
+hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, hipStream_t);
 hipError_t launch_final_gather(const FrameArgs& a, uint32_t grid, uint32_t block, bool count, bool commit, hipStream_t);
 hipError_t launch_final_gather_shade(const FrameArgs& a, bool commit, hipStream_t);
 hipError_t launch_gather_order(const FrameArgs& a, uint32_t n_tiles, hipStream_t);
@@ -409,7 +409,6 @@ struct Tuning {
   uint32_t in_flight_oversub = 0;  // IN_FLIGHT_OVERSUB (percent)
   bool wide_share = false;         // WIDE_SHARE: two frames in flight on half of the slots each as 1024-thread workgroups, one per CU (experiment)
   bool no_stream_lds = false;   // NO_STREAM_LDS: the ray streams read grid, boxes and enter records from memory
-  uint32_t batch_experiment = 0;  // BATCH_EXPERIMENT: bits of launch_primary_ao_batch's schedule experiments
   bool packet_gi() const { return gi_path != DUST_GI_PATH_STREAMS; }    // the GI passes a packet of 64 rays at a time (k_final_gather, k_surfel_trace)
   bool packet_only() const { return gi_path == DUST_GI_PATH_PACKETS; }  // ... even where the streams are the default
   static uint32_t num(const char* name, uint32_t dflt) {
@@ -441,7 +440,6 @@ struct Tuning {
     t.force_moving = flag("FORCE_MOVING");
     t.in_flight_oversub = std::min(100u, num("IN_FLIGHT_OVERSUB", 0));
     t.wide_share = flag("WIDE_SHARE");
-    t.batch_experiment = num("BATCH_EXPERIMENT", 0);
     return t;
   }
 };
@@ -2124,7 +2122,7 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
     say_start(a);
     if (role == FrameRole::Lead) {
       join->frames[0] = a;
-      HIP_TRY(dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, tune.batch_experiment, st));
+      HIP_TRY(dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st));
     } else {
       HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
     }
@@ -2291,7 +2289,7 @@ static bool batchable(uint32_t n, DustHipPipeline* const* pipes, const DustHipSc
     if (fps[i].passes != want || fps[i].row_begin != fps[0].row_begin || fps[i].row_end != fps[0].row_end) return false;
     if (t.no_fuse || t.block != t0.block || t.blocks_per_cu != t0.blocks_per_cu || t.no_lds_boxes != t0.no_lds_boxes || t.wide_fused != t0.wide_fused ||
         t.debug != t0.debug || t.static_rounds != t0.static_rounds || t.reserve_blocks != t0.reserve_blocks || p->in_collective != p0->in_collective ||
-        t.in_flight_slots != t0.in_flight_slots || p->frames_in_flight != p0->frames_in_flight)
+        p->frames_in_flight != p0->frames_in_flight || (p->frames_in_flight > 1 && t.in_flight_slots != t0.in_flight_slots))
       return false;
     for (uint32_t j = 0; j < i; ++j)
       if (pipes[j] == p) return false;   // (the same pipeline twice: the second frame overwrites the first -- in sequence)

@@ -284,9 +284,6 @@ struct FrameArgs {
   // ---- round 6, second half: several frames in ONE persistent launch (dust_hip_render_frames, k_primary_ao_batch). Set in the FIRST descriptor of
   // a BatchArgs only: how many of its descriptors are frames of this launch. 0 / 1 everywhere else.
   uint32_t batch_frames;
-  uint32_t band_tries;        // bands a workgroup tries before it gives the frame up: kRegions (its own, then the others'), or 1 for a frame of a batched launch that is
-                              // not the last (experiment BATCH_OWN_BANDS: the other bands' leftovers are their own workgroups' business, this one goes on to the next frame)
-  uint32_t prio_off;          // experiment BATCH_NO_PRIO: tiles start at issue priority 0 whatever their place in the order
 };
 
 // The kernel argument of k_primary_ao_batch: up to kMaxBatch whole launch descriptors, one per frame, side by side in the kernel-argument segment

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
 template <int MODE>
 __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao_batch(const BatchArgs) {
   ArgsRef lead = launch_args();
-  stage_roots(lead);
+  stage_roots_of<true>(lead);
   uint32_t* cand = wave_cand_list(lead);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};  // (never a counting build: dead)
   const uint32_t n_frames = lead.batch_frames;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
     WorkCursor wc = cursor_begin();
     wc.frame = f;
     Packet p;
-    while (next_packet(a0, wc, p)) {
+    while (next_packet_of<true>(a0, wc, p)) {
       float hitT;
       uint32_t npk;
       primary_packet<MODE>(reload_args(a0), p, cand, st, false, hitT, npk);
@@ -706,17 +706,16 @@ hipError_t launch_primary_ao(const FrameArgs& a_in, uint32_t grid, uint32_t bloc
   return hipGetLastError();
 }
 // n frames (2 .. kMaxBatch) in one launch; frames[0] decides the kernel variant and the geometry. Frames after the first: no dealt round.
-// experiment bits (diagnostic, Tuning::batch_experiment): 1 = the further frames are dealt a first round too, 2 = no position priorities in frames
-// before the last, 4 = frames before the last: a workgroup stays on its own band
-hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, uint32_t experiment, hipStream_t s) {
+// n frames (2 .. kMaxBatch) in one launch; frames[0] decides the kernel variant and the geometry. Frames after the first: no dealt round.
+hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, hipStream_t s) {
   if (n < 1u || n > kMaxBatch) return hipErrorInvalidValue;
   const size_t lds = lds_bytes(frames[0], block) + 16u * (n - 1u);   // + a tile queue per further frame (frame_queue)
   BatchArgs b;
   for (uint32_t i = 0; i < n; ++i) {
     b.f[i] = with_schedule(frames[i], grid, block);
-    if (i && !(experiment & 1u)) b.f[i].static_rounds = 0u;
-    if ((experiment & 2u) && i + 1u < n) b.f[i].prio_off = 1u;
-    if ((experiment & 4u) && i + 1u < n) b.f[i].band_tries = 1u;
+    // (a dealt tile is BOUND to its wave: a wave held up by a long tile of frame i would sit on the most expensive tiles of every later frame --
+    //  measured on 1/8 row bands: 0.095 ms per band frame against 0.039)
+    if (i) b.f[i].static_rounds = 0u;
     b.f[i].batch_frames = i ? 0u : n;
   }
   for (uint32_t i = n; i < kMaxBatch; ++i) b.f[i] = b.f[0];   // (never read)

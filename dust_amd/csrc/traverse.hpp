@@ -1496,7 +1496,7 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
     // waves that give way have slack.
     // (round 4: without these priorities the kernel is 8-10 % slower; six other gradings and static per-slot priorities: no better)
     const uint32_t rank = pos < (per >> 5) ? 3u : (pos < (per >> 3) ? 2u : (pos < (per >> 1) ? 1u : 0u));
-    const uint32_t prio = a.prio_off ? 0u : (rank > a.prio_floor ? rank : a.prio_floor);
+    const uint32_t prio = rank > a.prio_floor ? rank : a.prio_floor;
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
@@ -1513,7 +1513,8 @@ __device__ __forceinline__ void packet_of_tile(ArgsRef a, uint32_t ticket, uint3
   p.py = a.row_begin + ty * kTileH + (lane / kTileW);
   p.valid = p.px < a.width && p.py < a.row_end;
 }
-__device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) {
+template <bool BATCH>   // BATCH: a launch of several frames (k_primary_ao_batch) -- the queue is frame w.frame's; else the workgroup's one queue
+__device__ __forceinline__ bool next_packet_of(ArgsRef a, WorkCursor& w, Packet& p) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t own = blockIdx.x & 7u;
   PROF_ENTER(P_GRAB);
@@ -1528,7 +1529,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     if (pos < bn) { packet_of_tile(a, blo + pos, pos, bn, p); PROF_LEAVE(P_GRAB); return true; }
     w.round = a.static_rounds;  // (a band shorter than the deal: on to the queue, which is empty for it too)
   }
-  unsigned long long* q = frame_queue(a, w.frame);
+  unsigned long long* q = BATCH ? frame_queue(a, w.frame) : block_queue(a);
   volatile unsigned long long* qv = q;
   volatile uint32_t* band_try = reinterpret_cast<volatile uint32_t*>(q + 1);  // bands this workgroup has given up on
   for (;;) {
@@ -1549,7 +1550,7 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
     // exactly empty: this wave refills. Own band first, then the others' (a band stays in one XCD's L2 while it lasts).
     uint32_t bt = (uint32_t)__builtin_amdgcn_readfirstlane((int)*band_try);
     for (;;) {
-      if (bt >= a.band_tries) {
+      if (bt >= kRegions) {
         if (lane == 0) *qv = (unsigned long long)kQueueDone;
         account_tile(a, 0xFFFFFFFFu);
         PROF_LEAVE(P_GRAB);
@@ -1576,6 +1577,8 @@ __device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p)
   }
 }
 
+__device__ __forceinline__ bool next_packet(ArgsRef a, WorkCursor& w, Packet& p) { return next_packet_of<false>(a, w, p); }
+
 __device__ __forceinline__ void prof_begin() {
 #ifdef DUST_PROFILE
   if ((threadIdx.x & 63u) == 0)
@@ -1593,7 +1596,8 @@ __device__ __forceinline__ void prof_end() {
     for (int i = 0; i < kProfBuckets; ++i) atomicAdd(&g_prof_out[i], g_prof[threadIdx.x >> 6][i]);
 #endif
 }
-__device__ __forceinline__ void stage_roots(ArgsRef a) {
+template <bool BATCH>
+__device__ __forceinline__ void stage_roots_of(ArgsRef a) {
   prof_begin();
 #ifdef DUST_TRACE_DEBUG
   if (threadIdx.x < 16) g_dbg_mask[threadIdx.x] = 0;
@@ -1602,7 +1606,7 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.started_word)  // (dust_dev.h: the frame's first launch tells the host it is running)
     __hip_atomic_store((uint32_t*)a.started_word, a.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(block_queue(a))[threadIdx.x] = 0u;  // {next, end} = {0, 0}: empty; band_try = 0
-  if (a.batch_frames > 1u && threadIdx.x < 4u * (a.batch_frames - 1u)) reinterpret_cast<uint32_t*>(frame_queue(a, 1u))[threadIdx.x] = 0u;  // the further frames' queues
+  if (BATCH && a.batch_frames > 1u && threadIdx.x < 4u * (a.batch_frames - 1u)) reinterpret_cast<uint32_t*>(frame_queue(a, 1u))[threadIdx.x] = 0u;  // the further frames' queues
   if (threadIdx.x < (blockDim.x >> 6) * 2u) reinterpret_cast<uint32_t*>(block_queue(a) + 2)[threadIdx.x] = 0xFFFFFFFFu;  // per-wave tile accounts: none open
   // root masks + rank prefixes of the first n_lds_models models -> LDS: one coalesced 16 B-per-lane copy of the
   // scene's packed root table
@@ -1626,6 +1630,7 @@ __device__ __forceinline__ void stage_roots(ArgsRef a) {
   __syncthreads();
   PROF_LEAVE(P_STAGE);
 }
+__device__ __forceinline__ void stage_roots(ArgsRef a) { stage_roots_of<false>(a); }
 __device__ __forceinline__ uint32_t* wave_cand_list(ArgsRef a) {  // kMaxCand entries + kMaxCand of sort staging
   return reinterpret_cast<uint32_t*>(g_lds + a.n_lds_models * kN16LdsBytes) + (threadIdx.x >> 6) * (kMaxCand * 2);
 }
@@ -1928,7 +1933,6 @@ static FrameArgs with_schedule(const FrameArgs& in, uint32_t grid, uint32_t bloc
   const uint32_t rounds = waves ? a.tiles_per_band / waves : 0u;
   a.static_rounds = rounds >= 1u ? 1u : 0u;  // (see next_packet: dealing more than the first round was measured and lost)
   if (a.static_rounds_request != 0xFFFFFFFFu) a.static_rounds = a.static_rounds_request;
-  if (!a.band_tries) a.band_tries = kRegions;
   return a;
 }
 // kernel<MODE>: bit 0 = counting build, bit 1 = DEEP (the scene holds a 4096^3 model), bit 2 = LARGE (more than kFlatCullMax instances)

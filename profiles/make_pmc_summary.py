@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel<MODE>: MODE 0 = the timed two-level build, 2 = the DEEP build (4096^3 scenes); 1 / 3 are the counting builds
-KEYS = {"k_primary_ao<0>": "primary_ao", "k_final_gather<0>": "final_gather", "k_surfel_trace<0>": "surfel_trace",
+KEYS = {"k_primary_ao<0>": "primary_ao", "k_primary_ao_batch<0>": "primary_ao_batch", "k_final_gather<0>": "final_gather", "k_surfel_trace<0>": "surfel_trace",
         "k_primary<0>": "primary", "k_ambient_occlusion<0>": "ambient_occlusion"}
 DEEP_KEYS = {"k_primary_ao<2>": "primary_ao", "k_final_gather<2>": "final_gather", "k_ray_walk<2, 2>": "final_gather_walk", "k_surfel_trace<2>": "surfel_trace"}
 
@@ -30,11 +30,16 @@ def parse(path, keys=None):
 if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     c = parse(os.path.join(HERE, f"{tag}_pmc.txt"))
+    single = os.path.join(HERE, f"{tag}_pmc_single.txt")   # the same passes with --frames-per-launch 1 (k_primary_ao<0>; the default line launches k_primary_ao_batch<0>, four frames each)
+    if os.path.exists(single):
+        for k, v in parse(single).items():
+            c.setdefault(k, v)
     gi = os.path.join(HERE, f"{tag}_pmc_gi.txt")
     if os.path.exists(gi):
         for k, v in parse(gi).items():
             c.setdefault(k, v)
-    s = {"workload": "castle-standin", "scale": 1.0, "round": int(tag[1:]),
+    s = {"workload": "castle-standin", "scale": 1.0, "round": int(re.match(r"r(\d+)", tag).group(1)), "tag": tag,
+         "primary_ao_batch_frames": 4,   # (frames per k_primary_ao_batch launch in these passes: bench.py's default)
          "note": "rocprofv3 --pmc passes of `python bench.py [--workload gi] --steps 4 --warmup 1` (tools/profile_round.sh), "
                  "means per launch of the timed (non-counting) kernel instantiations. FETCH_SIZE/WRITE_SIZE are KiB. "
                  "MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies half of a wide coalesced read stream, so it is doubled "

@@ -130,6 +130,22 @@ static int gpu_frame(int argc, char** argv) {
     for (uint32_t r = 0; r < world; ++r) comms[r]->gather_planes(pipe_of(r), (1u << DUST_PLANE_ILLUMINANCE) | (1u << DUST_PLANE_VOXEL_ID), cuts, 0);
     comms[0]->wait();
     comms[0]->sync();
+  } else if (std::string(argv[1]) == "frames") {
+    // frames in flight (rhyolite_bevy/src/lib.rs:58): three frames handed over in ONE call, one persistent launch (dust_hip_render_frames) --
+    // frame 0 into `pipeline` (what is written out and compared), frames 1 and 2 into pipelines of their own with their own index and rand
+    std::vector<std::unique_ptr<dust::StandardPipeline>> more;
+    for (int i = 0; i < 2; ++i) {
+      more.emplace_back(new dust::StandardPipeline(ctx, w, h));
+      more.back()->set_blue_noise(5, noise5.data(), uint32_t(noise5.size() / (128 * 128 * 4)));
+    }
+    dust::StandardPipeline* pipes[3] = {&pipeline, more[0].get(), more[1].get()};
+    const DustHipCamera cams[3] = {cam, cam, cam};
+    const DustHipSky skies[3] = {sky, sky, sky};
+    const uint32_t idx[3] = {1, 2, 3}, rnd[3] = {4242, 17, 99};
+    EXPECT(dust::StandardPipeline::render_frames(pipes, 3, scene, cams, skies, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, idx, rnd));
+    ctx.sync();
+    const auto d1 = more[0]->read_plane<float>(DUST_PLANE_DEPTH), d0 = pipeline.read_plane<float>(DUST_PLANE_DEPTH);
+    EXPECT(d1.size() == d0.size() && std::memcmp(d1.data(), d0.data(), d0.size() * 4) == 0);   // same camera: same depth, whatever the frame's noise
   } else {
     const bool ok = pipeline.render(scene, cam, sky, DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION, 1, 4242);
     EXPECT(ok);
@@ -199,7 +215,7 @@ static int commit_loop(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   try {
-    if (argc >= 2 && (std::string(argv[1]) == "gpu" || std::string(argv[1]) == "bands")) return gpu_frame(argc, argv);
+    if (argc >= 2 && (std::string(argv[1]) == "gpu" || std::string(argv[1]) == "bands" || std::string(argv[1]) == "frames")) return gpu_frame(argc, argv);
     if (argc >= 2 && std::string(argv[1]) == "commit") return commit_loop(argc, argv);
     return cpu_tests();
   } catch (const dust::Error& e) {

@@ -27,10 +27,11 @@ def test_cpp_mirror_cpu(exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["gpu", "bands"])
+@pytest.mark.parametrize("mode", ["gpu", "bands", "frames"])
 def test_cpp_mirror_gpu_frame_matches_python_path(exe, tmp_path, mode):
     """mode "bands": the frame as 8 emulated ranks render and gather it through dust::DeviceComm (a loopback group on this device,
-    include/dust_hip.hpp) -- bit-identical to the single-device frame."""
+    include/dust_hip.hpp) -- bit-identical to the single-device frame. mode "frames": three frames in one call and one launch
+    (dust::StandardPipeline::render_frames -> dust_hip_render_frames); the first one's planes are the single frame's."""
     import parity_util as P
     from dust_amd import _lib as L, api, synth
     data, _ = synth.castle_scene(scale=0.15)

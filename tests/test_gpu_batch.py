@@ -246,3 +246,28 @@ def test_batched_frames_at_full_size_and_the_launch_is_timed_once():
         alone.render(scene, cam, sky, PAO, frame_index=last[i], rand=synth.frame_rand(1, last[i]))
         _same(_planes(batch[i]), _planes(alone), f"1080p frame {i}")
     print(f"k_primary_ao_batch, 4 frames of 1080p: {ms[0] / n[0]:.4f} ms per launch = {ms[0] / n[0] / 4:.4f} ms per frame")
+
+
+def test_settings_that_do_not_shape_a_launch_do_not_split_it():
+    """in_flight_slots only matters with several frames in flight: pipelines that differ in it (and nothing else) still share a launch --
+    seen in the timing: the first pipeline's pair brackets the one launch, the other has none. A pipeline that leaves slots free for another
+    queue's kernels (reserve_blocks) has another launch geometry: frames in sequence, a launch timed on each."""
+    w, h = 128, 80
+    desc = P.small_scene(seed=4, n_models=3, n_instances=6)
+    ctx = api.Context(device=0, timing=True)
+    scene = P.hip_scene(ctx, desc)
+    sky = P.sky_state()
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    cam = P.camera_for((90.0, 60.0, -80.0))
+    a, b = _pipes(ctx, 2, w, h, n5)
+    a.configure(frames_in_flight=1, in_flight_slots="all")
+    for p in (a, b):
+        p.mark_kernel_times()
+    api.StandardPipeline.render_frames([a, b], scene, cam, sky, PAO, [1, 2], [3, 4])
+    assert a.kernel_times()[1][0] == 1 and b.kernel_times()[1][0] == 0
+    b.configure(reserve_blocks=32)
+    api.StandardPipeline.render_frames([a, b], scene, cam, sky, PAO, [3, 4], [5, 6])
+    assert a.kernel_times()[1][0] == 1 and b.kernel_times()[1][0] == 1
+    c = _pipes(ctx, 1, w, h, n5)[0]
+    c.render(scene, cam, sky, PAO, frame_index=4, rand=6)
+    _same(_planes(b), _planes(c), "the frame of the pipeline with reserved slots")

@@ -13,8 +13,13 @@ cd "$R" || exit 1
 { echo "# HEAD ${HEAD_STAMP:-unknown}"; python -m pytest tests -m gpu -x -q -p no:cacheprovider; } > "$out/${tag}_gpu_tests.log" 2>&1
 tail -2 "$out/${tag}_gpu_tests.log"
 
-python bench.py --no-extra-curves > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"
+python bench.py --no-extra-curves > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"   # the headline: four frames per launch (dust_hip_render_frames)
 tail -1 "$out/${tag}_bench.log" | cut -c1-600
+# round 6, second half: frames per launch -- 1 (rounds 1-5's headline: a launch per frame), 2, 3 (the reference's frames in flight), 8
+for k in 1 2 3 8; do
+  python bench.py --frames-per-launch $k --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_fpl$k.log" 2>> "$out/${tag}_bench.err"
+done
+python bench.py --width 3840 --height 2160 --steps 60 --frames-per-launch 1 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k_fpl1.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_gi.log" | cut -c1-600
 python bench.py --workload deep --steps 30 > "$out/${tag}_bench_deep.log" 2>> "$out/${tag}_bench.err"
@@ -25,8 +30,8 @@ python bench.py --workload teapot_cpu > "$out/${tag}_bench_teapot_cpu.log" 2>> "
 python bench.py --workload gi --width 3840 --height 2160 --steps 40 --no-cpu-baseline > "$out/${tag}_bench_gi_4k.log" 2>> "$out/${tag}_bench.err"
 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_inplace.log" 2>> "$out/${tag}_bench.err"
 # round 6: two whole frames in flight on one GPU (each on half of the slots / every launch asking for all of them), the deterministic apply on one GPU
-python bench.py --frames-in-flight 2 --in-flight-slots share --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined.log" 2>> "$out/${tag}_bench.err"
-python bench.py --frames-in-flight 2 --in-flight-slots all --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined_all.log" 2>> "$out/${tag}_bench.err"
+python bench.py --frames-in-flight 2 --frames-per-launch 1 --in-flight-slots share --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined.log" 2>> "$out/${tag}_bench.err"
+python bench.py --frames-in-flight 2 --frames-per-launch 1 --in-flight-slots all --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined_all.log" 2>> "$out/${tag}_bench.err"
 DUST_BENCH_GI_ORDERED=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ordered_inplace.log" 2>> "$out/${tag}_bench.err"
 python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 # round 5: thousands of instances (the packet cull's 64-wide hierarchy against every box for every packet), the GI passes as ray streams
@@ -41,7 +46,7 @@ python bench.py --denoise --no-cpu-baseline --no-extra-curves > "$out/${tag}_ben
 # every band of N = 8 while the cuts are balanced on measured band steps (round 6), the timed region on the SLOWEST band; N = 2 and 4 likewise
 : > "$out/${tag}_bench_bands_emulated.log"
 for n in 2 4 8; do
-  DUST_BENCH_EMULATE_BAND=all/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 2>> "$out/${tag}_bench.err" |
+  DUST_BENCH_EMULATE_BAND=all/$n python bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline --no-extra-curves --frames-in-flight 4 --frames-per-launch 1 2>> "$out/${tag}_bench.err" |
     python -c "import sys,json; j=json.loads(sys.stdin.read()); c=j['config']; print(json.dumps({'bands': $n, 'slowest_band': c['emulated_band'], 'ms_per_step_slowest': j['ms_per_step'], 'band_steps_ms': c['band_steps_ms'], 'band_balance': c['band_balance'], 'frames_in_flight': c['frames_in_flight']}))" >> "$out/${tag}_bench_bands_emulated.log"
 done
 # ... and of an N = 8 GI job (round 6: pixel passes on the band, the exchange's export / import, 1/8 of the surfel trace, ordering + ordered apply replicated; one frame in flight)
@@ -90,15 +95,18 @@ head -12 "$out/${tag}_kernel_stats.txt"
 groups=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"
         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY"
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE")
-for wl in primary_ao gi deep; do
+for wl in primary_ao single gi deep; do
   for c in "${groups[@]}"; do
     n=$(echo $c | cut -d' ' -f1)
     if [ $wl = deep ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ]; then continue; fi
+    if [ $wl = single ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ] && [ $n != TCC_HIT_sum ]; then continue; fi
+    if [ $wl = single ]; then wa="--workload primary_ao --frames-per-launch 1"; else wa="--workload $wl"; fi   # (single: k_primary_ao<0>, a launch per frame)
     rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$tag" -o ${wl}_$n -- \
-        python "$R/bench.py" --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${wl}_$n.log" 2>&1
+        python "$R/bench.py" $wa --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${wl}_$n.log" 2>&1
   done
 done
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'primary_ao_*_results.db' | sort) > "$out/${tag}_pmc.txt" 2>&1
+python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'single_*_results.db' | sort) > "$out/${tag}_pmc_single.txt" 2>&1
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'gi_*_results.db' | sort) > "$out/${tag}_pmc_gi.txt" 2>&1
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'deep_*_results.db' | sort) > "$out/${tag}_pmc_deep.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o denoise -- \
