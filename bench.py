@@ -76,8 +76,10 @@ def parse(argv=None):
                          "launch (dust_hip_render_frames: G-buffers of their own on one context and stream; a wavefront that finds frame i without tiles "
                          "goes on to frame i + 1, so the launch's tail, root staging and inter-launch gap are paid once per launch; every frame's planes "
                          "are the bits the frame rendered alone gives). 1 = a launch per frame (rounds 1-5's headline; the default line carries it as "
-                         "curves.one_frame_per_launch). Default: 4 on one GPU -- the reference's host keeps up to three frames in flight, "
-                         "rhyolite_bevy/src/lib.rs:58 -- and 1 for GI workloads, N > 1 GPUs, emulated bands and --frames-in-flight runs")
+                         "curves.one_frame_per_launch, and four per launch as curves.four_frames_per_launch). Default: 8 on one GPU (offline rendering: the "
+                         "reference's host keeps up to three frames in flight, rhyolite_bevy/src/lib.rs:58; three per launch measure 0.397-0.404 of the "
+                         "roofline proxy, four 0.399-0.408, eight 0.402-0.412 from box to box) and 1 for GI workloads, N > 1 GPUs, emulated bands, "
+                         "--camera orbit and --frames-in-flight runs")
     ap.add_argument("--in-flight-slots", choices=["auto", "share", "all"], default="auto",
                     help="with several frames in flight: share = every launch on 1/D of the workgroup slots (row bands: a band is as long as its "
                          "heaviest tile, D of them side by side fill the device); all = every launch asks for ALL slots, so the next frame's workgroups "
@@ -680,14 +682,16 @@ def compact(curve, gi_mode):
                          "algorithmic_bytes_per_launch": int(d[1]), "kernel_ms": round(d[2], 4)}}
 
 
-def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.15, period=4.0):
+def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.15, period=4.0, fpl=1):
     """The reference is a real-time renderer: an FPS camera and a teapot that swings (examples/castle.rs:105-130,287-291). Here the
     eye sways along the circle round the castle that the reference's start position lies on -- angle `swing` * sin(2 pi t / `period`)
     either side of it, 60 frames a second of scene time, never at rest --, the teapot follows
     Transform::from_translation((sin t * 50, 200, 0)) -- set_transform + commit every frame, motion vectors against the previous
     frame's transform. One GPU; the castle's instances plus the teapot. (A full orbit shows a different castle every second: its
     frames cost up to 20 % more or less than the headline's view for reasons that have nothing to do with moving; the sway keeps the
-    comparison with the still view a like-for-like one, and `still_same_views` times three of its cameras standing still.)"""
+    comparison with the still view a like-for-like one, and `still_same_views` times three of its cameras standing still.)
+    fpl > 1: that many consecutive frames of the motion per call and per launch (dust_hip_render_frames with each frame's moves: the library
+    commits the teapot's transform before preparing the frame that sees it -- a scene image per frame in the scene's ring)."""
     import math
     import numpy as np
     api, L, synth, P = be.api, be.L, be.synth, be.P
@@ -714,6 +718,13 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
     scene.commit()
     pipe = api.StandardPipeline(ctx, W, H)
     pipe.set_noise(5, noise5)
+    pipes = [pipe]
+    for _ in range(max(1, int(fpl)) - 1):
+        pipes.append(api.StandardPipeline(ctx, W, H))
+        pipes[-1].set_noise(5, noise5)
+    fpl = len(pipes)
+    steps = -(-steps // fpl) * fpl   # whole launches
+    settle = -(-settle // fpl) * fpl
     sky = be.sky_struct(base["sky"])
     sc = args.scale
     eye0 = (122.0 * sc, 300.61 * sc, 54.45 * sc)
@@ -736,6 +747,17 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
         scene.set_transform(tea, flat[k], prevs[k])
         scene.commit()
         pipe.render(scene, cams[k], sky, passes | (L.PASS_COUNT_STATS if count else 0), frame_index=1 + k, rand=synth.frame_rand(1, 1 + k))
+
+    def stretch(first, last):
+        """frames first .. last - 1: a launch per frame, or fpl of them per call"""
+        if fpl == 1:
+            for k in range(first, last):
+                frame(k)
+            return
+        for k in range(first, last, fpl):
+            ks = list(range(k, min(k + fpl, last)))
+            api.StandardPipeline.render_frames(pipes[:len(ks)], scene, [cams[j] for j in ks], sky, passes, [1 + j for j in ks],
+                                               [synth.frame_rand(1, 1 + j) for j in ks], moves=[[(tea, flat[j], prevs[j])] for j in ks])
     # untimed: the rays of exactly the frames that are timed below (they differ from frame to frame)
     rays = 0
     algo = 0   # algorithmic bytes (SURVEY 8d) of the same frames: every frame of a moving view has its own counts
@@ -757,13 +779,11 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
     # other curves, single passes, do not have). All passes are listed in `passes_ms_per_step`.
     runs = []
     for _ in range(3):
-        for k in range(settle):
-            frame(k)
+        stretch(0, settle)
         be.sync()
         pipe.mark_kernel_times()
         t0 = time.perf_counter()
-        for k in range(settle, n):
-            frame(k)
+        stretch(settle, n)
         be.sync()
         dt_i = time.perf_counter() - t0
         runs.append((dt_i,) + tuple(pipe.kernel_times(mark=True)))
@@ -774,20 +794,26 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
     for k in (settle, settle + steps // 2, n - 1):
         scene.set_transform(tea, flat[k], prevs[k])
         scene.commit()
-        for j in range(80):
+        for j in range(0, 80, fpl):
             if j == 40:
                 be.sync()
                 t1 = time.perf_counter()
-            pipe.render(scene, cams[k], sky, passes, frame_index=1 + j, rand=synth.frame_rand(1, 1 + j))
+            if fpl == 1:
+                pipe.render(scene, cams[k], sky, passes, frame_index=1 + j, rand=synth.frame_rand(1, 1 + j))
+            else:   # (the still views at the same number of frames per launch)
+                api.StandardPipeline.render_frames(pipes, scene, cams[k], sky, passes, [1 + j + i for i in range(fpl)], [synth.frame_rand(1, 1 + j + i) for i in range(fpl)])
         be.sync()
         still_ms.append((time.perf_counter() - t1) / 40 * 1e3)
     speed = swing * 2.0 * math.pi / period
     k_ms = lm[0] / ln[0] if ln[0] else None
-    achieved = (algo / steps) / (k_ms * 1e-3) / 1e9 if k_ms else None
-    return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+    if fpl > 1 and k_ms and k_ms < 0.6 * fpl * (dt / steps * 1e3):   # (the frames did not share launches: accounted per frame)
+        fpl = 1
+    achieved = (algo / steps * fpl) / (k_ms * 1e-3) / 1e9 if k_ms else None
+    kname = "k_primary_ao_batch" if fpl > 1 else "k_primary_ao"
+    return {"value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "frames_per_launch": fpl,
             "rays_per_step": int(rays / steps), "settle_steps": settle, "passes_ms_per_step": [round(r[0] / steps * 1e3, 4) for r in runs],
-            "kernels_ms": {"k_primary_ao": round(k_ms, 4) if k_ms else None},
-            "roofline": {"bound": "hbm", "kernel": "k_primary_ao", "algorithmic_bytes_per_launch": int(algo / steps), "kernel_ms": round(k_ms, 4) if k_ms else None,
+            "kernels_ms": {kname: round(k_ms, 4) if k_ms else None},
+            "roofline": {"bound": "hbm", "kernel": kname, "algorithmic_bytes_per_launch": int(algo / steps * fpl), "kernel_ms": round(k_ms, 4) if k_ms else None,
                          "achieved": round(achieved, 3) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6) if achieved else None,
                          "note": "mean algorithmic bytes of the timed frames (each counted in an untimed pass of its own) over the mean kernel time of the "
@@ -894,9 +920,10 @@ def extra_curves(args, be, noise0, noise5, base):
         rec["steps"], rec["frames_per_launch"] = a.steps, 1
         return rec
     run("one_frame_per_launch", one_frame_per_launch)
-    run("eight_frames_per_launch", lambda: batched(8))
+    run("four_frames_per_launch", lambda: batched(4))
     run("pipelined", lambda: pipelined(2))
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
+    run("moving_four_frames_per_launch", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20), fpl=4))
     run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
     run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))
     run("deep", deep)
@@ -965,9 +992,9 @@ def run_rank(args, be, dist):
             pipe.clear()
         in_flight = 1 if gi_mode else (args.frames_in_flight or (4 if (world > 1 and shard == "bands") else 1))
         fpl = args.frames_per_launch
-        if fpl is None:   # the default: four frames per launch where nothing else was asked for
-            fpl = 4 if (world == 1 and not gi_mode and not args.frames_in_flight and not os.environ.get("DUST_BENCH_EMULATE_BAND")
-                        and not getattr(args, "denoise", False)) else 1
+        if fpl is None:   # the default: eight frames per launch where nothing else was asked for
+            fpl = 8 if (world == 1 and not gi_mode and not args.frames_in_flight and not os.environ.get("DUST_BENCH_EMULATE_BAND")
+                        and not getattr(args, "denoise", False) and args.camera != "orbit") else 1   # (a moving view commits the scene between frames: a launch per frame)
         if fpl > 1 and world == 1 and not gi_mode and hasattr(be, "open_batch_lane"):
             # --frames-per-launch: that many G-buffers on the first lane's context; consecutive steps share a launch (dust_hip_render_frames)
             batch_lanes = [lanes_for(1)[0]]
@@ -1110,7 +1137,7 @@ def run_rank(args, be, dist):
         out["config"]["workload"] += "; MOVING view: " + mv["camera"] + "; " + mv["scene"]
         out["config"]["rays_per_step_all_gpus"] = mv["rays_per_step"]
         out["config"]["instances"] = mv["instances"]
-        if mv["kernels_ms"]["k_primary_ao"]:
+        if mv["kernels_ms"].get("k_primary_ao"):
             k_ms = mv["kernels_ms"]["k_primary_ao"]
             out["roofline"].update(kernel_ms=k_ms, kernels_ms=mv["kernels_ms"],
                                    note="moving view: kernel time of the moving frames; algorithmic bytes per launch are the still frame's "

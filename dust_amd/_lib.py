@@ -83,6 +83,10 @@ class FrameParams(C.Structure):
                 ("rand", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("surfel_rank", C.c_uint32), ("surfel_world", C.c_uint32)]
 
 
+class FrameMoves(C.Structure):   # DustHipFrameMoves: the instances moved before a frame of dust_hip_render_frames
+    _fields_ = [("n", C.c_uint32), ("instance_ids", C.POINTER(C.c_uint32)), ("obj_to_world", C.POINTER(C.c_float)), ("prev_obj_to_world", C.POINTER(C.c_float))]
+
+
 class ToneMapParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("transfer_function", C.c_uint32), ("color_space_conversion", C.c_float * 9),
                 ("min_log_luminance", C.c_float), ("max_log_luminance", C.c_float), ("time_coefficient", C.c_float)]
@@ -170,7 +174,7 @@ SYMBOLS = {
     "dust_hip_pipeline_destroy": (None, [_P]),
     "dust_hip_pipeline_set_noise": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
     "dust_hip_render_frame": (C.c_int, [_P, _P, C.POINTER(Camera), C.POINTER(Sky), C.POINTER(FrameParams)]),
-    "dust_hip_render_frames": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p), _P, C.POINTER(Camera), C.POINTER(Sky), C.POINTER(FrameParams)]),
+    "dust_hip_render_frames": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p), _P, C.POINTER(Camera), C.POINTER(Sky), C.POINTER(FrameParams), C.POINTER(FrameMoves)]),
     "dust_hip_pipeline_pass_stats": (C.c_int, [_P, C.c_uint32, C.POINTER(PassStats)]),
     "dust_hip_pipeline_kernel_times": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "dust_hip_pipeline_tile_costs": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _u32p, _u32p]),

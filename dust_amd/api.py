@@ -467,10 +467,11 @@ class StandardPipeline:
         L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
 
     @staticmethod
-    def render_frames(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0)):
+    def render_frames(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0), moves=None):
         """dust_hip_render_frames: frame i -- cameras[i], skies[i], frame_indices[i], rands[i] -- into pipes[i], the results of len(pipes)
         render() calls in that order; primary + AO frames of distinct pipelines of one context share ONE persistent launch (up to 8 frames each).
-        cameras / skies: one per frame, or a single Camera / Sky for all of them."""
+        cameras / skies: one per frame, or a single Camera / Sky for all of them. moves: per frame None or a list of (instance id, obj_to_world[12],
+        prev_obj_to_world mat4[16] or None): what Scene.set_transform + Scene.commit would do before that frame."""
         n = len(pipes)
         cams = (L.Camera * n)(*[(cameras if isinstance(cameras, L.Camera) else cameras[i]) for i in range(n)])
         one_sky = isinstance(skies, L.Sky) or (not isinstance(skies, (list, tuple)))
@@ -479,7 +480,23 @@ class StandardPipeline:
         fps = (L.FrameParams * n)(*[L.FrameParams(C.sizeof(L.FrameParams), passes, int(frame_indices[i]), int(rands[i]) & 0xFFFFFFFF, rows[0], rows[1], 0, 0)
                                     for i in range(n)])
         hs = (C.c_void_p * n)(*[p._h for p in pipes])
-        L.check(pipes[0]._lib.dust_hip_render_frames(n, hs, scene._h, cams, sk, fps))
+        mv, keep = None, []
+        if moves is not None:
+            mv = (L.FrameMoves * n)()
+            for i in range(n):
+                ms = moves[i] or []
+                if not ms:
+                    continue
+                ids = np.ascontiguousarray([m[0] for m in ms], np.uint32)
+                xf = np.ascontiguousarray([np.asarray(m[1], np.float32).reshape(12) for m in ms], np.float32)
+                have_prev = all(len(m) > 2 and m[2] is not None for m in ms)
+                pv = np.ascontiguousarray([np.asarray(m[2], np.float32).reshape(16) for m in ms], np.float32) if have_prev else None
+                keep += [ids, xf, pv]
+                mv[i].n = len(ms)
+                mv[i].instance_ids = ids.ctypes.data_as(C.POINTER(C.c_uint32))
+                mv[i].obj_to_world = xf.ctypes.data_as(C.POINTER(C.c_float))
+                mv[i].prev_obj_to_world = pv.ctypes.data_as(C.POINTER(C.c_float)) if pv is not None else None
+        L.check(pipes[0]._lib.dust_hip_render_frames(n, hs, scene._h, cams, sk, fps, mv))
 
     def pass_stats(self, index):
         st = L.PassStats()

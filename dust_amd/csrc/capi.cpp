@@ -515,7 +515,7 @@ struct DustHipPipeline {
   // GI frame runs its surfel pass in place and is timed (P: primary / AO kernels, Q: the pass); once those events have completed --
   // looked at without waiting, some frames later -- the pass's share is 100 Q / (Q + 1.05 P) - 3, which is where the measured optima
   // of three workloads lie (castle 1080p 50 %, 4K 20 %, the 4096^3 tree 25 %). Until then: a guess from the ray counts.
-  struct { hipEvent_t p0 = nullptr, p1 = nullptr, q0 = nullptr, q1 = nullptr; int state = 0; uint32_t share = 0; } side_cal;
+  struct { hipEvent_t p0 = nullptr, p1 = nullptr, q0 = nullptr, q1 = nullptr; int state = 0; uint32_t share = 0; uint32_t gi_frames = 0; } side_cal;
 };
 
 static const size_t kPlaneBytesPerPixel[DUST_PLANE_COUNT] = {8, 8, 4, 4, 4, 8, 4, 16, 8};
@@ -1853,9 +1853,12 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
 // counters, tile order -- and left in `frames[1 ..]`; the first frame ("lead"), prepared last, launches k_primary_ao_batch over all of them.
 struct BatchJoin {
   dust::FrameArgs frames[dust::kMaxBatch];
+  uint32_t image_of[dust::kMaxBatch] = {};   // which of the scene's ring of device images each frame reads (the scene may be committed between two frames of a launch)
+  DustHipPipeline* timer = nullptr;          // frame 0's pipeline: its HIP-event pair brackets the launch
   uint32_t n = 0;      // frames of the launch
-  uint32_t slot = 0;   // where the follower being prepared goes
+  uint32_t slot = 0;   // the frame being prepared
 };
+// Follower: frames 0 .. n - 2 of a launch, prepared in order; Lead: frame n - 1 -- prepared last, launches all of them
 enum class FrameRole { Single, Follower, Lead };
 // every argument check of a frame, before anything is enqueued or changed (a frame that has started is finished); fp_copy: the caller's
 // parameters widened to this library's struct
@@ -2015,10 +2018,11 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
   p->stats_valid = false;
   // An event pair around a launch costs the stream ~6 us per record (a marker packet the next dispatch waits behind): 5 % of a
   // 0.23 ms frame. A context that only wants averages over a run of frames (bench.py) times every 4th frame's launches.
-  // (a follower of a batched launch has no launch of its own to time: the lead's pair brackets the launch of all of its frames)
+  // (the further frames of a batched launch have no launch of their own to time: frame 0's pair brackets the launch of all of them)
   // -- at the same rate PER FRAME as single launches are: a launch of n frames counts as n of the stride
-  const uint32_t stride = role == FrameRole::Lead ? std::max(1u, ctx->timing_stride / join->n) : ctx->timing_stride;
-  p->timed_frame = role != FrameRole::Follower && ctx->timing && (p->frame_counter++ % stride) == 0;
+  const uint32_t stride = role != FrameRole::Single ? std::max(1u, ctx->timing_stride / join->n) : ctx->timing_stride;
+  const bool times_launch = role == FrameRole::Single || join->slot == 0;   // (a launch of several frames: frame 0's pipeline)
+  p->timed_frame = times_launch && ctx->timing && (p->frame_counter++ % stride) == 0;
   // (a frame that is not timed has no times: dust_hip_pipeline_pass_stats must not hand out an earlier frame's)
   if (!p->timed_frame) for (bool& v : p->ev_valid) v = false;
   // while a surfel pass may be running on the second stream, the primary / AO kernels leave it its share of the slots (persistent
@@ -2043,7 +2047,11 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
     }
     (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error of this call)
     const bool gi_frame = (fp->passes & DUST_PASS_PRIMARY) && (fp->passes & DUST_PASS_SURFEL);
-    calibrate = cal.state == 0 && gi_frame && !tune.no_side_stream && !count && !sharded && !ctx->side_busy && !(tune.debug & 16u);
+    // (not the pipeline's first GI frames: they touch the hash and the pool for the first time -- 400 MB of first-touch page faults inside the
+    //  timed pass; one deep-tree run in five calibrated a share half as large again from it: 4.66 ms per frame against 4.27-4.30)
+    if (gi_frame && cal.state == 0) ++cal.gi_frames;
+    calibrate = cal.state == 0 && cal.gi_frames >= 3u && gi_frame && !tune.no_side_stream && !count && !sharded && !(tune.debug & 16u);
+    if (calibrate) HIP_TRY(join_side(ctx));   // (the timed frame runs its passes one after the other, behind the previous frame's surfel pass)
     if (calibrate && !cal.p0)
       for (hipEvent_t* e : {&cal.p0, &cal.p1, &cal.q0, &cal.q1}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableSystemFence));
     if (cal.share) share = cal.share;
@@ -2097,12 +2105,14 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
     take_counters(p, 0, a);
     { DustStatus os = order_tiles(p, 0, a, st); if (os != DUST_OK) return os; }
     a.stats = static_cast<dust::DevStats*>(p->stats.p);
-    if (role == FrameRole::Follower) {   // prepared; the lead launches it
+    if (role != FrameRole::Single) {   // a frame of a launch of several: prepared; the last one launches them all
       join->frames[join->slot] = a;
-      for (bool& v : p->ev_valid) v = false;
-      return DUST_OK;
+      join->image_of[join->slot] = s->current;
+      if (join->slot == 0) join->timer = p;
+      if (role == FrameRole::Follower) return DUST_OK;
     }
-    if (p->timed_frame) HIP_TRY(hipEventRecord(p->ev_begin(0), st));
+    DustHipPipeline* tp = role == FrameRole::Lead ? join->timer : p;   // whose event pair brackets the launch
+    if (tp->timed_frame) HIP_TRY(hipEventRecord(tp->ev_begin(0), st));
     // One 1024-thread workgroup per CU when the kernel has the device to itself (no surfel pass beside it, one frame in flight,
     // no slots reserved, the default block size): the roots are staged once per CU and sixteen waves share a tile queue
     uint32_t fblock = block, fgrid = grid;
@@ -2119,15 +2129,21 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
       fblock = 1024;
       fgrid = std::max(8u, (frame_slots / 2u) & ~7u);
     }
-    say_start(a);
     if (role == FrameRole::Lead) {
-      join->frames[0] = a;
+      say_start(join->frames[0]);   // (the kernel's first descriptor says it)
+      for (uint32_t i = 0; i < join->n; ++i) {
+        // every scene image a frame of the launch reads is in use until the launch has started (dust_hip_scene_commit recycles by last_seq)
+        s->slots[join->image_of[i]].last_seq = join->frames[0].started_seq;
+        // the boxes staged in LDS are frame 0's image's: a frame of another image (an instance moved in between) reads its own from memory
+        if (join->image_of[i] != join->image_of[0]) join->frames[i].n_lds_boxes = 0;
+      }
       HIP_TRY(dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st));
     } else {
+      say_start(a);
       HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
     }
     a.started_word = nullptr;
-    if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(0), st)); p->ev_valid[0] = true; p->ev_valid[1] = false; }
+    if (tp->timed_frame) { HIP_TRY(hipEventRecord(tp->ev_end(0), st)); tp->ev_valid[0] = true; tp->ev_valid[1] = false; }
   }
   if (!fuse && (fp->passes & DUST_PASS_PRIMARY)) {
     take_counters(p, 0, a);
@@ -2296,36 +2312,55 @@ static bool batchable(uint32_t n, DustHipPipeline* const* pipes, const DustHipSc
   }
   return true;
 }
-DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pipelines, const DustHipScene* s, const DustHipCamera* cameras,
-                                  const DustHipSky* skies, const DustHipFrameParams* params) {
+// what the host does to the scene before frame i (the reference's tlas_system pushes the moved entities every frame, tlas.rs:79-128)
+static DustStatus apply_moves(DustHipScene* s, const DustHipFrameMoves& m) {
+  if (!m.n) return DUST_OK;
+  for (uint32_t j = 0; j < m.n; ++j) {
+    DustStatus ms = dust_hip_scene_set_transform(s, m.instance_ids[j], m.obj_to_world + size_t(j) * 12, m.prev_obj_to_world ? m.prev_obj_to_world + size_t(j) * 16 : nullptr);
+    if (ms != DUST_OK) return ms;
+  }
+  return dust_hip_scene_commit(s);
+}
+DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pipelines, DustHipScene* s, const DustHipCamera* cameras,
+                                  const DustHipSky* skies, const DustHipFrameParams* params, const DustHipFrameMoves* moves) {
   if (!pipelines || !s || !cameras || !skies || !params) return fail(DUST_ERR_INVALID_ARGUMENT, "null argument");
   if (!n_frames) return DUST_OK;
   return guarded([&]() -> DustStatus {
-  // every frame's arguments are checked before the first one is enqueued
+  // every frame's arguments are checked before the first one is enqueued (and before the scene is touched)
   std::vector<DustHipFrameParams> fps(n_frames);
   for (uint32_t i = 0; i < n_frames; ++i) {
     // (params[] is an array of THIS library's struct: every element must say so, or the stride is not ours)
     if (params[i].struct_size != sizeof(DustHipFrameParams)) return fail(DUST_ERR_INVALID_ARGUMENT, "dust_hip_render_frames: params[i].struct_size must be sizeof(DustHipFrameParams)");
     DustStatus cs = check_frame(pipelines[i], s, &cameras[i], &skies[i], &params[i], fps[i]);
     if (cs != DUST_OK) return cs;
+    if (moves && moves[i].n) {
+      if (!moves[i].instance_ids || !moves[i].obj_to_world) return fail(DUST_ERR_INVALID_ARGUMENT, "dust_hip_render_frames: moves[i] without instance ids or transforms");
+      for (uint32_t j = 0; j < moves[i].n; ++j)
+        if (moves[i].instance_ids[j] >= s->instances.size()) return fail(DUST_ERR_INVALID_ARGUMENT, "dust_hip_render_frames: moves[i] names an instance the scene does not have");
+    }
   }
   for (uint32_t at = 0; at < n_frames;) {
-    const uint32_t n = std::min<uint32_t>(dust::kMaxBatch, n_frames - at);
-    if (!batchable(n, pipelines + at, s, fps.data() + at)) {   // one frame, or frames that cannot share a launch: in sequence, the same results
+    uint32_t n = std::min<uint32_t>(dust::kMaxBatch, n_frames - at);
+    while (n >= 2 && !batchable(n, pipelines + at, s, fps.data() + at)) --n;   // the longest run from here that can share a launch
+    if (n < 2) {   // one frame, or a frame that cannot share a launch with its successor: in sequence, the same results
+      if (moves) { DustStatus ms = apply_moves(s, moves[at]); if (ms != DUST_OK) return ms; }
       DustStatus rs = render_frame_impl(pipelines[at], s, &cameras[at], &skies[at], &params[at], FrameRole::Single, nullptr);
       if (rs != DUST_OK) return rs;
       at += 1;
       continue;
     }
+    // in frame order: the scene as frame i sees it (its moves committed: a scene image of its own in the ring), then frame i's descriptor against it;
+    // the last frame's preparation launches them all. At most kMaxBatch commits lie between two launches -- the ring holds as many images --, so no
+    // commit of this run lands on an image one of its own frames still waits to read.
+    static_assert(dust::kMaxBatch <= DustHipScene::kImages, "a launch's frames must fit the scene's ring of images");
     BatchJoin join;
     join.n = n;
-    for (uint32_t i = 1; i < n; ++i) {
+    for (uint32_t i = 0; i < n; ++i) {
+      if (moves) { DustStatus ms = apply_moves(s, moves[at + i]); if (ms != DUST_OK) return ms; }
       join.slot = i;
-      DustStatus rs = render_frame_impl(pipelines[at + i], s, &cameras[at + i], &skies[at + i], &params[at + i], FrameRole::Follower, &join);
+      DustStatus rs = render_frame_impl(pipelines[at + i], s, &cameras[at + i], &skies[at + i], &params[at + i], i + 1 == n ? FrameRole::Lead : FrameRole::Follower, &join);
       if (rs != DUST_OK) return rs;
     }
-    DustStatus rs = render_frame_impl(pipelines[at], s, &cameras[at], &skies[at], &params[at], FrameRole::Lead, &join);
-    if (rs != DUST_OK) return rs;
     at += n;
   }
   return DUST_OK;

@@ -717,6 +717,7 @@ hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t
     //  measured on 1/8 row bands: 0.095 ms per band frame against 0.039)
     if (i) b.f[i].static_rounds = 0u;
     b.f[i].batch_frames = i ? 0u : n;
+    b.f[i].batch_queue_base = (uint32_t)lds_bytes(frames[0], block);
   }
   for (uint32_t i = n; i < kMaxBatch; ++i) b.f[i] = b.f[0];   // (never read)
   switch ((b.f[0].deep ? 2 : 0) | (b.f[0].n_groups ? 4 : 0)) {

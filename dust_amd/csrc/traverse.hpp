@@ -1460,7 +1460,7 @@ __device__ __forceinline__ u32x4* lds_boxes(ArgsRef a) {  // behind the queue an
 // the boxes, at the very end of the launch's LDS (lds_bytes + 16 per further frame).
 __device__ __forceinline__ unsigned long long* frame_queue(ArgsRef a, uint32_t frame) {
   if (frame == 0u) return block_queue(a);
-  return reinterpret_cast<unsigned long long*>(lds_boxes(a) + a.n_lds_boxes * 2u) + (frame - 1u) * 2u;
+  return reinterpret_cast<unsigned long long*>(g_lds + a.batch_queue_base) + (frame - 1u) * 2u;
 }
 // The tile a wave is working on and when it started, in the wave's LDS slot behind the workgroup's queue: next_packet closes
 // the previous tile's account (cycles -> a.tile_cost) when the wave comes back for more. No register is carried for it.

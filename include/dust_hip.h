@@ -322,18 +322,30 @@ DustStatus dust_hip_pipeline_set_noise(DustHipPipeline*, uint32_t texture, const
  * the pass in place. */
 DustStatus dust_hip_render_frame(DustHipPipeline*, const DustHipScene*, const DustHipCamera*, const DustHipSky*,
                                  const DustHipFrameParams*);
+/* What the host does to the scene before a frame of dust_hip_render_frames: the transforms of the entities that moved since the previous frame
+ * (tlas_system pushes them every frame, accel_struct/tlas.rs:79-128; castle.rs:287-291 moves the teapot). n == 0: the scene as the previous
+ * frame left it. */
+typedef struct DustHipFrameMoves {
+  uint32_t n;                      /* instances moved before this frame */
+  const uint32_t* instance_ids;    /* n ids (dust_hip_scene_add_instance) */
+  const float* obj_to_world;       /* n x 12, as dust_hip_scene_set_transform takes them */
+  const float* prev_obj_to_world;  /* n x 16 (the previous frame's transforms, for the motion vectors), or NULL */
+} DustHipFrameMoves;
 /* Frames in flight (rhyolite_bevy/src/lib.rs:58 `max_frame_in_flight: 3`; StandardPipeline::render is called once per frame and the frames
- * overlap on the device): n_frames frames in one call -- frame i with cameras[i], skies[i], params[i] into pipelines[i] -- with exactly the
- * results of n_frames dust_hip_render_frame calls in that order. Frames that qualify share ONE persistent launch (up to 8 per launch, more
- * are split): a wavefront that finds frame i without tiles goes straight on to frame i + 1, so the launch's tail, the staging of the roots
- * and the gap between launches are paid once for all of its frames (1080p primary + AO: 0.22 ms per frame alone). Qualifying: passes ==
- * DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION for every frame, distinct pipelines of the scene's context with one frame size, one row
- * band and the same DustHipPipelineConfig, no surfel pass outstanding. Anything else (GI passes: a frame's gather reads the hash its
- * predecessor's surfel pass wrote) is enqueued frame after frame as dust_hip_render_frame would. Every frame's arguments are checked
- * before the first frame is enqueued; params[i].struct_size must be sizeof(DustHipFrameParams). With DUST_HIP_CONTEXT_TIMING the
- * launch's time is reported by pipelines[0] (pass 0), once for all frames of the launch. */
-DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pipelines, const DustHipScene*, const DustHipCamera* cameras,
-                                  const DustHipSky* skies, const DustHipFrameParams* params);
+ * overlap on the device): n_frames frames in one call -- frame i with cameras[i], skies[i], params[i] into pipelines[i], after moves[i] (if
+ * moves != NULL) have been applied to the scene and committed -- with exactly the results of, for every i in order,
+ * dust_hip_scene_set_transform x moves[i].n + dust_hip_scene_commit + dust_hip_render_frame. Frames that qualify share ONE persistent launch
+ * (up to 8 per launch, more are split): a wavefront that finds frame i without tiles goes straight on to frame i + 1, so the launch's tail,
+ * the staging of the roots and the gap between launches are paid once for all of its frames (1080p primary + AO: 0.22 ms per frame alone,
+ * 0.209 at four per launch, 0.2065 at eight). Qualifying: passes == DUST_PASS_PRIMARY | DUST_PASS_AMBIENT_OCCLUSION for every frame, distinct pipelines of
+ * the scene's context with one frame size, one row band and the same DustHipPipelineConfig, no surfel pass outstanding. Every frame reads the
+ * scene as ITS moves left it (the scene's ring of device images holds as many states as a launch has frames). Anything else (GI passes: a
+ * frame's gather reads the hash its predecessor's surfel pass wrote) is enqueued frame after frame as dust_hip_render_frame would. Every
+ * frame's arguments are checked before the scene is touched and the first frame is enqueued; params[i].struct_size must be
+ * sizeof(DustHipFrameParams). With DUST_HIP_CONTEXT_TIMING the launch's time is reported by pipelines[0] (pass 0), once for all frames of
+ * the launch. After the call the scene is as the last frame saw it. */
+DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pipelines, DustHipScene*, const DustHipCamera* cameras,
+                                  const DustHipSky* skies, const DustHipFrameParams* params, const DustHipFrameMoves* moves);
 /* pass: 0 primary, 1 AO-pass sun-shadow rays, 2 AO rays, 3 final gather, 4 surfel sun rays, 5 surfel cosine rays.
  * When primary and AO passes are requested together they run as ONE fused kernel: its time is reported under
  * pass 0 and passes 1-2 report ms = 0 (set DUST_HIP_NO_FUSE=1 to launch them separately). */

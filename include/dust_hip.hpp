@@ -321,8 +321,9 @@ class StandardPipeline {
   }
   // Frames in flight (rhyolite_bevy/src/lib.rs:58): n frames, frame i into pipelines[i], as n render() calls in that order; primary + AO frames of
   // distinct pipelines of one context share one persistent launch (dust_hip_render_frames). false where any of them is not ready.
-  static bool render_frames(StandardPipeline* const* pipelines, uint32_t n, const Scene& scene, const DustHipCamera* cameras, const DustHipSky* skies,
-                            uint32_t passes, const uint32_t* frame_indices, const uint32_t* rands, uint32_t row_begin = 0, uint32_t row_end = 0) {
+  static bool render_frames(StandardPipeline* const* pipelines, uint32_t n, Scene& scene, const DustHipCamera* cameras, const DustHipSky* skies,
+                            uint32_t passes, const uint32_t* frame_indices, const uint32_t* rands, uint32_t row_begin = 0, uint32_t row_end = 0,
+                            const DustHipFrameMoves* moves = nullptr) {   // moves[i]: the entities that moved before frame i (tlas_system's per-frame push), or null
     std::vector<DustHipPipeline*> hs(n);
     std::vector<DustHipFrameParams> fps(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -331,7 +332,7 @@ class StandardPipeline {
       fps[i].struct_size = sizeof(DustHipFrameParams);
       fps[i].passes = passes; fps[i].frame_index = frame_indices[i]; fps[i].rand = rands[i]; fps[i].row_begin = row_begin; fps[i].row_end = row_end;
     }
-    const DustStatus s = dust_hip_render_frames(n, hs.data(), scene.raw(), cameras, skies, fps.data());
+    const DustStatus s = dust_hip_render_frames(n, hs.data(), scene.raw(), cameras, skies, fps.data(), moves);
     if (s == DUST_ERR_NOT_READY) return false;
     check(s);
     return true;

@@ -39,7 +39,7 @@ if __name__ == "__main__":
         for k, v in parse(gi).items():
             c.setdefault(k, v)
     s = {"workload": "castle-standin", "scale": 1.0, "round": int(re.match(r"r(\d+)", tag).group(1)), "tag": tag,
-         "primary_ao_batch_frames": 4,   # (frames per k_primary_ao_batch launch in these passes: bench.py's default)
+         "primary_ao_batch_frames": 8,   # (frames per k_primary_ao_batch launch in these passes: bench.py's default)
          "note": "rocprofv3 --pmc passes of `python bench.py [--workload gi] --steps 4 --warmup 1` (tools/profile_round.sh), "
                  "means per launch of the timed (non-counting) kernel instantiations. FETCH_SIZE/WRITE_SIZE are KiB. "
                  "MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies half of a wide coalesced read stream, so it is doubled "

@@ -300,10 +300,10 @@ def test_bench_line_on_the_gpu_keeps_the_contract():
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0.0 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
-    # a launch cannot take longer than the steps it holds (the default line: four frames = four steps per launch, dust_hip_render_frames)
-    assert rf["frames_per_launch"] == j["config"]["frames_per_launch"] == 4 and rf["kernel"] == "k_primary_ao_batch"
+    # a launch cannot take longer than the steps it holds (the default line: eight frames = eight steps per launch, dust_hip_render_frames)
+    assert rf["frames_per_launch"] == j["config"]["frames_per_launch"] == 8 and rf["kernel"] == "k_primary_ao_batch"
     assert 0.0 < rf["kernel_ms"] <= j["ms_per_step"] * rf["frames_per_launch"] * 1.05
-    assert abs(rf["kernel_ms_per_frame"] - rf["kernel_ms"] / 4) < 1e-3
+    assert abs(rf["kernel_ms_per_frame"] - rf["kernel_ms"] / 8) < 1e-3
     one = j["curves"]["one_frame_per_launch"]   # rounds 1-5's headline rides along
     assert one["roofline"]["kernel"] == "k_primary_ao" and 0.0 < one["roofline"]["kernel_ms"] <= one["ms_per_step"] * 1.05
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3

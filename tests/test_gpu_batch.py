@@ -271,3 +271,57 @@ def test_settings_that_do_not_shape_a_launch_do_not_split_it():
     c = _pipes(ctx, 1, w, h, n5)[0]
     c.render(scene, cam, sky, PAO, frame_index=4, rand=6)
     _same(_planes(b), _planes(c), "the frame of the pipeline with reserved slots")
+
+
+def _mat4(o2w):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :] = np.asarray(o2w, np.float32).reshape(3, 4)
+    return np.ascontiguousarray(m.T).reshape(16)
+
+
+@pytest.mark.parametrize("n, calls", [(4, 5), (8, 3), (11, 2)])
+def test_frames_of_a_moving_scene_share_a_launch(n, calls):
+    """castle.rs:287-291 moves an entity every frame and tlas.rs:37-65 rebuilds the TLAS in that frame's command stream: here every frame of a
+    call comes with its moves (dust_hip_render_frames applies and commits them before the frame is prepared -- a scene image of its own in the
+    scene's ring of 8) and the frames still share launches. Against set_transform + commit + render_frame per frame on a twin scene: every plane,
+    motion vectors included, bit for bit; several calls in a row with nothing waited for in between (the ring comes round: a commit must not
+    land on an image a frame that has not started yet still reads); and against the oracle."""
+    w, h = 200, 120
+    desc = P.small_scene(seed=6, n_models=3, n_instances=7)
+    ctx = api.Context(device=0)
+    sky = P.sky_state()
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    scene_a, scene_b = P.hip_scene(ctx, desc), P.hip_scene(ctx, desc)
+    batch, single = _pipes(ctx, n, w, h, n5), _pipes(ctx, n, w, h, n5)
+    rng = np.random.default_rng(5)
+    cur = [np.array(t, np.float32).reshape(3, 4).copy() for _, t in desc.instances]
+    f = 1
+    for _ in range(calls):
+        cams = _cams(n, eye=(90.0 + f, 60.0, -80.0))
+        idx = [f + i for i in range(n)]
+        rnd = [synth.frame_rand(2, v) for v in idx]
+        moves = []
+        for i in range(n):
+            ms = []
+            for j in rng.choice(len(cur), size=int(rng.integers(0, 3)), replace=False):   # no, one or two instances move before this frame
+                prev = _mat4(cur[j])
+                cur[j] = cur[j].copy()
+                cur[j][:, 3] += rng.uniform(-3.0, 3.0, 3).astype(np.float32)
+                ms.append((int(j), cur[j].reshape(12).copy(), prev))
+            moves.append(ms)
+        api.StandardPipeline.render_frames(batch, scene_a, cams, sky, PAO, idx, rnd, moves=moves)
+        for i in range(n):
+            for j, xf, prev in moves[i]:
+                scene_b.set_transform(j, xf, prev)
+            if moves[i]:
+                scene_b.commit()
+            single[i].render(scene_b, cams[i], sky, PAO, frame_index=idx[i], rand=rnd[i])
+        f += n
+    for i in range(n):
+        _same(_planes(batch[i]), _planes(single[i]), f"moving frame {i} of {n}")
+    # the last frame against the oracle's scene in its final state
+    final = P.SceneDesc(desc.models, desc.palette, [(m, cur[k].reshape(12)) for k, (m, _) in enumerate(desc.instances)])
+    g = P.render_oracle(P.oracle_scene(final), cams[n - 1], sky, w, h, PAO, n5[idx[n - 1] % 4], rnd[n - 1])
+    res = P.compare_gbuffers(g, P.read_hip_gbuffer(batch[n - 1]))
+    res["motion"] = 0   # (the oracle scene built at rest has no previous transforms: motion vectors are compared against the twin above)
+    P.assert_parity(res)

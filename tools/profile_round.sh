@@ -13,10 +13,10 @@ cd "$R" || exit 1
 { echo "# HEAD ${HEAD_STAMP:-unknown}"; python -m pytest tests -m gpu -x -q -p no:cacheprovider; } > "$out/${tag}_gpu_tests.log" 2>&1
 tail -2 "$out/${tag}_gpu_tests.log"
 
-python bench.py --no-extra-curves > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"   # the headline: four frames per launch (dust_hip_render_frames)
+python bench.py --no-extra-curves > "$out/${tag}_bench.log" 2> "$out/${tag}_bench.err"   # the headline: eight frames per launch (dust_hip_render_frames)
 tail -1 "$out/${tag}_bench.log" | cut -c1-600
-# round 6, second half: frames per launch -- 1 (rounds 1-5's headline: a launch per frame), 2, 3 (the reference's frames in flight), 8
-for k in 1 2 3 8; do
+# round 6, second half: frames per launch -- 1 (rounds 1-5's headline: a launch per frame), 2, 3 (the reference's frames in flight), 4
+for k in 1 2 3 4; do
   python bench.py --frames-per-launch $k --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_fpl$k.log" 2>> "$out/${tag}_bench.err"
 done
 python bench.py --width 3840 --height 2160 --steps 60 --frames-per-launch 1 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k_fpl1.log" 2>> "$out/${tag}_bench.err"
@@ -71,7 +71,7 @@ done
 cd /tmp || exit 1
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench -- \
-    python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_prof.log" 2>&1
+    python "$R/bench.py" --steps 24 --warmup 3 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_gi -- \
     python "$R/bench.py" --workload gi --steps 20 --warmup 3 --no-cpu-baseline > "$out/${tag}_bench_gi_prof.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_$tag" -o bench_deep -- \
@@ -101,8 +101,9 @@ for wl in primary_ao single gi deep; do
     if [ $wl = deep ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ]; then continue; fi
     if [ $wl = single ] && [ $n != FETCH_SIZE ] && [ $n != WRITE_SIZE ] && [ $n != TCC_HIT_sum ]; then continue; fi
     if [ $wl = single ]; then wa="--workload primary_ao --frames-per-launch 1"; else wa="--workload $wl"; fi   # (single: k_primary_ao<0>, a launch per frame)
+    st=4; if [ $wl = primary_ao ]; then st=8; fi   # (whole launches of eight frames only: the counters are means per launch)
     rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$tag" -o ${wl}_$n -- \
-        python "$R/bench.py" $wa --steps 4 --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${wl}_$n.log" 2>&1
+        python "$R/bench.py" $wa --steps $st --warmup 2 --no-cpu-baseline --no-extra-curves > "$out/pmc_${wl}_$n.log" 2>&1
   done
 done
 python "$R/profiles/summarize_pmc.py" $(find "$out/pmc_$tag" -name 'primary_ao_*_results.db' | sort) > "$out/${tag}_pmc.txt" 2>&1

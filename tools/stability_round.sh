@@ -25,6 +25,7 @@ mkdir -p gpurun_out
   run timeout 900 python3 tools/stress_host.py commits 600 $((92300 + off))
   run timeout 900 python3 tools/stress_host.py threads 20 $((92600 + off))
   run timeout 900 python3 tools/stress_host.py schedule 40 $((92700 + off))
+  run timeout 900 python3 tools/stress_host.py frames 400 $((92800 + off))
   run timeout 600 python3 tools/stress_edits.py
   run timeout 600 python3 tools/stress_denoise.py
   run timeout 600 python3 tools/stress_tonemap.py

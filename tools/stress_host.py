@@ -6,7 +6,10 @@
             reallocation when the scene grows, the dirty-range copy, the second stream)
   threads : several host threads, a context each, on one device at the same time
   schedule: big frames under random launch shapes against the default launch
-usage: stress_host.py bands|commits|threads|schedule [n] [first_seed]"""
+  frames  : dust_hip_render_frames -- random numbers of frames (1 .. 19: launches of up to 8), frame sizes from a few tiles to 1080p, cameras, row bands,
+            launch shapes, calls repeated so that measured tile orders come in, single-frame calls and commits in between, frames that cannot
+            share a launch mixed in -- against the same frames one dust_hip_render_frame at a time
+usage: stress_host.py bands|commits|threads|schedule|frames [n] [first_seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -246,11 +249,82 @@ def schedule(n, first):
     return bad
 
 
+def frames(n, first):
+    """Several frames per launch (k_primary_ao_batch) against a launch per frame: every plane of every frame, bit for bit."""
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    n0 = synth.stbn_scalar(layers=4)
+    sky = S.sky_state()
+    bad = []
+    keys = ("DUST_HIP_BLOCK", "DUST_HIP_BLOCKS_PER_CU", "DUST_HIP_RESERVE_BLOCKS", "DUST_HIP_STATIC_ROUNDS", "DUST_HIP_NO_TILE_ORDER", "DUST_HIP_NO_LDS_BOXES",
+            "DUST_HIP_EQUAL_BANDS", "DUST_HIP_NO_WIDE_FUSED", "DUST_HIP_FORCE_MOVING")
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        for k_ in keys:
+            os.environ.pop(k_, None)
+        if rng.random() < 0.5:   # a random launch shape, the same for every pipeline of the case
+            os.environ["DUST_HIP_BLOCK"] = str(int(rng.choice([128, 256, 512])))
+            os.environ["DUST_HIP_BLOCKS_PER_CU"] = str(int(rng.choice([1, 2])))
+            os.environ["DUST_HIP_STATIC_ROUNDS"] = str(int(rng.choice([0, 1, 2])))
+        for name in ("NO_TILE_ORDER", "NO_LDS_BOXES", "EQUAL_BANDS", "NO_WIDE_FUSED", "FORCE_MOVING"):
+            if rng.random() < 0.25:
+                os.environ["DUST_HIP_" + name] = "1"
+        if rng.random() < 0.2:
+            os.environ["DUST_HIP_RESERVE_BLOCKS"] = "32"
+        ctx = api.Context(device=0)
+        pal = synth.make_palette(seed)
+        models = small_models(ctx, rng, pal, int(rng.integers(1, 4)))
+        scene = api.Scene(ctx)
+        xfs = [rand_xf(rng).reshape(12) for _ in range(int(rng.integers(1, 30)))]
+        ids = [scene.add_instance(models[int(rng.integers(0, len(models)))], x) for x in xfs]
+        scene.commit()
+        big = rng.random() < 0.15
+        w, h = ((1920, 1080) if rng.random() < 0.5 else (1280, 720)) if big else (int(rng.integers(8, 400)), int(rng.integers(8, 260)))
+        nf = int(rng.integers(1, 20 if not big else 7))
+        rows = (0, 0)
+        if rng.random() < 0.3 and h > 16:
+            r0 = int(rng.integers(0, h - 8)); rows = (r0, int(rng.integers(r0 + 1, h + 1)))
+
+        def cam():
+            eye = tuple(float(v) for v in rng.uniform(-120, 120, 3))
+            return S.camera_for(eye if abs(eye[0]) + abs(eye[2]) > 1e-3 else (1.0, eye[1], eye[2]))
+        pipes = [api.StandardPipeline(ctx, w, h) for _ in range(nf)]
+        alone = [api.StandardPipeline(ctx, w, h) for _ in range(nf)]
+        for p_ in pipes + alone:
+            p_.set_noise(5, n5)
+        odd = int(rng.integers(0, nf)) if (nf > 2 and rng.random() < 0.3) else -1   # one pipeline of another frame size in the middle: splits the call
+        if odd >= 0:
+            pipes[odd] = api.StandardPipeline(ctx, w + 8, h); alone[odd] = api.StandardPipeline(ctx, w + 8, h)
+            pipes[odd].set_noise(5, n5); alone[odd].set_noise(5, n5)
+        rounds = int(rng.integers(1, 12 if not big else 4))
+        f = 1
+        for rd in range(rounds):
+            cams = [cam() for _ in range(nf)] if rng.random() < 0.5 else [cam()] * nf
+            idx = [f + i for i in range(nf)]
+            rnd = [int(rng.integers(0, 1 << 32)) for _ in range(nf)]
+            api.StandardPipeline.render_frames(pipes, scene, cams, sky, PA, idx, rnd, rows=rows)
+            for i in range(nf):
+                alone[i].render(scene, cams[i], sky, PA, frame_index=idx[i], rand=rnd[i], rows=rows)
+            f += nf
+            if rng.random() < 0.3:   # a frame of its own on one of the pipelines, and a moved instance, between two calls
+                j = int(rng.integers(0, nf))
+                pipes[j].render(scene, cams[j], sky, PA, frame_index=f, rand=7, rows=rows)
+                alone[j].render(scene, cams[j], sky, PA, frame_index=f, rand=7, rows=rows)
+                scene.set_transform(ids[int(rng.integers(0, len(ids)))], rand_xf(rng).reshape(12))
+                scene.commit()
+        diff = [(i, pl) for i in range(nf) for pl, a, b in zip(PLANES, planes(pipes[i]), planes(alone[i])) if not np.array_equal(a, b)]
+        if diff:
+            bad.append(seed)
+            print(f"seed {seed}: {nf} frames of {w}x{h} rows {rows}, {rounds} calls, odd {odd}, env { {k_: os.environ[k_] for k_ in keys if k_ in os.environ} }: (frame, plane) {diff[:6]} differ", flush=True)
+    for k_ in keys:
+        os.environ.pop(k_, None)
+    return bad
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     t0 = time.time()
-    bad = {"bands": bands, "commits": commits, "threads": threads, "schedule": schedule}[what](n, first)
+    bad = {"bands": bands, "commits": commits, "threads": threads, "schedule": schedule, "frames": frames}[what](n, first)
     print(f"{what}: {n} cases, {len(bad)} with mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
