@@ -273,10 +273,14 @@ def frames(n, first):
         ctx = api.Context(device=0)
         pal = synth.make_palette(seed)
         models = small_models(ctx, rng, pal, int(rng.integers(1, 4)))
-        scene = api.Scene(ctx)
+        scene, twin = api.Scene(ctx), api.Scene(ctx)   # (the twin: the same scene, moved and committed frame by frame for the single-frame calls)
         xfs = [rand_xf(rng).reshape(12) for _ in range(int(rng.integers(1, 30)))]
-        ids = [scene.add_instance(models[int(rng.integers(0, len(models)))], x) for x in xfs]
-        scene.commit()
+        which = [int(rng.integers(0, len(models))) for _ in xfs]
+        ids = [scene.add_instance(models[w_], x) for w_, x in zip(which, xfs)]
+        for w_, x in zip(which, xfs):
+            twin.add_instance(models[w_], x)
+        scene.commit(); twin.commit()
+        with_moves = rng.random() < 0.4   # every frame comes with the instances that moved before it (DustHipFrameMoves)
         big = rng.random() < 0.15
         w, h = ((1920, 1080) if rng.random() < 0.5 else (1280, 720)) if big else (int(rng.integers(8, 400)), int(rng.integers(8, 260)))
         nf = int(rng.integers(1, 20 if not big else 7))
@@ -301,20 +305,28 @@ def frames(n, first):
             cams = [cam() for _ in range(nf)] if rng.random() < 0.5 else [cam()] * nf
             idx = [f + i for i in range(nf)]
             rnd = [int(rng.integers(0, 1 << 32)) for _ in range(nf)]
-            api.StandardPipeline.render_frames(pipes, scene, cams, sky, PA, idx, rnd, rows=rows)
+            moves = None
+            if with_moves:
+                moves = [[(ids[int(rng.integers(0, len(ids)))], rand_xf(rng).reshape(12), mat4(rand_xf(rng))) for _ in range(int(rng.integers(0, 3)))] for _ in range(nf)]
+            api.StandardPipeline.render_frames(pipes, scene, cams, sky, PA, idx, rnd, rows=rows, moves=moves)
             for i in range(nf):
-                alone[i].render(scene, cams[i], sky, PA, frame_index=idx[i], rand=rnd[i], rows=rows)
+                for j_, x_, p_ in (moves[i] if moves else []):
+                    twin.set_transform(j_, x_, p_)
+                if moves and moves[i]:
+                    twin.commit()
+                alone[i].render(twin, cams[i], sky, PA, frame_index=idx[i], rand=rnd[i], rows=rows)
             f += nf
             if rng.random() < 0.3:   # a frame of its own on one of the pipelines, and a moved instance, between two calls
                 j = int(rng.integers(0, nf))
                 pipes[j].render(scene, cams[j], sky, PA, frame_index=f, rand=7, rows=rows)
-                alone[j].render(scene, cams[j], sky, PA, frame_index=f, rand=7, rows=rows)
-                scene.set_transform(ids[int(rng.integers(0, len(ids)))], rand_xf(rng).reshape(12))
-                scene.commit()
+                alone[j].render(twin, cams[j], sky, PA, frame_index=f, rand=7, rows=rows)
+                mv_id, mv_xf = ids[int(rng.integers(0, len(ids)))], rand_xf(rng).reshape(12)
+                scene.set_transform(mv_id, mv_xf); scene.commit()
+                twin.set_transform(mv_id, mv_xf); twin.commit()
         diff = [(i, pl) for i in range(nf) for pl, a, b in zip(PLANES, planes(pipes[i]), planes(alone[i])) if not np.array_equal(a, b)]
         if diff:
             bad.append(seed)
-            print(f"seed {seed}: {nf} frames of {w}x{h} rows {rows}, {rounds} calls, odd {odd}, env { {k_: os.environ[k_] for k_ in keys if k_ in os.environ} }: (frame, plane) {diff[:6]} differ", flush=True)
+            print(f"seed {seed}: {nf} frames of {w}x{h} rows {rows}, {rounds} calls, odd {odd}, moves {with_moves}, env { {k_: os.environ[k_] for k_ in keys if k_ in os.environ} }: (frame, plane) {diff[:6]} differ", flush=True)
     for k_ in keys:
         os.environ.pop(k_, None)
     return bad
