@@ -841,19 +841,24 @@ def extra_curves(args, be, noise0, noise5, base):
         gc.enable()
         gc.collect()
 
-    def curve(workload, W, H, sc):
+    def curve(workload, W, H, sc, fpl=1):
+        """fpl > 1 (primary + AO workloads): that many frames per launch, like the headline (dust_hip_render_frames)"""
         a = argparse.Namespace(**vars(args))
-        a.workload, a.width, a.height, a.steps, a.warmup = workload, W, H, args.extra_steps, 0
-        lane = Lane()
-        lane.stream, lane.ctx, lane.sc = base.stream, base.ctx, sc
-        lane.pipe = be.api.StandardPipeline(base.ctx, W, H)
-        lane.pipe.set_noise(5, noise5)
+        a.workload, a.width, a.height, a.steps, a.warmup, a.frames_per_launch = workload, W, H, -(-args.extra_steps // fpl) * fpl, 0, fpl
+        lanes = []
+        for _ in range(fpl):
+            lane = Lane()
+            lane.stream, lane.ctx, lane.sc = base.stream, base.ctx, sc
+            lane.pipe = be.api.StandardPipeline(base.ctx, W, H)
+            lane.pipe.set_noise(5, noise5)
+            lane.enter = base.enter
+            lanes.append(lane)
         gi = workload != "primary_ao"
         if gi:
-            lane.pipe.set_noise(0, noise0)
-        lane.enter = base.enter
-        rec = compact(measure_curve(be, None, a, [lane], "bands"), gi)
-        rec["steps"], rec["frame"] = a.steps, [W, H]
+            lanes[0].pipe.set_noise(0, noise0)
+        c = measure_curve(be, None, a, lanes, "bands")
+        rec = compact(c, gi)
+        rec["steps"], rec["frame"], rec["frames_per_launch"] = a.steps, [W, H], c.get("frames_per_launch", 1)
         return rec
 
     def deep():
@@ -867,7 +872,7 @@ def extra_curves(args, be, noise0, noise5, base):
         a = argparse.Namespace(**vars(args))
         a.props = 4000
         sc = be.build_scene(a)
-        rec = curve("primary_ao", args.width, args.height, sc)
+        rec = curve("primary_ao", args.width, args.height, sc, fpl=8)
         rec["scene"] = f"the castle + 4000 scattered props: {sc['info']['n_instances']} instances of {sc['info']['n_models']} models"
         return rec
     def pipelined(depth):
@@ -924,7 +929,7 @@ def extra_curves(args, be, noise0, noise5, base):
     run("pipelined", lambda: pipelined(2))
     run("moving", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20)))
     run("moving_four_frames_per_launch", lambda: measure_moving(be, args, base, noise5, max(args.extra_steps, 20), fpl=4))
-    run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc))
+    run("primary_ao_4k", lambda: curve("primary_ao", 3840, 2160, base.sc, fpl=8))
     run("gi_1080p", lambda: curve("gi", args.width, args.height, base.sc))
     run("deep", deep)
     if not getattr(args, "props", 0):

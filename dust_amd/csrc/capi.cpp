@@ -2132,7 +2132,11 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
     if (role == FrameRole::Lead) {
       say_start(join->frames[0]);   // (the kernel's first descriptor says it)
       for (uint32_t i = 0; i < join->n; ++i) {
-        // every scene image a frame of the launch reads is in use until the launch has started (dust_hip_scene_commit recycles by last_seq)
+        // Every scene image a frame of the launch reads is in use from NOW until the launch is done. dust_hip_scene_commit recycles an image by
+        // `epoch` (has anybody waited for the stream since a frame reading it was enqueued?) and `last_seq`: both were stamped when the frame
+        // was PREPARED (touch()), and a commit between then and now may have waited for the stream -- the image would pass for idle
+        // (found by tools/stress_host.py frames: 17 to 19 frames per call with moves, the third launch's commits landing on the second's images).
+        s->slots[join->image_of[i]].epoch = ctx->sync_epoch;
         s->slots[join->image_of[i]].last_seq = join->frames[0].started_seq;
         // the boxes staged in LDS are frame 0's image's: a frame of another image (an instance moved in between) reads its own from memory
         if (join->image_of[i] != join->image_of[0]) join->frames[i].n_lds_boxes = 0;

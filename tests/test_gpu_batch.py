@@ -279,7 +279,7 @@ def _mat4(o2w):
     return np.ascontiguousarray(m.T).reshape(16)
 
 
-@pytest.mark.parametrize("n, calls", [(4, 5), (8, 3), (11, 2)])
+@pytest.mark.parametrize("n, calls", [(4, 5), (8, 3), (11, 2), (19, 3)])
 def test_frames_of_a_moving_scene_share_a_launch(n, calls):
     """castle.rs:287-291 moves an entity every frame and tlas.rs:37-65 rebuilds the TLAS in that frame's command stream: here every frame of a
     call comes with its moves (dust_hip_render_frames applies and commits them before the frame is prepared -- a scene image of its own in the
