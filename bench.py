@@ -53,7 +53,7 @@ SETTLE_MAX_STEPS = 20000
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=96)   # (whole launches at 1, 2, 3, 4 and 8 frames per launch)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -1144,7 +1144,7 @@ def run_rank(args, be, dist):
         out["config"]["instances"] = mv["instances"]
         if mv["kernels_ms"].get("k_primary_ao"):
             k_ms = mv["kernels_ms"]["k_primary_ao"]
-            out["roofline"].update(kernel_ms=k_ms, kernels_ms=mv["kernels_ms"],
+            out["roofline"].update(kernel_ms=k_ms, kernels_ms=mv["kernels_ms"], kernel_ms_per_frame=k_ms, frames_per_launch=1,
                                    note="moving view: kernel time of the moving frames; algorithmic bytes per launch are the still frame's "
                                         "(achieved / frac are recomputed with them -- the orbit keeps the castle in view, rays per frame within a few percent)")
             out["roofline"]["achieved"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 3)

@@ -280,4 +280,14 @@ def run_smoke():
     g = render_oracle(oracle_scene(desc), cam, sky, w, h, passes, noise5[1 % 2], 12345)
     res = compare_gbuffers(g, hip)
     assert_parity(res)
-    print("smoke ok:", res, "hit pixels:", int(np.isfinite(g.depth).sum()))
+    # ... and the same frame as the second of three in ONE persistent launch (dust_hip_render_frames / k_primary_ao_batch: bench.py's headline path)
+    more = []
+    for _ in range(3):
+        p2 = api.StandardPipeline(ctx, w, h)
+        p2.set_noise(5, noise5)
+        more.append(p2)
+    api.StandardPipeline.render_frames(more, scene, cam, sky, passes, [2, 1, 3], [7, 12345, 9])
+    ctx.sync()
+    res2 = compare_gbuffers(g, read_hip_gbuffer(more[1]))
+    assert_parity(res2)
+    print("smoke ok:", res, "hit pixels:", int(np.isfinite(g.depth).sum()), "| second of three frames in one launch:", res2)

@@ -19,7 +19,7 @@ tail -1 "$out/${tag}_bench.log" | cut -c1-600
 for k in 1 2 3 4; do
   python bench.py --frames-per-launch $k --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_fpl$k.log" 2>> "$out/${tag}_bench.err"
 done
-python bench.py --width 3840 --height 2160 --steps 60 --frames-per-launch 1 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k_fpl1.log" 2>> "$out/${tag}_bench.err"
+python bench.py --width 3840 --height 2160 --steps 64 --frames-per-launch 1 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k_fpl1.log" 2>> "$out/${tag}_bench.err"
 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi.log" 2>> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench_gi.log" | cut -c1-600
 python bench.py --workload deep --steps 30 > "$out/${tag}_bench_deep.log" 2>> "$out/${tag}_bench.err"
@@ -33,7 +33,7 @@ DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$ou
 python bench.py --frames-in-flight 2 --frames-per-launch 1 --in-flight-slots share --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined.log" 2>> "$out/${tag}_bench.err"
 python bench.py --frames-in-flight 2 --frames-per-launch 1 --in-flight-slots all --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_pipelined_all.log" 2>> "$out/${tag}_bench.err"
 DUST_BENCH_GI_ORDERED=1 DUST_HIP_NO_SIDE_STREAM=1 python bench.py --workload gi --no-cpu-baseline > "$out/${tag}_bench_gi_ordered_inplace.log" 2>> "$out/${tag}_bench.err"
-python bench.py --width 3840 --height 2160 --steps 60 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
+python bench.py --width 3840 --height 2160 --steps 64 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_4k.log" 2>> "$out/${tag}_bench.err"
 # round 5: thousands of instances (the packet cull's 64-wide hierarchy against every box for every packet), the GI passes as ray streams
 # (opt-in on the castle, the default for the deep tree's gather), N-rank denoise on one GPU
 python bench.py --props 4000 --no-cpu-baseline --no-extra-curves > "$out/${tag}_bench_props.log" 2>> "$out/${tag}_bench.err"
