@@ -2360,10 +2360,16 @@ DustStatus dust_hip_render_frames(uint32_t n_frames, DustHipPipeline* const* pip
     BatchJoin join;
     join.n = n;
     for (uint32_t i = 0; i < n; ++i) {
-      if (moves) { DustStatus ms = apply_moves(s, moves[at + i]); if (ms != DUST_OK) return ms; }
+      DustStatus rs = moves ? apply_moves(s, moves[at + i]) : DUST_OK;
       join.slot = i;
-      DustStatus rs = render_frame_impl(pipelines[at + i], s, &cameras[at + i], &skies[at + i], &params[at + i], i + 1 == n ? FrameRole::Lead : FrameRole::Follower, &join);
-      if (rs != DUST_OK) return rs;
+      if (rs == DUST_OK) rs = render_frame_impl(pipelines[at + i], s, &cameras[at + i], &skies[at + i], &params[at + i], i + 1 == n ? FrameRole::Lead : FrameRole::Follower, &join);
+      if (rs != DUST_OK) {
+        // (a HIP failure or a commit that could not grow the scene: the frames prepared so far are never launched -- their pipelines took a set of
+        //  work counters for nothing, and no launch zeroed the other one: give it back, or their next launch would pull tiles from a set that an
+        //  earlier launch has counted up)
+        for (uint32_t j = 0; j < i; ++j) pipelines[at + j]->counter_parity[0] ^= 1u;
+        return rs;
+      }
     }
     at += n;
   }
