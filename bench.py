@@ -1025,7 +1025,7 @@ def run_rank(args, be, dist):
     # (tools/profile_round.sh); the committed summary of the latest one is quoted with its provenance, or nothing is
     traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path) and world == 1 and (W, H) == (1920, 1080):
+    if os.path.exists(pmc_path) and world == 1 and (W, H) == (1920, 1080) and not getattr(args, "props", 0):   # (the counter passes ran on the castle as it is)
         try:
             pm = json.load(open(pmc_path))
             key = "castle-standin" if not deep else "deep-tree"
