@@ -1849,8 +1849,8 @@ static DustStatus run_surfel_pass(DustHipPipeline* p, const dust::FrameArgs& a, 
     if (p->timed_frame) { HIP_TRY(hipEventRecord(p->ev_end(3), st)); p->ev_valid[3] = true; }
   return DUST_OK;
 }
-// Several frames in one persistent launch (dust_hip_render_frames): the frames after the first ("followers") are PREPARED -- descriptor, work
-// counters, tile order -- and left in `frames[1 ..]`; the first frame ("lead"), prepared last, launches k_primary_ao_batch over all of them.
+// Several frames in one persistent launch (dust_hip_render_frames): the frames are PREPARED in order -- the scene as each of them sees it, its
+// descriptor, work counters, tile order -- and left in `frames[]`; the preparation of the last one launches k_primary_ao_batch over all of them.
 struct BatchJoin {
   dust::FrameArgs frames[dust::kMaxBatch];
   uint32_t image_of[dust::kMaxBatch] = {};   // which of the scene's ring of device images each frame reads (the scene may be committed between two frames of a launch)

@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
 // is left of the 1080p frame (4 % + 1 % + 1.9 %). Each frame writes the planes of ITS pipeline with the bits the single-frame
 // kernel writes (same packets, same arithmetic; tests/test_gpu_batch.py). The reference keeps up to three frames in flight
 // (rhyolite_bevy/src/lib.rs:58); the GI passes cannot ride along: a frame's gather reads the hash its predecessor's surfel pass wrote.
-// Frames after the first are not dealt a first round (with_schedule_follower): their waves arrive one by one and take the most expensive
-// tiles left, in order.
+// Frames after the first are not dealt a first round (launch_primary_ao_batch): their waves arrive one by one and take the most expensive
+// tiles left, in order. The frames may read different images of the scene's ring (an instance moved between them): what is staged in LDS
+// is frame 0's, and a frame of another image has n_lds_boxes = 0 (its boxes come from memory).
 template <int MODE>
 __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao_batch(const BatchArgs) {
   ArgsRef lead = launch_args();
@@ -705,7 +706,6 @@ hipError_t launch_primary_ao(const FrameArgs& a_in, uint32_t grid, uint32_t bloc
   DUST_LAUNCH_MODE(k_primary_ao, count, a_in);
   return hipGetLastError();
 }
-// n frames (2 .. kMaxBatch) in one launch; frames[0] decides the kernel variant and the geometry. Frames after the first: no dealt round.
 // n frames (2 .. kMaxBatch) in one launch; frames[0] decides the kernel variant and the geometry. Frames after the first: no dealt round.
 hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t grid, uint32_t block, hipStream_t s) {
   if (n < 1u || n > kMaxBatch) return hipErrorInvalidValue;
