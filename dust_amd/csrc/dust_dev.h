@@ -284,6 +284,8 @@ struct FrameArgs {
   // ---- round 6, second half: several frames in ONE persistent launch (dust_hip_render_frames, k_primary_ao_batch). Set in the FIRST descriptor of
   // a BatchArgs only: how many of its descriptors are frames of this launch. 0 / 1 everywhere else.
   uint32_t batch_frames;
+  uint32_t batch_grab;        // every descriptor of a BatchArgs: tickets a refill of this frame's queue takes (launch_primary_ao_batch: up to 16 where a band
+                              // holds many rounds of tiles for its workgroups, 4 in the launch's last frame and in small frames)
   uint32_t batch_queue_base;  // every descriptor of a BatchArgs: LDS byte offset of frame 1's tile queue (frame f: + 16 (f - 1)) -- the end of frame 0's LDS layout, which a
                               // frame that reads another scene image (n_lds_boxes = 0: its boxes come from memory) cannot work out from its own fields
 };

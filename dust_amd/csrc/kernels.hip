@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
 
 // Several frames in ONE persistent launch (dust_hip_render_frames): the kernel argument is a BatchArgs, `batch_frames` whole launch
 // descriptors side by side. The frames share what is staged in LDS (one scene) and the launch geometry; a wave that finds frame f without
-// tiles -- its own band's, then the others' -- takes the next frame's descriptor and queue and goes on, so the launch has ONE tail (waves idle
+// tiles -- its own band's; in the last frame the others' too -- takes the next frame's descriptor and queue and goes on, so the launch has ONE tail (waves idle
 // behind the last long tiles), one staging of the roots and one inter-launch gap for all of its frames: the per-launch costs that are what
 // is left of the 1080p frame (4 % + 1 % + 1.9 %). Each frame writes the planes of ITS pipeline with the bits the single-frame
 // kernel writes (same packets, same arithmetic; tests/test_gpu_batch.py). The reference keeps up to three frames in flight
@@ -261,6 +261,12 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
     if (f != 0u && blockIdx.x == 0 && threadIdx.x < kRegions) a0.next_work_counters[threadIdx.x * kCounterStride] = 0u;
     WorkCursor wc = cursor_begin();
     wc.frame = f;
+    wc.grab = a0.batch_grab;
+    // Before the launch's last frame a workgroup stays on its OWN band -- its XCD's L2 -- and goes on to the next frame when that is handed out:
+    // the band's last tiles are its own workgroups' business, nobody waits for a frame in the middle of a launch, and the up to seven refused
+    // atomics on the other bands' counters per workgroup and frame are not paid (8 frames per launch: 1.6653 -> 1.6574 ms). The last frame is
+    // finished by whoever is free, as a single frame is.
+    wc.tries = f + 1u == n_frames ? kRegions : 1u;
     Packet p;
     while (next_packet_of<true>(a0, wc, p)) {
       float hitT;
@@ -715,8 +721,14 @@ hipError_t launch_primary_ao_batch(const FrameArgs* frames, uint32_t n, uint32_t
     b.f[i] = with_schedule(frames[i], grid, block);
     // (a dealt tile is BOUND to its wave: a wave held up by a long tile of frame i would sit on the most expensive tiles of every later frame --
     //  measured on 1/8 row bands: 0.095 ms per band frame against 0.039)
+    // (... and for whole frames, several rounds of tiles per wave, dealing every frame's first round changes nothing: 1.6653 -> 1.6635 ms)
     if (i) b.f[i].static_rounds = 0u;
     b.f[i].batch_frames = i ? 0u : n;
+    {  // tickets per refill: a quarter of what a workgroup's share of a band comes to, between kGrabBatch and kBatchGrabMax; the last frame: kGrabBatch
+      const uint32_t groups_per_band = (grid + kRegions - 1u) / kRegions;
+      const uint32_t share = b.f[i].tiles_per_band / (4u * (groups_per_band ? groups_per_band : 1u));
+      b.f[i].batch_grab = i + 1u == n ? kGrabBatch : (share < kGrabBatch ? kGrabBatch : (share > kBatchGrabMax ? kBatchGrabMax : share));
+    }
     b.f[i].batch_queue_base = (uint32_t)lds_bytes(frames[0], block);
   }
   for (uint32_t i = n; i < kMaxBatch; ++i) b.f[i] = b.f[0];   // (never read)
