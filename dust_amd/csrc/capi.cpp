@@ -319,7 +319,10 @@ struct DustHipScene : RefCounted {
   // next) -- and frames enqueued from then on read that slot. A slot is rewritten kImages commits later: the frames that read it
   // are done if the library has waited for the streams since they were enqueued (a frame loop does, to read its result or pace
   // itself); otherwise the host is kImages commits ahead of the GPU and waits here (the reference's host runs <= 3 frames ahead).
-  static constexpr int kImages = 8;
+#ifndef DUST_SCENE_IMAGES
+#define DUST_SCENE_IMAGES 16   // (8 until dust_hip_render_frames took moves: a launch of eight frames, each with an image of its own, left the host no image to
+#endif                        //  prepare the next launch in while that one ran -- 0.2457 ms per frame of a moving view against 0.2257 with 16; an image is ~150 KB for the castle)
+  static constexpr int kImages = DUST_SCENE_IMAGES;
   struct Slot {
     DeviceBuffer dev;
     void* host = nullptr;

@@ -283,7 +283,7 @@ def _mat4(o2w):
 def test_frames_of_a_moving_scene_share_a_launch(n, calls):
     """castle.rs:287-291 moves an entity every frame and tlas.rs:37-65 rebuilds the TLAS in that frame's command stream: here every frame of a
     call comes with its moves (dust_hip_render_frames applies and commits them before the frame is prepared -- a scene image of its own in the
-    scene's ring of 8) and the frames still share launches. Against set_transform + commit + render_frame per frame on a twin scene: every plane,
+    scene's ring of 16) and the frames still share launches. Against set_transform + commit + render_frame per frame on a twin scene: every plane,
     motion vectors included, bit for bit; several calls in a row with nothing waited for in between (the ring comes round: a commit must not
     land on an image a frame that has not started yet still reads); and against the oracle."""
     w, h = 200, 120

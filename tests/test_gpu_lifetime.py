@@ -139,7 +139,7 @@ def test_commit_between_frames_changes_nothing_and_does_not_wait():
 
 def test_host_a_ring_of_commits_ahead_of_the_gpu():
     """A frame loop that never waits: set_transform + commit + render, 64 times over at a frame size the GPU needs longer for than
-    the host. The scene image lives in a ring of 8 copies; when the ring comes round the commit waits until the frame after the
+    the host. The scene image lives in a ring of 16 copies (8 when this test was written: 64 frames go round either several times); when the ring comes round the commit waits until the frame after the
     slot's last reader has STARTED (the word its first launch writes, DustHipContext::started) -- not for the whole queue.
     Every frame goes into the running mean (PASS_ACCUMULATE) and moves the instance by its own amount: a frame that saw a
     recycled image too early, or too late, changes the mean. Equal, bit for bit, to the same loop with a wait after every frame;
