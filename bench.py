@@ -558,6 +558,9 @@ def measure_curve(be, dist, args, lanes, shard):
         elif world > 1:
             gather.submit_view(targets[k % S][send[0]:send[1]])  # asynchronous gather, straight from the target
 
+    if batched:   # the cameras and skies of a call, as the arrays the C entry point takes: made once (one view, one sky)
+        cam_arr, sky_arr = (L.Camera * D)(*([cam] * D)), (L.Sky * D)(*([sky] * D))
+
     def steps_from(first, n):
         """steps first .. first + n - 1: one launch each, or (--frames-per-launch) D of them per dust_hip_render_frames call"""
         if not batched:
@@ -570,7 +573,7 @@ def measure_curve(be, dist, args, lanes, shard):
             ks = [first + i + j for j in range(m)]
             idx = [(1 + k) if bands else sharding.sample_frame_index(k, rank, world) for k in ks]
             if have_rows:
-                be.api.StandardPipeline.render_frames([lanes[(k % S) % D].pipe for k in ks], lanes[0].sc["scene"], cam, sky, passes, idx,
+                be.api.StandardPipeline.render_frames([lanes[(k % S) % D].pipe for k in ks], lanes[0].sc["scene"], cam_arr, sky_arr, passes, idx,
                                                       [synth.frame_rand(1, v) for v in idx], rows=rows if bands else (0, 0))
             i += m
 

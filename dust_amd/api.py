@@ -473,10 +473,18 @@ class StandardPipeline:
         cameras / skies: one per frame, or a single Camera / Sky for all of them. moves: per frame None or a list of (instance id, obj_to_world[12],
         prev_obj_to_world mat4[16] or None): what Scene.set_transform + Scene.commit would do before that frame."""
         n = len(pipes)
-        cams = (L.Camera * n)(*[(cameras if isinstance(cameras, L.Camera) else cameras[i]) for i in range(n)])
-        one_sky = isinstance(skies, L.Sky) or (not isinstance(skies, (list, tuple)))
-        sk = (L.Sky * n)(*[((skies if isinstance(skies, L.Sky) else sky_struct(skies)) if one_sky else
-                            (skies[i] if isinstance(skies[i], L.Sky) else sky_struct(skies[i]))) for i in range(n)])
+        # (a frame loop hands over ctypes arrays it made once -- at least n entries each: building them is most of this call's host time)
+        if isinstance(cameras, C.Array) and getattr(cameras, "_type_", None) is L.Camera:
+            cams = cameras
+        else:
+            cams = (L.Camera * n)(*[(cameras if isinstance(cameras, L.Camera) else cameras[i]) for i in range(n)])
+        if isinstance(skies, C.Array) and getattr(skies, "_type_", None) is L.Sky:
+            sk = skies
+        else:
+            one_sky = isinstance(skies, L.Sky) or (not isinstance(skies, (list, tuple)))
+            sk = (L.Sky * n)(*[((skies if isinstance(skies, L.Sky) else sky_struct(skies)) if one_sky else
+                                (skies[i] if isinstance(skies[i], L.Sky) else sky_struct(skies[i]))) for i in range(n)])
+        assert len(cams) >= n and len(sk) >= n
         fps = (L.FrameParams * n)(*[L.FrameParams(C.sizeof(L.FrameParams), passes, int(frame_indices[i]), int(rands[i]) & 0xFFFFFFFF, rows[0], rows[1], 0, 0)
                                     for i in range(n)])
         hs = (C.c_void_p * n)(*[p._h for p in pipes])
