@@ -2144,7 +2144,12 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
         // the boxes staged in LDS are frame 0's image's: a frame of another image (an instance moved in between) reads its own from memory
         if (join->image_of[i] != join->image_of[0]) join->frames[i].n_lds_boxes = 0;
       }
-      HIP_TRY(dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st));
+      if (dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st) != hipSuccess) {
+        // (the launch carries 8.5 KB of kernel arguments -- probed on this runtime, which takes 16 KB. Should a runtime refuse it: the prepared
+        //  frames one launch each, the same results)
+        (void)hipGetLastError();
+        for (uint32_t i = 0; i < join->n; ++i) HIP_TRY(dust::launch_primary_ao(join->frames[i], fgrid, fblock, false, st));
+      }
     } else {
       say_start(a);
       HIP_TRY(dust::launch_primary_ao(a, fgrid, fblock, count, st));
