@@ -2144,7 +2144,7 @@ static DustStatus render_frame_impl(DustHipPipeline* p, const DustHipScene* s, c
         // the boxes staged in LDS are frame 0's image's: a frame of another image (an instance moved in between) reads its own from memory
         if (join->image_of[i] != join->image_of[0]) join->frames[i].n_lds_boxes = 0;
       }
-      if (dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st) != hipSuccess) {
+      if ((tune.debug & 32u) || dust::launch_primary_ao_batch(join->frames, join->n, fgrid, fblock, st) != hipSuccess) {   // (DUST_HIP_DEBUG bit 32: as if refused)
         // (the launch carries 8.5 KB of kernel arguments -- probed on this runtime, which takes 16 KB. Should a runtime refuse it: the prepared
         //  frames one launch each, the same results)
         (void)hipGetLastError();

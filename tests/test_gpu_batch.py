@@ -325,3 +325,29 @@ def test_frames_of_a_moving_scene_share_a_launch(n, calls):
     res = P.compare_gbuffers(g, P.read_hip_gbuffer(batch[n - 1]))
     res["motion"] = 0   # (the oracle scene built at rest has no previous transforms: motion vectors are compared against the twin above)
     P.assert_parity(res)
+
+
+def test_a_refused_batched_launch_falls_back_to_a_launch_per_frame(monkeypatch):
+    """The batched launch carries 8.5 KB of kernel arguments (the runtime takes 16 KB: probed). Should a runtime refuse it, the prepared frames
+    are launched one by one -- DUST_HIP_DEBUG bit 32 takes that way: the same planes, moves included."""
+    monkeypatch.setenv("DUST_HIP_DEBUG", "32")
+    w, h = 160, 96
+    desc = P.small_scene(seed=9, n_models=3, n_instances=6)
+    ctx = api.Context(device=0)
+    sky = P.sky_state()
+    n5 = synth.stbn_unitvec3_cosine(layers=4)
+    scene_a, scene_b = P.hip_scene(ctx, desc), P.hip_scene(ctx, desc)
+    batch = _pipes(ctx, 4, w, h, n5)
+    cams = _cams(4)
+    xf = np.array(desc.instances[1][1], np.float32).reshape(3, 4).copy()
+    xf[:, 3] += 5.0
+    moves = [[], [(1, xf.reshape(12), _mat4(desc.instances[1][1]))], [], []]
+    api.StandardPipeline.render_frames(batch, scene_a, cams, sky, PAO, [1, 2, 3, 4], [5, 6, 7, 8], moves=moves)
+    monkeypatch.delenv("DUST_HIP_DEBUG")
+    single = _pipes(ctx, 4, w, h, n5)
+    for i in range(4):
+        for j, x, pv in moves[i]:
+            scene_b.set_transform(j, x, pv)
+            scene_b.commit()
+        single[i].render(scene_b, cams[i], sky, PAO, frame_index=1 + i, rand=5 + i)
+        _same(_planes(batch[i]), _planes(single[i]), f"fallback frame {i}")
