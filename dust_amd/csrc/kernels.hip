@@ -248,7 +248,14 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
 template <int MODE>
 __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao_batch(const BatchArgs) {
   ArgsRef lead = launch_args();
+#ifdef DUST_WAVE_TIMES   // (tools/wave_times.py --frames-per-launch: when the launch's waves start, get past staging and run out of tiles)
+  const unsigned long long wt0 = __builtin_amdgcn_s_memtime(), ww0 = wall_clock64();
+  unsigned long long wt_tiles = 0;
+#endif
   stage_roots_of<true>(lead);
+#ifdef DUST_WAVE_TIMES
+  const unsigned long long wt1 = __builtin_amdgcn_s_memtime();
+#endif
   uint32_t* cand = wave_cand_list(lead);
   LaneStats st = {0, 0, 0, 0, 0, 0}, st_sun = {0, 0, 0, 0, 0, 0}, st_ao = {0, 0, 0, 0, 0, 0};  // (never a counting build: dead)
   const uint32_t n_frames = lead.batch_frames;
@@ -271,10 +278,23 @@ __global__ void __launch_bounds__(DUST_PAO_THREADS, DUST_PAO_WAVES) k_primary_ao
     while (next_packet_of<true>(a0, wc, p)) {
       float hitT;
       uint32_t npk;
+#ifdef DUST_WAVE_TIMES
+      wt_tiles += 1;
+#endif
       primary_packet<MODE>(reload_args(a0), p, cand, st, false, hitT, npk);
       ao_packet<MODE>(reload_args(a0), p, cand, st_sun, st_ao, hitT, npk, mk(0, 0, 0));
     }
   }
+#ifdef DUST_WAVE_TIMES
+  if ((threadIdx.x & 63u) == 0) {
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w < 8192u) {
+      g_wave_times[w][0] = wt0; g_wave_times[w][1] = wt1; g_wave_times[w][2] = __builtin_amdgcn_s_memtime();
+      g_wave_times[w][3] = ww0; g_wave_times[w][4] = wall_clock64(); g_wave_times[w][5] = wt_tiles;
+      for (int k = 6; k < 12; ++k) g_wave_times[w][k] = 0;
+    }
+  }
+#endif
   prof_end();
 }
 

@@ -134,6 +134,7 @@ unset DUST_HIP_RAY_STREAM
 python "$R/tools/tile_costs.py" > "$out/${tag}_tile_costs.txt" 2>&1
 python "$R/tools/diag/surfel_items.py" 40 > "$out/${tag}_surfel_items.txt" 2>&1
 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times.txt" 2>&1
+DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 320 --frames-per-launch 8 > "$out/${tag}_wave_times_8_per_launch.txt" 2>&1
 DUST_HIP_EQUAL_BANDS=1 DUST_HIP_LIB=$R/dust_amd/libdust_hip_wt.so python "$R/tools/wave_times.py" 300 > "$out/${tag}_wave_times_equal_bands.txt" 2>&1
 wc -l "$out/${tag}_pmc.txt" "$out/${tag}_pmc_gi.txt"
 rm -rf "$out/prof_$tag" "$out/pmc_$tag"
