@@ -651,7 +651,9 @@ def measure_curve(be, dist, args, lanes, shard):
     # --frames-per-launch: did the frames share launches? (dust_hip_render_frames enqueues frames that do not qualify one after the other, with the
     # same results: a launch of D frames lasts about D steps, a frame's own launch one.) If they did not, the line says so and accounts per frame.
     launch_frames = (args.steps / -(-args.steps // D)) if batched else 1.0
-    shared_launches = batched and ms[0] > 0.6 * launch_frames * (elapsed / args.steps * 1e3)
+    # (threshold: the geometric mean of the two cases' ratios, 1 and 1 / D -- a host stall of several milliseconds inside the timed region, which
+    #  stretches ms_per_step, does not flip it)
+    shared_launches = batched and ms[0] > (1.0 / D) ** 0.5 * launch_frames * (elapsed / args.steps * 1e3)
     if batched and not shared_launches:
         sys.stderr.write("bench.py: --frames-per-launch: the frames did not share a launch (kernel time of ONE frame); accounted per frame\n")
         launch_frames = 1.0
@@ -818,7 +820,7 @@ def measure_moving(be, args, lane, noise5, steps, settle=48, fps=60.0, swing=0.1
         still_ms.append((time.perf_counter() - t1) / 40 * 1e3)
     speed = swing * 2.0 * math.pi / period
     k_ms = lm[0] / ln[0] if ln[0] else None
-    if fpl > 1 and k_ms and k_ms < 0.6 * fpl * (dt / steps * 1e3):   # (the frames did not share launches: accounted per frame)
+    if fpl > 1 and k_ms and k_ms < (1.0 / fpl) ** 0.5 * fpl * (dt / steps * 1e3):   # (the frames did not share launches: accounted per frame)
         fpl = 1
     achieved = (algo / steps * fpl) / (k_ms * 1e-3) / 1e9 if k_ms else None
     kname = "k_primary_ao_batch" if fpl > 1 else "k_primary_ao"
