@@ -462,9 +462,18 @@ class StandardPipeline:
     def render(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0), surfel_shard=(0, 0)):
         """sky: 56 floats, or a DustHipSky made once with api.sky_struct() (a frame loop: the conversion is most of this call's host time).
         surfel_shard: (rank, world) -- with PASS_SURFEL | PASS_GI_SHARDED the pass only traces rank's share of the ordered pool (Comm.gi_surfel_exchange completes it)"""
+        self.frame_call(scene, camera, sky, passes, frame_index, rand, rows, surfel_shard)()
+
+    def frame_call(self, scene, camera, sky, passes, frame_index=1, rand=0, rows=(0, 0), surfel_shard=(0, 0)):
+        """-> a callable that makes ONE dust_hip_render_frame call with the arguments marshalled HERE (a frame loop that knows its frames ahead builds
+        the calls first: what is left per call is the C entry point -- a band-sized step of an N-GPU job is 30 us, of which render()'s marshalling was a third)"""
         s = sky if isinstance(sky, L.Sky) else sky_struct(sky)
         fp = L.FrameParams(C.sizeof(L.FrameParams), passes, frame_index, rand & 0xFFFFFFFF, rows[0], rows[1], surfel_shard[0], surfel_shard[1])
-        L.check(self._lib.dust_hip_render_frame(self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp)))
+        fn, h, sh, cam_ref, sky_ref, fp_ref, check = self._lib.dust_hip_render_frame, self._h, scene._h, C.byref(camera), C.byref(s), C.byref(fp), L.check
+
+        def call(_keep=(self, scene, camera, s, fp)):
+            check(fn(h, sh, cam_ref, sky_ref, fp_ref))
+        return call
 
     @staticmethod
     def render_frames(pipes, scene, cameras, skies, passes, frame_indices, rands, rows=(0, 0), moves=None):
